@@ -1,0 +1,123 @@
+"""ctypes wrapper of oracle/libflowz_oracle.so (compiled scalar closures) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+All entry points take/return numpy float32 arrays of time-major frames [T, n_streams, n_wires]
+(the device layout) unless `stream_major=True` ([n_streams, T, n_wires], the CPU-friendly
+layout used for the timed CPU baseline).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+F32 = np.float32
+_fp = ctypes.POINTER(ctypes.c_float)
+_pd = ctypes.c_ssize_t
+
+
+class Coef(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ("b0", "b1", "b2", "a1", "a2")]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libflowz_oracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libflowz_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _strides(T, ns, nw, stream_major):
+    # (stream stride, time stride) in floats
+    return (T * nw, nw) if stream_major else (nw, ns * nw)
+
+
+def _prep(x, n_in, stream_major):
+    x = np.ascontiguousarray(x, dtype=F32)
+    if x.ndim == 2:
+        x = x[:, :, None]
+    if stream_major:
+        ns, T, nw = x.shape
+    else:
+        T, ns, nw = x.shape
+    assert nw == n_in, (nw, n_in)
+    return x, T, ns
+
+
+def _coefs(cs):
+    arr = (Coef * len(cs))()
+    for i, c in enumerate(cs):
+        arr[i] = Coef(*[float(F32(v)) for v in c])
+    return arr
+
+
+def _run(fname, pre_args, x, n_in, n_out, stream_major):
+    x, T, ns = _prep(x, n_in, stream_major)
+    y = np.empty((ns, T, n_out) if stream_major else (T, ns, n_out), F32)
+    xss, xts = _strides(T, ns, n_in, stream_major)
+    yss, yts = _strides(T, ns, n_out, stream_major)
+    getattr(lib(), fname)(*pre_args, _p(x), _pd(xss), _pd(xts), _p(y), _pd(yss), _pd(yts),
+                          ctypes.c_long(ns), ctypes.c_long(T))
+    return y
+
+
+def df1_cascade(coefs, x, stream_major=False):
+    return _run("fzo_df1_cascade", (_coefs(coefs), ctypes.c_int(len(coefs))), x, 1, 1, stream_major)
+
+
+def df2(c, x, stream_major=False):
+    return _run("fzo_df2", (_coefs([c]),), x, 1, 1, stream_major)
+
+
+def df1t(c, x, stream_major=False):
+    return _run("fzo_df1t", (_coefs([c]),), x, 1, 1, stream_major)
+
+
+def df2t_flowz(c, x, stream_major=False):
+    return _run("fzo_df2t_flowz", (_coefs([c]),), x, 1, 1, stream_major)
+
+
+def integrator(x, stream_major=False):
+    return _run("fzo_integrator", (), x, 1, 1, stream_major)
+
+
+def one_quad(x, c1=0.9, c2=0.8, stream_major=False):
+    return _run("fzo_one_quad", (ctypes.c_float(float(F32(c1))), ctypes.c_float(float(F32(c2)))), x, 1, 1, stream_major)
+
+
+def cross_wire(x, c1=0.9, c2=0.2, stream_major=False):
+    return _run("fzo_cross_wire", (ctypes.c_float(float(F32(c1))), ctypes.c_float(float(F32(c2)))), x, 1, 2, stream_major)
+
+
+def par4_sum(coefs4, x, fanout=False, stream_major=False):
+    return _run("fzo_par4_sum", (_coefs(coefs4), ctypes.c_int(int(fanout))), x, 1 if fanout else 4, 1, stream_major)
+
+
+def osc_chain(params, x, n_stage=6, stream_major=False):
+    """params: [1+5*n_stage, n_streams] planar per-stream coefficients."""
+    params = np.ascontiguousarray(params, dtype=F32)
+    assert params.shape[0] == 1 + 5 * n_stage
+    return _run("fzo_osc_chain", (_p(params), _pd(params.shape[1]), ctypes.c_int(n_stage)), x, 1, 1, stream_major)
+
+
+def synth_fill(seed, stream0, n_streams, T, n_wires=1, t0=0, stream_major=False):
+    out = np.empty((n_streams, T, n_wires) if stream_major else (T, n_streams, n_wires), F32)
+    ss, ts = _strides(T, n_streams, n_wires, stream_major)
+    lib().fzo_synth_fill(_p(out), _pd(ss), _pd(ts), ctypes.c_uint32(seed), ctypes.c_uint64(stream0),
+                         ctypes.c_long(n_streams), ctypes.c_long(T), ctypes.c_int(n_wires), ctypes.c_uint64(t0))
+    return out

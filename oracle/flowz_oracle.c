@@ -1,0 +1,231 @@
+/* CPU ORACLE (compiled scalar closures) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  Nothing under zignal_amd/ or include/ links or calls it.
+ *
+ * What it restates: what the reference's compile()-callable computes per call for the
+ * BASELINE workload graphs, i.e. stateful_lambda::operator() (flowz/flowz.hpp:1225-1229)
+ * after template inlining: a scalar closure with zero-initialised float state
+ * (flowz.hpp:1245), one IEEE float32 rounding per operator in the expression tree's
+ * association order (proto::_default, flowz.hpp:769-772), shift-register delay lines
+ * (rotate_push_back, flowz.hpp:130-148).  The per-sample recurrences are the normative
+ * traces of SURVEY.md 3.5, each derived from the cited reference expression.
+ * "Mode A, reference-faithful" (BASELINE.md 3): one closure per stream, one call per sample.
+ *
+ * Build: gcc -O3 -ffp-contract=off (no -march, no -ffast-math), see oracle/Makefile --
+ * the reference's flags are `-O3 --std=c++1y` without -march (CMakeLists.txt:18).
+ *
+ * Parity status: PINNED through tests/test_oracle_golden.py + tests/test_oracle_c.py:
+ * each closure here is bit-compared with the generic Python oracle (which is itself pinned
+ * to test/tests.cpp known answers) and with the reference's own hand-written lambdas
+ * built from the reference sources (oracle/build_ref.sh, tests/golden/ref_biquad_vectors.json).
+ *
+ * Addressing: element (stream s, time t, wire w) of a signal lives at
+ *     p[s*ss + t*ts + w]           (ss/ts in floats)
+ * so the same code walks time-major device-style frames (ss = n_wires, ts = n_streams*n_wires)
+ * and per-stream contiguous arrays (ss = T*n_wires, ts = n_wires).
+ */
+#include <stddef.h>
+#include <stdint.h>
+
+typedef struct { float b0, b1, b2, a1, a2; } fzo_coef;
+
+/* ---- DF1  `fwd |= bwd`  (test/benchmark.cpp:25-26,32):
+ *   f = (b0*x + b1*x1) + b2*x2 ;  y = (f + a1*y1) + a2*y2                               */
+typedef struct { float x1, x2, y1, y2; } fzo_df1_state;
+
+static inline float df1_call(const fzo_coef* c, fzo_df1_state* s, float x0)
+{
+   float f = (c->b0 * x0 + c->b1 * s->x1) + c->b2 * s->x2;
+   float y = (f + c->a1 * s->y1) + c->a2 * s->y2;
+   s->x2 = s->x1; s->x1 = x0;          /* rotate_push_back, front-panel / sequence node */
+   s->y2 = s->y1; s->y1 = y;           /* rotate_push_back, binary_feedback node :1067  */
+   return y;
+}
+
+#define FZO_MAX_STAGES 64
+
+/* n_stage x DF1 in series.  coef: [n_stage] uniform, or per-stream when coef_ss != 0
+ * (coefficient j of stage k for stream s at coef_ps[(k*5+j)*coef_ss + s]).              */
+void fzo_df1_cascade(const fzo_coef* coef, int n_stage,
+                     const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                     float* y, ptrdiff_t yss, ptrdiff_t yts,
+                     long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      fzo_df1_state st[FZO_MAX_STAGES] = {{0}};
+      const float* xp = x + s * xss;
+      float* yp = y + s * yss;
+      for (long t = 0; t < T; ++t) {
+         float v = xp[t * xts];
+         for (int k = 0; k < n_stage; ++k) v = df1_call(&coef[k], &st[k], v);
+         yp[t * yts] = v;
+      }
+   }
+}
+
+/* ---- DF2  `bwd |= fwd` (test/benchmark.cpp:62):
+ *   u = (x + a1*u1) + a2*u2 ;  y = (b0*u + b1*u1) + b2*u2                               */
+void fzo_df2(const fzo_coef* c, const float* x, ptrdiff_t xss, ptrdiff_t xts,
+             float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      float u1 = 0.f, u2 = 0.f;
+      for (long t = 0; t < T; ++t) {
+         float x0 = x[s * xss + t * xts];
+         float u = (x0 + c->a1 * u1) + c->a2 * u2;
+         float o = (c->b0 * u + c->b1 * u1) + c->b2 * u2;
+         u2 = u1; u1 = u;
+         y[s * yss + t * yts] = o;
+      }
+   }
+}
+
+/* ---- DF1T `~bwdt |= fwdt` (test/benchmark.cpp:79-81,87); na1 = -a1, na2 = -a2 are
+ *   negated in C++ before they become terminals:
+ *   u = w1 + x ; y = v1 + b0*u ; v1' = v2 + b1*u ; v2' = b2*u ; w1' = w2 + na1*u ; w2' = na2*u */
+void fzo_df1t(const fzo_coef* c, const float* x, ptrdiff_t xss, ptrdiff_t xts,
+              float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   const float na1 = -c->a1, na2 = -c->a2;
+   for (long s = 0; s < n_streams; ++s) {
+      float v1 = 0.f, v2 = 0.f, w1 = 0.f, w2 = 0.f;
+      for (long t = 0; t < T; ++t) {
+         float x0 = x[s * xss + t * xts];
+         float u = w1 + x0;
+         float o = v1 + c->b0 * u;
+         float nv1 = v2 + c->b1 * u, nv2 = c->b2 * u;
+         float nw1 = w2 + na1 * u, nw2 = na2 * u;
+         v1 = nv1; v2 = nv2; w1 = nw1; w2 = nw2;
+         y[s * yss + t * yts] = o;
+      }
+   }
+}
+
+/* ---- DF2T as the Flowz GRAPH `fwdt |= ~bwdt` (test/benchmark.cpp:113) -- NOT the merged
+ * two-state lambda of :116-126, which rounds differently:
+ *   f = v1 + b0*x ; v1' = v2 + b1*x ; v2' = b2*x ; y = w1 + f ; w1' = w2 + na1*y ; w2' = na2*y */
+void fzo_df2t_flowz(const fzo_coef* c, const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                    float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   const float na1 = -c->a1, na2 = -c->a2;
+   for (long s = 0; s < n_streams; ++s) {
+      float v1 = 0.f, v2 = 0.f, w1 = 0.f, w2 = 0.f;
+      for (long t = 0; t < T; ++t) {
+         float x0 = x[s * xss + t * xts];
+         float f = v1 + c->b0 * x0;
+         float nv1 = v2 + c->b1 * x0, nv2 = c->b2 * x0;
+         float o = w1 + f;
+         float nw1 = w2 + na1 * o, nw2 = na2 * o;
+         v1 = nv1; v2 = nv2; w1 = nw1; w2 = nw2;
+         y[s * yss + t * yts] = o;
+      }
+   }
+}
+
+/* ---- integrator `~(_1[_1] + _2)` (test/tests.cpp:130): y = y1 + x */
+void fzo_integrator(const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                    float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      float y1 = 0.f;
+      for (long t = 0; t < T; ++t) { y1 = y1 + x[s * xss + t * xts]; y[s * yss + t * yts] = y1; }
+   }
+}
+
+/* ---- one_quad `~(0.9f*_1[_1] - 0.8f*_1[_2] + _2)`
+ * (experimental_steps/multi_wires_feedback.cpp:705): y = (c1*y1 - c2*y2) + x */
+void fzo_one_quad(float c1, float c2, const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                  float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      float y1 = 0.f, y2 = 0.f;
+      for (long t = 0; t < T; ++t) {
+         float o = (c1 * y1 - c2 * y2) + x[s * xss + t * xts];
+         y2 = y1; y1 = o;
+         y[s * yss + t * yts] = o;
+      }
+   }
+}
+
+/* ---- cross_wire `~( (_2[_1],_3,_1[_1]) |= (.9f*_1 + _2) | (.2f*_1) )`
+ * (...feedback.cpp:721): u1' = c1*u2 + x ; u2' = c2*u1 ; two output wires (new u1, u2) */
+void fzo_cross_wire(float c1, float c2, const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                    float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      float u1 = 0.f, u2 = 0.f;
+      for (long t = 0; t < T; ++t) {
+         float n1 = c1 * u2 + x[s * xss + t * xts];
+         float n2 = c2 * u1;
+         u1 = n1; u2 = n2;
+         y[s * yss + t * yts + 0] = n1;
+         y[s * yss + t * yts + 1] = n2;
+      }
+   }
+}
+
+/* ---- config 3: (bq|bq|bq|bq) |= (_1+_2+_3+_4), 4 DF1 boxes, frames of 4 input wires
+ * (wiring pattern experimental_steps/multi_wires_with_parallel_and_delay.cpp:573-577):
+ *   y = ((q0 + q1) + q2) + q3.   fanout != 0: all four boxes read wire 0 (1-wire frames). */
+void fzo_par4_sum(const fzo_coef* coef4, int fanout,
+                  const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                  float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      fzo_df1_state st[4] = {{0}};
+      for (long t = 0; t < T; ++t) {
+         const float* f = x + s * xss + t * xts;
+         float q0 = df1_call(&coef4[0], &st[0], f[0]);
+         float q1 = df1_call(&coef4[1], &st[1], fanout ? f[0] : f[1]);
+         float q2 = df1_call(&coef4[2], &st[2], fanout ? f[0] : f[2]);
+         float q3 = df1_call(&coef4[3], &st[3], fanout ? f[0] : f[3]);
+         y[s * yss + t * yts] = ((q0 + q1) + q2) + q3;
+      }
+   }
+}
+
+/* ---- config 4: resonator `~(k*_1[_1] - _1[_2] + _2)` |= n x DF1, per-stream coefficients.
+ * params: [1 + 5*n_stage][n_streams] planar (param j of stream s at params[j*pss + s]):
+ * param 0 = k, then b0,b1,b2,a1,a2 per stage.   r = (k*r1 - r2) + x                      */
+void fzo_osc_chain(const float* params, ptrdiff_t pss, int n_stage,
+                   const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                   float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      fzo_coef c[FZO_MAX_STAGES];
+      fzo_df1_state st[FZO_MAX_STAGES] = {{0}};
+      const float k = params[s];
+      for (int j = 0; j < n_stage; ++j) {
+         const float* p = params + (ptrdiff_t)(1 + 5 * j) * pss + s;
+         c[j].b0 = p[0]; c[j].b1 = p[pss]; c[j].b2 = p[2 * pss]; c[j].a1 = p[3 * pss]; c[j].a2 = p[4 * pss];
+      }
+      float r1 = 0.f, r2 = 0.f;
+      for (long t = 0; t < T; ++t) {
+         float v = (k * r1 - r2) + x[s * xss + t * xts];
+         r2 = r1; r1 = v;
+         for (int j = 0; j < n_stage; ++j) v = df1_call(&c[j], &st[j], v);
+         y[s * yss + t * yts] = v;
+      }
+   }
+}
+
+/* ---- synthetic input, identical to oracle/flowz_oracle.py: synth_input -------------- */
+static inline uint32_t fmix32(uint32_t h)
+{
+   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+   return h;
+}
+
+void fzo_synth_fill(float* dst, ptrdiff_t ss, ptrdiff_t ts, uint32_t seed,
+                    uint64_t stream0, long n_streams, long T, int n_wires, uint64_t t0)
+{
+   for (long s = 0; s < n_streams; ++s)
+      for (long t = 0; t < T; ++t)
+         for (int w = 0; w < n_wires; ++w) {
+            uint64_t sid = (stream0 + (uint64_t)s) * (uint64_t)n_wires + (uint64_t)w;
+            uint32_t h = seed ^ (uint32_t)(sid * 0x9E3779B9ull) ^ (uint32_t)((t0 + (uint64_t)t) * 0x85EBCA6Bull);
+            h = fmix32(fmix32(h));
+            dst[s * ss + t * ts + w] = (float)(int32_t)(h >> 8) * 0x1p-23f - 1.0f;
+         }
+}

@@ -1,0 +1,341 @@
+"""CPU ORACLE for Flowz flow-graph evaluation -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product path (zignal_amd/, include/) never does: it fails loudly when the
+HIP library is missing.
+
+What this restates
+------------------
+The per-sample evaluator of the reference, /root/reference/flowz/flowz.hpp:
+
+* arity rules            input_arity  :162-214, output_arity :217-246
+* wire routing           sequence :960-1001, parallel :1076-1101, channel :765-768,
+                         binary_feedback :1031-1074 (with the arity-table routing, see
+                         SURVEY.md App. C.1 -- the shipped `std::min(0, ...)` drop is a
+                         reference quirk and such graphs are excluded from parity)
+* delay lines            rotate_push_back :130-148 (shift register, newest at the back),
+                         place_delay :950-958 (read `xs[N-n]` = value n samples ago),
+                         zero-initialised float state :1245, depth = max delay read on the
+                         wire (max_input_delays :502, build_state :685-725)
+* arithmetic             proto::_default<eval_it> :769-772 -- the built-in C++ operator on
+                         the evaluated children: one IEEE float32 rounding per operator, the
+                         user's association order, no FMA contraction (CMakeLists.txt:18)
+* call protocol          stateful_lambda::operator() :1225-1229 / call_impl :1193-1201:
+                         N inputs -> M outputs per call, state persists across calls
+
+How it is written (deliberately NOT like the product): the expression tree is elaborated
+once into persistent lazy `Wire` objects; every sample forces the output wires by demand
+(memoised recursion), and only afterwards pushes the current value of every delayed wire
+into its FIFO -- "all reads see the values pushed in previous samples; pushes happen after
+the consumer was evaluated" (flowz.hpp:994, :1067).  The product instead lowers to a
+CSE'd, topologically sorted flat DAG with register/LDS delay lines.  Values are numpy
+float32 arrays with one element per stream, so many independent streams are evaluated per
+Python-level operation.
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks this oracle against every
+evaluation known-answer of the reference's own test/tests.cpp (:88-178, transcribed into
+tests/golden/tests_cpp_known_answers.json) and against impulse/noise responses of the
+reference's Boost-free hand-written biquads (test/benchmark.cpp:35-126,
+experimental_steps/multi_wires_feedback.cpp:768-775) compiled from the reference sources
+where they lie (oracle/build_ref.sh -> oracle/_ref/, vectors committed as
+tests/golden/ref_biquad_vectors.json).
+
+Graph notation ("s-expressions", plain nested tuples; a shared data format, no code):
+    ('in', i)            placeholder _i                     flowz.hpp:1252-1257
+    ('del', i, n)        delayed placeholder _i[_n]         flowz.hpp:84-85
+    ('lit', v)           literal terminal (float32)         flowz.hpp:68-72
+    ('param', k)         per-stream coefficient k (block-constant std::ref analogue,
+                         flowz/README.md:42-61)
+    ('add'|'sub'|'mul'|'div', a, b), ('neg', a)             flowz.hpp:769-772
+    ('chan', a, b)       a , b                              flowz.hpp:90
+    ('par', a, b)        a | b                              flowz.hpp:91
+    ('seq', a, b)        a |= b                             flowz.hpp:92
+    ('fb', a)            ~a                                 flowz.hpp:93
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+_ARITH = ("add", "sub", "mul", "div")
+
+
+class GraphError(ValueError):
+    pass
+
+
+# ----------------------------------------------------------------------------------------
+# arity rules (flowz.hpp:162-246; cross-checked with experimental_steps/flowz2.cpp:65-78)
+# ----------------------------------------------------------------------------------------
+
+def input_arity(e) -> int:
+    k = e[0]
+    if k in ("in", "del"):
+        return int(e[1])                      # :163-170  arity of _i is i
+    if k in ("lit", "param"):
+        return 0                              # :171-174
+    if k == "fb":                             # :175-181
+        return max(0, input_arity(e[1]) - output_arity(e[1]))
+    if k == "par":                            # :195-198
+        return input_arity(e[1]) + input_arity(e[2])
+    if k == "seq":                            # :199-208
+        return input_arity(e[1]) + max(0, input_arity(e[2]) - output_arity(e[1]))
+    if k in _ARITH or k == "chan":            # :209-212  nary_expr -> max over children
+        return max(input_arity(e[1]), input_arity(e[2]))
+    if k == "neg":
+        return input_arity(e[1])
+    raise GraphError(f"unknown node {k!r}")
+
+
+def output_arity(e) -> int:
+    k = e[0]
+    if k == "chan":                           # :218-221
+        return output_arity(e[1]) + output_arity(e[2])
+    if k == "fb":                             # :222-225
+        return output_arity(e[1])
+    if k == "par":                            # :230-233
+        return output_arity(e[1]) + output_arity(e[2])
+    if k == "seq":                            # :234-243
+        return output_arity(e[2]) + max(0, output_arity(e[1]) - input_arity(e[2]))
+    return 1                                  # :244
+
+
+def max_input_delays(e) -> tuple:
+    """Per external input wire: deepest delayed read (flowz.hpp:443-502).
+
+    Tuple length follows the reference's generator (`make_arity`, :286-301): a leaf `_i`
+    contributes i entries, so the tuple may be shorter than input_arity for wires that are
+    only consumed by a later box."""
+    k = e[0]
+
+    def zipmax(a, b):                         # max_delay_of_wires :364-379
+        n = min(len(a), len(b))
+        return tuple(max(x, y) for x, y in zip(a[:n], b[:n])) + tuple(a[n:]) + tuple(b[n:])
+
+    if k == "del":
+        return (0,) * (e[1] - 1) + (int(e[2]),)
+    if k == "in":
+        return (0,) * e[1]
+    if k in ("lit", "param"):
+        return ()
+    if k == "fb":                             # :459-465
+        return max_input_delays(e[1])[output_arity(e[1]):]
+    if k == "par":                            # :479-482
+        return max_input_delays(e[1]) + max_input_delays(e[2])
+    if k == "seq":                            # :483-492
+        return max_input_delays(e[1]) + max_input_delays(e[2])[output_arity(e[1]):]
+    if k == "neg":
+        return max_input_delays(e[1])
+    if k in _ARITH or k == "chan":            # :493-496 fold with max-zip
+        return zipmax(max_input_delays(e[2]), max_input_delays(e[1]))
+    raise GraphError(f"unknown node {k!r}")
+
+
+# ----------------------------------------------------------------------------------------
+# lazy wires
+# ----------------------------------------------------------------------------------------
+
+class _Wire:
+    """One signal wire.  `fn()` computes the value of the current sample on demand."""
+
+    __slots__ = ("fn", "stamp", "val", "busy", "depth", "fifo")
+
+    def __init__(self, fn=None):
+        self.fn = fn
+        self.stamp = -1
+        self.val = None
+        self.busy = False
+        self.depth = 0          # deepest delayed read of this wire
+        self.fifo = None        # list of `depth` arrays, fifo[-1] = newest (rotate_push_back)
+
+
+class FlowzOracle:
+    """compile()-callable of the reference for `n_streams` independent streams at once.
+
+    step(*inputs) == one call of stateful_lambda::operator() per stream (flowz.hpp:1225)."""
+
+    def __init__(self, expr, n_streams: int = 1, params=None):
+        self.expr = expr
+        self.n_streams = int(n_streams)
+        self.n_in = input_arity(expr)
+        self.n_out = output_arity(expr)
+        self._t = 0
+        self._wires = []
+        self._params = None
+        if params is not None:
+            p = np.asarray(params, dtype=F32)
+            if p.ndim == 1:
+                p = p[:, None]
+            self._params = np.ascontiguousarray(np.broadcast_to(p, (p.shape[0], self.n_streams)))
+        self._cur_in = [None] * self.n_in
+        # add_front_panel (:261-277): one loose wire per external input
+        self._inputs = [self._new(self._mk_input(i)) for i in range(self.n_in)]
+        outs = self._elab(expr, self._inputs)
+        if len(outs) != self.n_out:
+            raise GraphError(f"arity table says {self.n_out} outputs, routing produced {len(outs)}")
+        self._outs = outs
+        self._delayed = [w for w in self._wires if w.depth > 0]
+        for w in self._delayed:                      # zero-initialised float state (:1245)
+            w.fifo = [np.zeros(self.n_streams, F32) for _ in range(w.depth)]
+
+    # -- construction ------------------------------------------------------------------
+    def _new(self, fn=None):
+        w = _Wire(fn)
+        self._wires.append(w)
+        return w
+
+    def _mk_input(self, i):
+        return lambda: self._cur_in[i]
+
+    def _value(self, w: _Wire):
+        if w.stamp == self._t:
+            return w.val
+        if w.busy:
+            raise GraphError("delay-free feedback loop (every cycle needs >= 1 delayed read)")
+        w.busy = True
+        try:
+            v = w.fn()
+        finally:
+            w.busy = False
+        w.val = v
+        w.stamp = self._t
+        return v
+
+    def _elab(self, e, ins):
+        """Elaborate node `e` fed by wires `ins`; returns its output wires."""
+        k = e[0]
+        if k == "in":                                           # place_the_holder :941-948
+            i = e[1]
+            if i > len(ins):
+                raise GraphError(f"placeholder _{i} has no wire to bind to")
+            return [ins[i - 1]]
+        if k == "del":                                          # place_delay :950-958
+            i, n = e[1], int(e[2])
+            if n < 1:
+                raise GraphError("delay must be >= 1")
+            if i > len(ins):
+                raise GraphError(f"placeholder _{i} has no wire to bind to")
+            src = ins[i - 1]
+            src.depth = max(src.depth, n)
+            return [self._new(lambda src=src, n=n: src.fifo[len(src.fifo) - n])]
+        if k == "lit":
+            c = F32(e[1])
+            return [self._new(lambda c=c: np.full(self.n_streams, c, F32))]
+        if k == "param":
+            idx = int(e[1])
+            return [self._new(lambda idx=idx: self._params[idx])]
+        if k in _ARITH:                                         # _default<eval_it> :769-772
+            a = self._one(e[1], ins)
+            b = self._one(e[2], ins)
+            if k == "add":
+                f = lambda a=a, b=b: self._value(a) + self._value(b)
+            elif k == "sub":
+                f = lambda a=a, b=b: self._value(a) - self._value(b)
+            elif k == "mul":
+                f = lambda a=a, b=b: self._value(a) * self._value(b)
+            else:
+                f = lambda a=a, b=b: self._value(a) / self._value(b)
+            return [self._new(f)]
+        if k == "neg":
+            a = self._one(e[1], ins)
+            return [self._new(lambda a=a: -self._value(a))]
+        if k == "chan":                                         # :765-768 same inputs to both
+            return self._elab(e[1], ins) + self._elab(e[2], ins)
+        if k == "par":                                          # :1087-1099 split at in(a)
+            na = input_arity(e[1])
+            nb = input_arity(e[2])
+            if na + nb > len(ins):
+                raise GraphError("parallel box needs more wires than available")
+            return self._elab(e[1], ins[:na]) + self._elab(e[2], ins[na:na + nb])
+        if k == "seq":                                          # :974-999
+            na = input_arity(e[1])
+            nb = input_arity(e[2])
+            ao = self._elab(e[1], ins[:na])
+            bi = ao + ins[na:]
+            bo = self._elab(e[2], bi)
+            return bo + ao[nb:]
+        if k == "fb":                                           # binary_feedback :1031-1074
+            n_fb = output_arity(e[1])
+            fwd = [self._new(None) for _ in range(n_fb)]
+            ao = self._elab(e[1], fwd + ins)
+            if len(ao) != n_fb:
+                raise GraphError("feedback body arity mismatch")
+            for f, o in zip(fwd, ao):
+                f.fn = (lambda o=o: self._value(o))
+            return ao
+        raise GraphError(f"unknown node {k!r}")
+
+    def _one(self, e, ins):
+        ws = self._elab(e, ins)
+        if len(ws) != 1:
+            raise GraphError("arithmetic operand must have exactly one output wire")
+        return ws[0]
+
+    # -- evaluation ----------------------------------------------------------------------
+    def step(self, *inputs):
+        """One sample for every stream.  inputs: n_in scalars or (n_streams,) arrays."""
+        if len(inputs) != self.n_in:
+            raise GraphError(f"expected {self.n_in} inputs, got {len(inputs)}")
+        self._t += 1
+        for i, x in enumerate(inputs):
+            self._cur_in[i] = np.ascontiguousarray(
+                np.broadcast_to(np.asarray(x, dtype=F32), (self.n_streams,)))
+        outs = [np.array(self._value(w), dtype=F32, copy=True) for w in self._outs]
+        # consumers first, pushes last (:994, :1067)
+        new = [np.array(self._value(w), dtype=F32, copy=True) for w in self._delayed]
+        for w, v in zip(self._delayed, new):
+            w.fifo.pop(0)               # rotate_push_back :130-137
+            w.fifo.append(v)
+        return tuple(outs)
+
+    def run(self, x):
+        """x: float32 [T, n_streams, n_in] (time-major frames) -> [T, n_streams, n_out]."""
+        x = np.asarray(x, dtype=F32)
+        if x.ndim == 2 and self.n_in == 1:
+            x = x[:, :, None]
+        T = x.shape[0]
+        y = np.empty((T, self.n_streams, self.n_out), F32)
+        with np.errstate(all="ignore"):
+            for t in range(T):
+                o = self.step(*[x[t, :, i] for i in range(self.n_in)])
+                for j in range(self.n_out):
+                    y[t, :, j] = o[j]
+        return y
+
+
+def compile(expr, n_streams: int = 1, params=None) -> FlowzOracle:  # noqa: A001 (mirrors flowz::compile)
+    return FlowzOracle(expr, n_streams, params)
+
+
+# ----------------------------------------------------------------------------------------
+# deterministic synthetic input (SURVEY.md 8d / BASELINE.md 3): integer hash -> [-1, 1)
+# ----------------------------------------------------------------------------------------
+
+def hash32(seed, s, t):
+    """murmur3 fmix32 of seed ^ s*0x9E3779B9 ^ t*0x85EBCA6B, applied twice (uint32 exact)."""
+    with np.errstate(over="ignore"):
+        s = np.asarray(s, dtype=np.uint64)
+        t = np.asarray(t, dtype=np.uint64)
+        h = (np.uint64(seed) ^ (s * np.uint64(0x9E3779B9)) ^ (t * np.uint64(0x85EBCA6B))) & np.uint64(0xFFFFFFFF)
+        for _ in range(2):
+            h ^= h >> np.uint64(16)
+            h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+            h ^= h >> np.uint64(13)
+            h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+            h ^= h >> np.uint64(16)
+    return h.astype(np.uint32)
+
+
+def u32_to_unit(h):
+    """(float)(int32)(h >> 8) * 2^-23 - 1  in [-1, 1), exact in float32."""
+    return ((h >> np.uint32(8)).astype(np.int32).astype(F32) * F32(2.0 ** -23) - F32(1.0)).astype(F32)
+
+
+def synth_input(seed, streams, T, n_wires=1, t0=0):
+    """Frames [T, len(streams), n_wires]; element (t, s, w) hashes (seed, s*n_wires + w, t0+t)."""
+    streams = np.asarray(streams, dtype=np.uint64)
+    t = (np.arange(T, dtype=np.uint64) + np.uint64(t0))[:, None, None]
+    w = np.arange(n_wires, dtype=np.uint64)[None, None, :]
+    sid = streams[None, :, None] * np.uint64(n_wires) + w
+    return u32_to_unit(hash32(seed, sid, t))

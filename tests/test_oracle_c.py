@@ -1,0 +1,88 @@
+"""The compiled scalar closures (oracle/flowz_oracle.c) vs the generic Python oracle and the
+reference-built golden vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import graphs as G
+import workloads as W
+from oracle import coracle as C
+from oracle import flowz_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = json.load(open(os.path.join(HERE, "golden", "ref_biquad_vectors.json")))
+REFC = (G.B0, G.B1, G.B2, G.A1, G.A2)
+
+
+def bits(hexlist):
+    return np.array([int(h, 16) for h in hexlist], np.uint32).view(np.float32)
+
+
+def same(a, b):
+    return np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("drive", ["dirac", "noise"])
+def test_c_closures_vs_reference_lambdas(drive):
+    x = bits(REF["inputs"][drive])[:, None, None]
+    out = REF["outputs"][drive]
+    assert same(C.df1_cascade([REFC], x)[:, 0, 0], bits(out["df1"]))
+    assert same(C.df1_cascade([REFC, REFC], x)[:, 0, 0], bits(out["df1x2"]))
+    assert same(C.df2(REFC, x)[:, 0, 0], bits(out["df2"]))
+    assert same(C.df1t(REFC, x)[:, 0, 0], bits(out["df1t"]))
+    y = C.cross_wire(x)
+    assert same(y[:, 0, 0], bits(out["xwire0"])) and same(y[:, 0, 1], bits(out["xwire1"]))
+
+
+def test_c_synth_matches_python():
+    a = C.synth_fill(20160512, 5, 7, 33, n_wires=4, t0=3)
+    b = O.synth_input(20160512, np.arange(5, 12), 33, n_wires=4, t0=3)
+    assert same(a, b)
+    a = C.synth_fill(1, 0, 3, 16, stream_major=True)
+    assert same(a.transpose(1, 0, 2), O.synth_input(1, np.arange(3), 16))
+
+
+NS, T = 5, 300
+
+
+def test_c_vs_python_generic_oracle():
+    x = O.synth_input(99, np.arange(NS), T)
+    assert same(C.df1_cascade([G.STABLE] * 6, x), O.compile(G.df1_cascade(6), NS).run(x))
+    assert same(C.df2(G.STABLE, x), O.compile(G.df2(*G.STABLE), NS).run(x))
+    assert same(C.df2t_flowz(REFC, x), O.compile(G.df2t(), NS).run(x))
+    assert same(C.df1t(REFC, x), O.compile(G.df1t(), NS).run(x))
+    assert same(C.integrator(x), O.compile(G.integrator(), NS).run(x))
+    assert same(C.one_quad(x), O.compile(G.one_quad(), NS).run(x))
+    assert same(C.cross_wire(x), O.compile(G.cross_wire(), NS).run(x))
+
+
+def test_c_par4_vs_python():
+    x4 = O.synth_input(5, np.arange(NS), T, n_wires=4)
+    assert same(C.par4_sum(G.PAR4_SETS, x4), O.compile(G.par4_sum(), NS).run(x4))
+    x1 = O.synth_input(5, np.arange(NS), T)
+    assert same(C.par4_sum(G.PAR4_SETS, x1, fanout=True), O.compile(G.par4_sum_fanout(), NS).run(x1))
+
+
+def test_c_osc_chain_vs_python():
+    P = W.osc_chain_params(20160513, np.arange(NS))
+    x = np.zeros((T, NS, 1), np.float32)
+    x[0] = 1.0
+    got = C.osc_chain(P, x)
+    want = O.compile(G.osc_chain(6), NS, params=P).run(x)
+    assert same(got, want)
+    assert np.isfinite(got).all() and np.abs(got).max() > 0
+
+
+def test_stream_major_layout_equivalent():
+    x = O.synth_input(3, np.arange(4), 50)
+    a = C.df1_cascade([G.STABLE] * 6, x)
+    b = C.df1_cascade([G.STABLE] * 6, np.ascontiguousarray(x.transpose(1, 0, 2)), stream_major=True)
+    assert same(a, b.transpose(1, 0, 2))
+
+
+def test_stable_set_stays_bounded_over_block():
+    x = O.synth_input(20160512, np.arange(8), 4096)
+    y = C.df1_cascade([G.STABLE] * 6, x)
+    assert np.isfinite(y).all() and np.abs(y).max() < 4.0
