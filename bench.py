@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 6-stage biquad (DF1) cascade, 1 M streams x 4096-sample blocks per GPU.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU.  One "step" = one fz_run_block launch = one
+4096-sample block of every stream of this rank (state carried from step to step), input frames
+already resident in HBM.  Rank 0 prints ONE JSON line.
+
+  value      whole-job Msamples/s = streams(all ranks) * 4096 * K / max-over-ranks wall time
+  roofline   dominant kernel fz_block_kernel: algorithmic bytes per launch / its average launch
+             duration measured with HIP events on the launch stream inside the timed region;
+             peak = 8000 GB/s (HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md)
+  cpu_baseline  the compiled scalar oracle (one closure per stream, one call per sample: what
+             the reference's compile()-callable does) timed on this box's host cores on a
+             bounded sample of the same workload, rank 0, N == 1 only; its outputs double as a
+             bitwise parity check of the GPU output for those streams.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SEED = 20160512
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(n_samples, gpu_out_sampler):
+    """Time the compiled oracle on all host cores; returns (dict, parity string)."""
+    import concurrent.futures as cf
+
+    import numpy as np
+
+    import graphs as G
+    from oracle import coracle
+
+    cores = os.cpu_count() or 1
+    coefs = [G.STABLE] * 6
+    per_thread = 64
+    # calibrate on a small piece, then size the sample for ~3 s per thread (bounded: 10-30 s CPU work)
+    x0 = coracle.synth_fill(SEED, 0, per_thread, n_samples, stream_major=True)
+    t0 = time.perf_counter()
+    y0 = coracle.df1_cascade(coefs, x0, stream_major=True)
+    dt = time.perf_counter() - t0
+    rate = per_thread * n_samples / dt
+    per_thread = int(min(max(64, (3.0 * rate / n_samples) // 64 * 64), 8192))
+    chunks = [coracle.synth_fill(SEED, i * per_thread, per_thread, n_samples, stream_major=True) for i in range(cores)]
+    with cf.ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        outs = list(ex.map(lambda c: coracle.df1_cascade(coefs, c, stream_major=True), chunks))
+        wall = time.perf_counter() - t0
+    total = cores * per_thread * n_samples
+    base = {"value": round(total / wall / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{cores * per_thread} streams x {n_samples} samples, 6-stage DF1 cascade, scalar "
+                      f"closure per stream (oracle/flowz_oracle.c, gcc -O3 -ffp-contract=off), "
+                      f"{cores} threads, {wall:.2f} s wall"}
+    # parity: GPU output of the first 64 streams vs the oracle's
+    got = gpu_out_sampler(64)                       # [T, 64] numpy
+    want = outs[0][:64, :, 0].T
+    nd = int((np.ascontiguousarray(got).view(np.uint32) != np.ascontiguousarray(want).view(np.uint32)).sum())
+    return base, ("bitwise-equal on 64 streams x %d samples" % n_samples) if nd == 0 else f"MISMATCH {nd} samples"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=1 << 20, help="streams PER GPU (weak scaling)")
+    ap.add_argument("--samples", type=int, default=4096, help="samples per block")
+    ap.add_argument("--lanes", type=int, default=0, help="streams per lane (0 = auto)")
+    ap.add_argument("--unroll", type=int, default=0)
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import graphs as G
+    from zignal_amd import dist as zdist
+    from zignal_amd import flowz as F
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the flow-graph evaluator has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ns, T = args.streams, args.samples
+    begin, end = zdist.shard_range(ns * world, rank, world)      # this rank's global stream ids
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    variant = F.make_variant(args.lanes, args.unroll, args.block, args.flags)
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device=dev)
+    y = torch.empty((T, ns, 1), dtype=torch.float32, device=dev)
+    state = torch.zeros((prog.n_state, ns), dtype=torch.float32, device=dev)
+    F.synth_fill(x, SEED, stream0=begin)
+    torch.cuda.synchronize()
+
+    # first block from zero state: kept for the parity check
+    prog.run_block(x, state=state, out=y, variant=variant)
+    torch.cuda.synchronize()
+    first64 = y[:, :64, 0].cpu().numpy() if rank == 0 else None
+    for _ in range(max(args.warmup - 1, 0)):
+        prog.run_block(x, state=state, out=y, variant=variant)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        prog.run_block(x, state=state, out=y, variant=variant)
+        ev[k][1].record()
+    barrier()
+    wall = time.perf_counter() - t0
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_avg_s = sum(kern_ms) / len(kern_ms) / 1e3
+
+    checksum = float(y[-1].double().sum().item())
+    stats = zdist.reduce_stats(wall, float(ns) * T * args.steps, checksum, device=dev)
+
+    # copy-kernel yardstick (same bytes in + out), rank 0 only
+    copy_gbs = None
+    if rank == 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        F.copy_probe(x, y)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(3):
+            F.copy_probe(x, y)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * x.numel() * 4 * 3 / (e0.elapsed_time(e1) / 1e3) / 1e9
+
+    if rank == 0:
+        b_alg = ns * (4 * T * (prog.n_in + prog.n_out) + 8 * prog.n_state + 4 * prog.n_param)
+        achieved = b_alg / kern_avg_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"cascade6_{ns}x{T}")
+        line = {
+            "metric": "Msamples/sec/GPU + achieved HBM GB/s, 6-biquad cascade, 1M streams",
+            "value": round(stats["samples"] / stats["seconds"] / 1e6, 1),
+            "unit": "Msamples/s",
+            "per_gpu": round(stats["samples"] / stats["seconds"] / 1e6 / world, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(stats["seconds"] / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"6-stage DF1 biquad cascade (flowz fwd|=bwd x6), {ns} streams/GPU x {T}-sample block, "
+                                   f"uniform stable coefficients, time-major frames [t][stream]",
+                       "streams_per_gpu": ns, "block_samples": T, "streams_total": ns * world,
+                       "parallelism": f"stream-sharded x{world}, no data-path collective",
+                       "kernel_variant": {"streams_per_lane": args.lanes, "unroll": args.unroll,
+                                          "block_threads": args.block, "flags": args.flags}},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "fz_block_kernel", "algorithmic_bytes_per_launch": b_alg,
+                         "avg_launch_ms": round(kern_avg_s * 1e3, 4),
+                         "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
+                         "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None},
+            "checksum": stats["checksum"],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, parity = cpu_baseline(T, lambda k: first64[:, :k])
+            line["cpu_baseline"] = base
+            line["parity"] = parity
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,182 @@
+/* flowz_hip.h -- C ABI of libflowz_hip.so: MI355X (gfx950) evaluator for Flowz flow-graphs.
+ *
+ * This is the drop-in boundary of the hot path.  The reference has no FFI: its path sits
+ * behind a C++ header API (/root/reference/flowz/flowz.hpp).  Each group below names the
+ * reference interface it replaces; the C++ front end (include/flowz/flowz.hpp) and the
+ * Python mirror (zignal_amd/flowz.py) are thin layers over exactly these entry points.
+ *
+ * Conventions: plain pointers and sizes, no exceptions cross the boundary.  Functions
+ * returning int give FZ_OK (0) or a negative fz_status; fz_last_error() returns a
+ * thread-local message for the last failure on the calling thread.
+ * All arithmetic is IEEE float32, one rounding per expression node in the user's
+ * association order, no FMA contraction, denormals kept (flowz.hpp:769-772,
+ * CMakeLists.txt:18).
+ */
+#ifndef FLOWZ_HIP_H
+#define FLOWZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum fz_status {
+   FZ_OK            =  0,
+   FZ_E_INVALID     = -1,   /* bad argument (null, misaligned, size mismatch)              */
+   FZ_E_GRAPH       = -2,   /* malformed flow-graph (arity, delay-free loop, ...)          */
+   FZ_E_NO_DEVICE   = -3,   /* no HIP device: the product path has no CPU fallback         */
+   FZ_E_HIP         = -4,   /* HIP runtime error                                           */
+   FZ_E_COMPILE     = -5,   /* hiprtc failed to build the generated kernel                 */
+   FZ_E_UNSUPPORTED = -6    /* valid graph, beyond this build (e.g. delay too long)        */
+} fz_status;
+
+const char* fz_last_error(void);
+const char* fz_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Expression construction  == the EDSL surface, flowz.hpp:68-93 and :1252-1257.
+ * Handles are immutable, reference counted trees; every constructor returns a NEW handle
+ * (refcount 1) and retains its operands, so the caller releases what it created
+ * (value semantics of proto's copy_domain, flowz.hpp:46-61).  NULL on error.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct fz_expr fz_expr;
+
+typedef enum fz_op { FZ_OP_ADD = 1, FZ_OP_SUB = 2, FZ_OP_MUL = 3, FZ_OP_DIV = 4, FZ_OP_NEG = 5 } fz_op;
+
+fz_expr* fz_placeholder(uint32_t i);                 /* _i          make_placeholder<i>() :78-82   */
+fz_expr* fz_delayed(uint32_t i, uint32_t n);         /* _i[_n]      delayed_placeholder   :84-85   */
+fz_expr* fz_literal(float value);                    /* terminal held by value  make_terminal :68-72 */
+fz_expr* fz_stream_param(uint32_t k);                /* per-stream, block-constant coefficient k:
+                                                        the std::ref terminal of flowz/README.md:42-61,
+                                                        one value per stream                          */
+fz_expr* fz_arith(fz_op op, fz_expr* a, fz_expr* b); /* any C++ arithmetic operator, _default :769-772;
+                                                        b is ignored (may be NULL) for FZ_OP_NEG      */
+fz_expr* fz_channel (fz_expr* a, fz_expr* b);        /* a , b       channel_operator   :90           */
+fz_expr* fz_parallel(fz_expr* a, fz_expr* b);        /* a | b       parallel_operator  :91           */
+fz_expr* fz_sequence(fz_expr* a, fz_expr* b);        /* a |= b      sequence_operator  :92           */
+fz_expr* fz_feedback(fz_expr* a);                    /* ~a          feedback_operator  :93           */
+void     fz_expr_retain (fz_expr* e);
+void     fz_expr_release(fz_expr* e);
+
+/* Static analysis transforms (flowz.hpp:162-246, :443-506; asserted by test/tests.cpp:63-102). */
+int fz_input_arity (const fz_expr* e);               /* >= 0, or negative fz_status                   */
+int fz_output_arity(const fz_expr* e);
+/* per external input wire, deepest delayed read; writes min(n, cap) entries, returns n        */
+int fz_max_input_delays(const fz_expr* e, uint32_t* out, uint32_t cap);
+
+/* ------------------------------------------------------------------------------------------
+ * compile()  == flowz::compile, flowz.hpp:1233-1249: arity, front panel, feedback
+ * resolution, state layout -- at run time instead of C++ template instantiation.
+ * Pure host work: succeeds without a GPU.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct fz_program fz_program;
+
+typedef struct fz_info {
+   uint32_t n_in;        /* external input wires  (frame width of `in`)                       */
+   uint32_t n_out;       /* output wires          (frame width of `out`)                      */
+   uint32_t n_nodes;     /* nodes of the lowered per-sample DAG                               */
+   uint32_t n_ops;       /* arithmetic nodes = float32 operations per stream-sample           */
+   uint32_t n_lines;     /* delay lines (one per delayed wire, shared by all its readers)     */
+   uint32_t n_state;     /* floats of state per stream = sum of line depths                   */
+   uint32_t n_const;     /* distinct uniform coefficients (literal terminals)                 */
+   uint32_t n_param;     /* per-stream coefficients (highest fz_stream_param index + 1)       */
+   uint32_t max_delay;   /* deepest delay line                                                */
+   uint32_t n_lds_slots; /* ring-buffer slots kept in LDS (lines deeper than the register cap) */
+} fz_info;
+
+int  fz_compile(const fz_expr* e, fz_program** out);
+void fz_program_destroy(fz_program* p);
+int  fz_program_info(const fz_program* p, fz_info* info);
+
+/* Lowered IR, for inspection and for tests (the product never interprets it on the CPU). */
+typedef enum fz_ir_kind {
+   FZ_IR_INPUT = 1,   /* a = input wire index                                                  */
+   FZ_IR_CONST = 2,   /* a = coefficient slot, value = its float                               */
+   FZ_IR_PARAM = 3,   /* a = per-stream coefficient index                                      */
+   FZ_IR_DELAY = 4,   /* a = source node, b = n : value of node a, n samples ago               */
+   FZ_IR_ADD = 5, FZ_IR_SUB = 6, FZ_IR_MUL = 7, FZ_IR_DIV = 8,   /* a (op) b                    */
+   FZ_IR_NEG = 9      /* -a                                                                    */
+} fz_ir_kind;
+
+typedef struct fz_ir_node { uint32_t kind, a, b; float value; } fz_ir_node;
+
+/* nodes are in evaluation (topological) order; writes min(n, cap), returns n */
+int fz_program_ir(const fz_program* p, fz_ir_node* nodes, uint32_t cap);
+/* node id of each output wire; writes min(n_out, cap), returns n_out */
+int fz_program_outputs(const fz_program* p, uint32_t* node_ids, uint32_t cap);
+/* delay lines: source node and depth of line l; state rows of line l start at the sum of the
+ * depths before it, row (start + j) holds the wire's value at t-1-j (j = 0 newest).          */
+int fz_program_lines(const fz_program* p, uint32_t* src_nodes, uint32_t* depths, uint32_t cap);
+/* read / overwrite a uniform coefficient (literal terminal) between blocks */
+int fz_program_get_const(const fz_program* p, uint32_t slot, float* value);
+int fz_program_set_const(fz_program* p, uint32_t slot, float value);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel variants.  One fused HIP kernel per (graph, variant) is generated and built with
+ * hiprtc for gfx950 (building needs no GPU; code objects are cached on disk).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct fz_variant {
+   uint32_t streams_per_lane;  /* 1, 2 (v_pk_* float2) or 4; 0 = choose from n_streams         */
+   uint32_t unroll;            /* time steps per prefetch chunk (1..32); 0 = default           */
+   uint32_t block_threads;     /* 64..1024, multiple of 64; 0 = default (256)                  */
+   uint32_t flags;             /* FZ_VF_* ; 0 = default                                        */
+} fz_variant;
+
+enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores                   */
+       FZ_VF_XCD_REMAP = 2u };  /* contiguous stream range per XCD                              */
+
+int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */
+/* generated HIP source of a variant (skeleton + graph body); returns length, writes <= cap    */
+long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap);
+
+/* ------------------------------------------------------------------------------------------
+ * fz_run_block -- the hot path: stateful_lambda::operator() (flowz.hpp:1225-1229) applied to
+ * n_samples consecutive samples of n_streams independent closures in ONE kernel launch
+ * (the caller's per-sample loop, test/benchmark.cpp:137-147, moves into the kernel).
+ *
+ * All pointers are DEVICE pointers, 16-byte aligned, owned by the caller:
+ *   in     [n_samples][n_streams][n_in]   time-major interleaved frames (NULL iff n_in == 0)
+ *   out    [n_samples][n_streams][n_out]
+ *   state  [n_state][n_streams]  in/out; zero it before the first block (flowz.hpp:1245);
+ *          carries the closure state from block to block (may be NULL iff n_state == 0)
+ *   params [n_param][n_streams]  (NULL iff n_param == 0)
+ * Asynchronous on `hip_stream` (hipStream_t, NULL = default stream); the caller synchronises.
+ * `v` may be NULL (all defaults).  A program may run concurrently on different state buffers.
+ * ---------------------------------------------------------------------------------------- */
+int fz_run_block(fz_program* p, const float* in, float* out, float* state, const float* params,
+                 uint64_t n_streams, uint32_t n_samples, const fz_variant* v, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fz_bank -- device-resident closure state for n_streams streams: the `state_` member of
+ * stateful_lambda (flowz.hpp:1190-1191).  clone == copying the closure (snapshot, :1206).
+ * The *_host entry points stage through device memory (H2D, kernel, D2H, synchronous); they
+ * exist so that the reference's per-sample call protocol works unchanged on top.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct fz_bank fz_bank;
+
+int  fz_bank_create(fz_program* p, uint64_t n_streams, fz_bank** out);   /* zero state        */
+int  fz_bank_clone(const fz_bank* b, fz_bank** out);
+void fz_bank_destroy(fz_bank* b);
+int  fz_bank_reset(fz_bank* b);                                          /* state := 0        */
+int  fz_bank_set_params_host(fz_bank* b, const float* params /* [n_param][n_streams] */);
+float* fz_bank_state_device(fz_bank* b);                                 /* [n_state][n_streams] */
+int  fz_bank_process(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples,
+                     const fz_variant* v, void* hip_stream);
+int  fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint32_t n_samples);
+
+/* ------------------------------------------------------------------------------------------
+ * Device utilities used by the measurement harness (bench.py) and tests.
+ * ---------------------------------------------------------------------------------------- */
+int fz_device_count(void);                /* 0 when no GPU is visible                          */
+/* synthetic frames dst[t][s][w] = unit(hash32(seed, (stream0+s)*n_wires + w, t0+t)) in [-1,1) */
+int fz_synth_fill(float* dst_dev, uint64_t n_streams, uint32_t n_samples, uint32_t n_wires,
+                  uint32_t seed, uint64_t stream0, uint64_t t0, void* hip_stream);
+/* plain float4 copy kernel: the measured-copy-bandwidth yardstick of the roofline report      */
+int fz_copy_probe(const float* src_dev, float* dst_dev, uint64_t n_floats, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWZ_HIP_H */

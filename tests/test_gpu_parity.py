@@ -1,0 +1,314 @@
+"""Parity tests proper (MI355X): the HIP path, called through the C ABI, against the oracle.
+
+Bar: BIT-EXACT float32 (0 ULP).  BASELINE.json's north_star allows 1 ULP; these tests assert 0."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import graphs as G
+import workloads as W
+from oracle import coracle as C
+from oracle import flowz_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KA = json.load(open(os.path.join(HERE, "golden", "tests_cpp_known_answers.json")))
+REF = json.load(open(os.path.join(HERE, "golden", "ref_biquad_vectors.json")))
+SEED = 20160512
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    torch.cuda.set_device(0)
+    return torch
+
+
+@pytest.fixture(scope="module")
+def F():
+    from zignal_amd import flowz
+    assert flowz.device_count() >= 1
+    return flowz
+
+
+def tup(x):
+    return tuple(tup(v) for v in x) if isinstance(x, list) else x
+
+
+def bits(hexlist):
+    return np.array([int(h, 16) for h in hexlist], np.uint32).view(np.float32)
+
+
+def ndiff(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return int((a.view(np.uint32) != b.view(np.uint32)).sum())
+
+
+def run_gpu(torch, F, prog, x_host, params=None, variant=None, state=None):
+    x = torch.from_numpy(np.ascontiguousarray(x_host)).cuda()
+    p = torch.from_numpy(np.ascontiguousarray(params)).cuda() if params is not None else None
+    y, st = prog.run_block(x, state=state, params=p, variant=variant)
+    torch.cuda.synchronize()
+    return y.cpu().numpy(), st
+
+
+# ---- the reference's own known answers, through the per-sample call protocol -------------------
+@pytest.mark.parametrize("case", KA["evaluation"] + KA["readme"], ids=lambda c: c["name"])
+def test_tests_cpp_known_answers_per_sample_calls(F, case):
+    """compile(expr)(x...) one sample at a time (test/tests.cpp:88-178) via fz_bank_process_host."""
+    from zignal_amd import _capi
+    prog = F.compile(F.from_sexpr(tup(case["graph"])))
+    bank = ctypes.c_void_p()
+    _capi.check(_capi.lib.fz_bank_create(prog._h, 1, ctypes.byref(bank)))
+    try:
+        for ins, outs in case["calls"]:
+            xi = (ctypes.c_float * len(ins))(*[float(v) for v in ins])
+            yo = (ctypes.c_float * len(outs))()
+            _capi.check(_capi.lib.fz_bank_process_host(bank, xi, yo, 1))
+            assert [float(v) for v in yo] == [float(v) for v in outs]
+    finally:
+        _capi.lib.fz_bank_destroy(bank)
+
+
+# ---- golden vectors produced by the reference's own hand-written filters ------------------------
+FORMS = {"df1": G.df1, "df2": G.df2, "df1t": G.df1t, "df1x2": lambda: G.seq(G.df1(), G.df1())}
+
+
+@pytest.mark.parametrize("drive", ["dirac", "noise"])
+@pytest.mark.parametrize("form", sorted(FORMS))
+def test_reference_golden_vectors(torch_cuda, F, form, drive):
+    x = bits(REF["inputs"][drive])
+    prog = F.compile(F.from_sexpr(FORMS[form]()))
+    y, _ = run_gpu(torch_cuda, F, prog, x[:, None, None])
+    assert ndiff(y[:, 0, 0], bits(REF["outputs"][drive][form])) == 0
+
+
+@pytest.mark.parametrize("drive", ["dirac", "noise"])
+def test_reference_x_wire_two_outputs(torch_cuda, F, drive):
+    x = bits(REF["inputs"][drive])
+    y, _ = run_gpu(torch_cuda, F, F.compile(F.from_sexpr(G.cross_wire())), x[:, None, None])
+    assert ndiff(y[:, 0, 0], bits(REF["outputs"][drive]["xwire0"])) == 0
+    assert ndiff(y[:, 0, 1], bits(REF["outputs"][drive]["xwire1"])) == 0
+
+
+# ---- every graph family vs the generic oracle, ragged sizes, all lane packings -------------------
+GRAPHS = {
+    "df1": G.df1, "df2": G.df2, "df1t": G.df1t, "df2t": G.df2t, "cascade6": lambda: G.df1_cascade(6),
+    "integrator": G.integrator, "one_quad": G.one_quad, "one_quad_chain": G.one_quad_chain,
+    "cross_wire": G.cross_wire, "par4": G.par4_sum, "par4_fanout": G.par4_sum_fanout,
+    "identity": lambda: G.IN(1), "unit_delay": lambda: G.DEL(1, 1),
+    "wire_around": lambda: ("seq", G.IN(1), G.IN(2)),
+    "nested_fb": lambda: G.fb(G.seq(G.DEL(1, 1), G.fb(G.add(G.DEL(1, 1), G.IN(2))))),
+    "long_delay_lds": lambda: G.seq(G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 40))),
+                                    G.fb(G.add(G.mul(G.lit(0.7), G.DEL(1, 23)), G.IN(2)))),
+    "depth8_regs": lambda: G.add(G.mul(G.lit(0.5), G.DEL(1, 8)), G.sub(G.DEL(1, 3), G.IN(1))),
+    "div_neg": lambda: ("div", ("neg", G.IN(1)), G.add(G.lit(2.5), G.mul(G.DEL(1, 1), G.DEL(1, 1)))),
+}
+
+
+@pytest.mark.parametrize("P", [1, 2, 4])
+@pytest.mark.parametrize("name", sorted(GRAPHS))
+def test_graphs_vs_oracle_ragged(torch_cuda, F, name, P):
+    g = GRAPHS[name]()
+    prog = F.compile(F.from_sexpr(g))
+    ns, T = 132, 101                      # 132 = 2 waves + 4 lanes: ragged last wave; T % unroll != 0
+    x = O.synth_input(SEED + 1, np.arange(ns), T, n_wires=max(prog.n_in, 1))
+    want = O.compile(g, ns).run(x)
+    got, _ = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(P, 8))
+    assert ndiff(got, want) == 0
+
+
+@pytest.mark.parametrize("U", [1, 3, 4, 16, 32])
+def test_unroll_variants_agree_with_oracle(torch_cuda, F, U):
+    g = G.df1_cascade(3)
+    prog = F.compile(F.from_sexpr(g))
+    ns, T = 200, 77
+    x = O.synth_input(5, np.arange(ns), T)
+    got, _ = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(2, U))
+    assert ndiff(got, C.df1_cascade([G.STABLE] * 3, x)) == 0
+
+
+def test_single_stream_single_sample_edges(torch_cuda, F):
+    prog = F.compile(F.from_sexpr(G.df1()))
+    x = O.synth_input(9, [0], 1024)
+    got, _ = run_gpu(torch_cuda, F, prog, x)                      # BASELINE config 1: 1 stream x 1024
+    assert ndiff(got, C.df1_cascade([(G.B0, G.B1, G.B2, G.A1, G.A2)], x)) == 0
+    got1, _ = run_gpu(torch_cuda, F, prog, x[:1])                 # one sample
+    assert ndiff(got1, got[:1]) == 0
+
+
+def test_block_chaining_and_state_layout(torch_cuda, F):
+    """Blocks chain through the state buffer; its rows follow the documented layout."""
+    from ir_interp import run_ir
+    g = G.df1_cascade(6)
+    prog = F.compile(F.from_sexpr(g))
+    ns = 192
+    x = O.synth_input(3, np.arange(ns), 300)
+    whole, st_w = run_gpu(torch_cuda, F, prog, x)
+    a, st = run_gpu(torch_cuda, F, prog, x[:123])
+    b, st = run_gpu(torch_cuda, F, prog, x[123:], state=st)
+    assert ndiff(np.concatenate([a, b]), whole) == 0
+    assert ndiff(st.cpu().numpy(), st_w.cpu().numpy()) == 0
+    _, st_ref = run_ir(prog, x)
+    assert ndiff(st_w.cpu().numpy(), st_ref) == 0
+    # LDS ring lines chain too, also when the split is not aligned with the ring size
+    g2 = GRAPHS["long_delay_lds"]()
+    p2 = F.compile(F.from_sexpr(g2))
+    x2 = O.synth_input(4, np.arange(70), 150, n_wires=1)
+    w2, _ = run_gpu(torch_cuda, F, p2, x2)
+    a2, s2 = run_gpu(torch_cuda, F, p2, x2[:37])
+    b2, s2 = run_gpu(torch_cuda, F, p2, x2[37:], state=s2)
+    assert ndiff(np.concatenate([a2, b2]), w2) == 0 and ndiff(w2, O.compile(g2, 70).run(x2)) == 0
+
+
+def test_osc_chain_per_stream_coefficients(torch_cuda, F):
+    ns, T = 1000, 512
+    prog = F.compile(F.from_sexpr(G.osc_chain(6)))
+    P = W.osc_chain_params(SEED + 1, np.arange(ns))
+    x = np.zeros((T, ns, 1), np.float32)
+    x[0] = 1.0
+    for lanes in (1, 2, 4):
+        got, _ = run_gpu(torch_cuda, F, prog, x, params=P, variant=F.make_variant(lanes, 8))
+        assert ndiff(got, C.osc_chain(P, x)) == 0
+
+
+def test_denormals_and_specials_are_kept(torch_cuda, F):
+    """No flush-to-zero, NaN/Inf propagate like the CPU."""
+    g = G.df1()
+    prog = F.compile(F.from_sexpr(g))
+    x = np.zeros((64, 8, 1), np.float32)
+    x[0, 0] = 1e-38
+    x[0, 1] = np.float32(1.5e-45)
+    x[0, 2] = np.inf
+    x[3, 3] = np.nan
+    x[0, 4] = -0.0
+    x[0, 5] = 3e38
+    want = O.compile(g, 8).run(x)
+    got, _ = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(2, 8))
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert ndiff(np.where(nan, 0, got), np.where(nan, 0, want)) == 0
+    assert (np.abs(want[np.isfinite(want)]) < 1.2e-38).any(), "test must exercise denormals"
+
+
+def test_set_const_changes_uniform_coefficient_between_blocks(torch_cuda, F):
+    prog = F.compile(F.from_sexpr(G.df1()))
+    x = O.synth_input(2, np.arange(64), 50)
+    slot = [i for i, v in enumerate(prog.consts()) if np.float32(v) == G.B0][0]
+    prog.set_const(slot, 0.5)
+    got, _ = run_gpu(torch_cuda, F, prog, x)
+    assert ndiff(got, C.df1_cascade([(0.5, G.B1, G.B2, G.A1, G.A2)], x)) == 0
+
+
+def test_bad_arguments_fail_loudly(torch_cuda, F):
+    torch = torch_cuda
+    prog = F.compile(F.from_sexpr(G.df1()))
+    x = torch.zeros((8, 6, 1), device="cuda")
+    with pytest.raises(F.FlowzError):
+        prog.run_block(x, variant=F.make_variant(4, 8))          # 6 streams not a multiple of 4
+    with pytest.raises(F.FlowzError):
+        prog.run_block_ptr(x.data_ptr() + 4, x.data_ptr(), x.data_ptr(), None, 6, 8)   # misaligned
+    with pytest.raises(F.NoDeviceError):
+        prog.run_block(torch.zeros((8, 6, 1)))                   # host tensor: no CPU path
+
+
+# ---- BASELINE sizes: sampled streams vs the compiled oracle + size-independent properties -------------
+def _sample_ids(ns, k, seed):
+    rng = np.random.default_rng(seed)
+    ids = np.unique(np.concatenate([[0, 1, 63, 64, ns - 1], rng.integers(0, ns, k)]))
+    return ids
+
+
+def test_config2_cascade6_65536x4096_full_block(torch_cuda, F):
+    """BASELINE config 2.  1024+ random streams, full length, bitwise vs the compiled oracle;
+    all lane packings bit-identical on the WHOLE output; split blocks == one block."""
+    torch = torch_cuda
+    ns, T = 65536, 4096
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED)
+    y1, st1 = prog.run_block(x, variant=F.make_variant(1, 8))
+    ids = _sample_ids(ns, 1024, 1)
+    xh = O.synth_input(SEED, ids, T)
+    idt = torch.from_numpy(ids).cuda()
+    assert ndiff(x[:, idt].cpu().numpy(), xh) == 0                # device generator == host generator
+    want = C.df1_cascade([G.STABLE] * 6, xh)
+    assert ndiff(y1[:, idt].cpu().numpy(), want) == 0
+    assert np.isfinite(want).all()
+    for P, U in ((2, 8), (4, 4), (2, 16)):
+        y2, st2 = prog.run_block(x, variant=F.make_variant(P, U))
+        assert torch.equal(y1.view(torch.int32), y2.view(torch.int32))
+        assert torch.equal(st1.view(torch.int32), st2.view(torch.int32))
+    # two half blocks chained through the state buffer
+    ya, sta = prog.run_block(x[:2048])
+    yb, stb = prog.run_block(x[2048:], state=sta)
+    assert torch.equal(y1[:2048].view(torch.int32), ya.view(torch.int32))
+    assert torch.equal(y1[2048:].view(torch.int32), yb.view(torch.int32))
+    assert torch.equal(st1.view(torch.int32), stb.view(torch.int32))
+
+
+def test_config3_par4_sum_1M_streams(torch_cuda, F):
+    """BASELINE config 3: 4 parallel biquads summed, 1 M streams (4 input wires per frame)."""
+    torch = torch_cuda
+    ns, T = 1 << 20, 1024
+    prog = F.compile(F.from_sexpr(G.par4_sum()))
+    x = torch.empty((T, ns, 4), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED)
+    y, _ = prog.run_block(x)
+    ids = _sample_ids(ns, 512, 2)
+    xh = O.synth_input(SEED, ids, T, n_wires=4)
+    idt = torch.from_numpy(ids).cuda()
+    assert ndiff(x[:, idt].cpu().numpy(), xh) == 0
+    assert ndiff(y[:, idt].cpu().numpy(), C.par4_sum(G.PAR4_SETS, xh)) == 0
+    y1, _ = prog.run_block(x, variant=F.make_variant(1, 4))
+    assert torch.equal(y.view(torch.int32), y1.view(torch.int32))
+    del x, y, y1
+    # fan-out variant: one input wire
+    progf = F.compile(F.from_sexpr(G.par4_sum_fanout()))
+    x1 = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x1, SEED)
+    yf, _ = progf.run_block(x1)
+    xh1 = O.synth_input(SEED, ids, T)
+    assert ndiff(yf[:, idt].cpu().numpy(), C.par4_sum(G.PAR4_SETS, xh1, fanout=True)) == 0
+
+
+def test_config4_osc_chain_1M_streams(torch_cuda, F):
+    """BASELINE config 4: resonator oscillator -> 6 biquads, per-stream coefficients, 1 M streams."""
+    torch = torch_cuda
+    ns, T = 1 << 20, 1024
+    prog = F.compile(F.from_sexpr(G.osc_chain(6)))
+    ids = _sample_ids(ns, 512, 3)
+    P = W.osc_chain_params(SEED + 1, np.arange(ns))
+    pd = torch.from_numpy(P).cuda()
+    x = torch.zeros((T, ns, 1), dtype=torch.float32, device="cuda")
+    x[0] = 1.0
+    y, _ = prog.run_block(x, params=pd)
+    xh = np.zeros((T, len(ids), 1), np.float32)
+    xh[0] = 1.0
+    idt = torch.from_numpy(ids).cuda()
+    want = C.osc_chain(np.ascontiguousarray(P[:, ids]), xh)
+    assert ndiff(y[:, idt].cpu().numpy(), want) == 0
+    assert np.isfinite(want).all() and np.abs(want[-1]).max() > 0      # still oscillating at the end
+
+
+def test_config5_shard_equals_global_stream_ids(torch_cuda, F):
+    """BASELINE config 5 shards streams across GPUs: a shard computed alone (stream0 offset in
+    the generator) is bit-identical to the same streams inside one big batch."""
+    torch = torch_cuda
+    ns, T, shard = 8192, 256, 2048
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED)
+    y, _ = prog.run_block(x)
+    for r in range(ns // shard):
+        xs = torch.empty((T, shard, 1), dtype=torch.float32, device="cuda")
+        F.synth_fill(xs, SEED, stream0=r * shard)
+        ys, _ = prog.run_block(xs)
+        assert torch.equal(ys.view(torch.int32), y[:, r * shard:(r + 1) * shard].contiguous().view(torch.int32))

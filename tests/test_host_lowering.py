@@ -1,0 +1,181 @@
+"""Host logic of the product (no GPU): C-ABI exports, EDSL analysis transforms, lowering.
+
+The lowered IR is evaluated by a tests-only numpy interpreter and compared with the oracle."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import graphs as G
+import workloads as W
+from ir_interp import run_ir
+from oracle import flowz_oracle as O
+from zignal_amd import _capi, flowz as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+KA = json.load(open(os.path.join(HERE, "golden", "tests_cpp_known_answers.json")))
+
+
+def tup(x):
+    return tuple(tup(v) for v in x) if isinstance(x, list) else x
+
+
+def same(a, b):
+    return np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "flowz_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fz_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/flowz_hip.h but not exported"
+    assert set(_capi.EXPORTS) == declared
+
+
+@pytest.mark.parametrize("case", KA["arity"], ids=lambda c: c["name"])
+def test_arity_transforms_match_tests_cpp(case):
+    e = F.from_sexpr(tup(case["graph"]))
+    assert e.ins == case["ins"] and e.outs == case["outs"]
+    if "max_input_delays" in case:
+        assert list(e.max_input_delays()) == case["max_input_delays"]
+
+
+@pytest.mark.parametrize("case", KA["evaluation"] + KA["readme"], ids=lambda c: c["name"])
+def test_lowering_reproduces_tests_cpp_known_answers(case):
+    p = F.compile(F.from_sexpr(tup(case["graph"])))
+    x = np.array([c[0] for c in case["calls"]], np.float32)[:, None, :]
+    y, _ = run_ir(p, x)
+    want = np.array([c[1] for c in case["calls"]], np.float32)
+    assert np.array_equal(y[:, 0, :], want)
+
+
+def test_python_edsl_operators_build_the_same_graph():
+    from zignal_amd.flowz import _1, _2
+    b0, b1, b2, a1, a2 = (float(v) for v in (G.B0, G.B1, G.B2, G.A1, G.A2))
+    fwd = b0 * _1 + b1 * _1[_1] + b2 * _1[_2]
+    bwd = ~(_2 + a1 * _1[_1] + a2 * _1[-2])
+    p1 = F.compile(fwd >> bwd)
+    p2 = F.compile(F.from_sexpr(G.df1()))
+    assert p1.ir() == p2.ir() and p1.outputs() == p2.outputs() and p1.lines() == p2.lines()
+    assert (fwd >> bwd).ins == 1 and (fwd >> bwd).outs == 1
+    assert F.seq(_1, _1, _1[_1]).ins == 1 and F.chan(_1, _2).outs == 2 and (_1 | _1).ins == 2
+
+
+GRAPHS = {
+    "df1": G.df1, "df2": G.df2, "df1t": G.df1t, "df2t": G.df2t, "cascade6": lambda: G.df1_cascade(6),
+    "integrator": G.integrator, "one_quad": G.one_quad, "one_quad_chain": G.one_quad_chain,
+    "cross_wire": G.cross_wire, "par4": G.par4_sum, "par4_fanout": G.par4_sum_fanout,
+    "nested_fb": lambda: G.fb(G.seq(G.DEL(1, 1), G.fb(G.add(G.DEL(1, 1), G.IN(2))))),   # tests.cpp:60
+    "long_delay": lambda: G.seq(G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 40))),
+                                G.fb(G.add(G.mul(G.lit(0.7), G.DEL(1, 23)), G.IN(2)))),
+    "div_neg": lambda: ("div", ("neg", G.IN(1)), G.add(G.lit(2.5), G.mul(G.DEL(1, 1), G.DEL(1, 1)))),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GRAPHS))
+def test_lowering_vs_oracle(name):
+    g = GRAPHS[name]()
+    p = F.compile(F.from_sexpr(g))
+    ns, T = 3, 96
+    assert p.n_in == O.input_arity(g) and p.n_out == O.output_arity(g)
+    x = O.synth_input(11, np.arange(ns), T, n_wires=max(p.n_in, 1))
+    want = O.compile(g, ns).run(x)
+    got, _ = run_ir(p, x)
+    assert same(got, want)
+
+
+def test_lowering_osc_chain_with_stream_params():
+    g = G.osc_chain(6)
+    p = F.compile(F.from_sexpr(g))
+    assert p.n_param == 31 and p.n_state == 14 and p.n_ops == 3 + 54   # resonator line is shared with stage 1
+    ns, T = 4, 128
+    P = W.osc_chain_params(20160513, np.arange(ns))
+    x = np.zeros((T, ns, 1), np.float32)
+    x[0] = 1
+    got, _ = run_ir(p, x, params=P)
+    assert same(got, O.compile(g, ns, params=P).run(x))
+
+
+def test_state_sharing_and_minimal_state():
+    p = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    # 2 + 2N floats for an N-stage DF1 chain, 54 unfused float32 ops per sample
+    assert (p.n_state, p.n_lines, p.n_ops, p.n_const, p.max_delay) == (14, 7, 54, 5, 2)
+    assert F.compile(F.from_sexpr(G.df2())).n_state == 2
+    assert F.compile(F.from_sexpr(G.par4_sum())).n_state == 16
+
+
+def test_block_chaining_through_state_rows():
+    g = G.df1_cascade(2)
+    p = F.compile(F.from_sexpr(g))
+    x = O.synth_input(3, np.arange(2), 64)
+    whole, st_w = run_ir(p, x)
+    a, st = run_ir(p, x[:40])
+    b, st = run_ir(p, x[40:], state=st)
+    assert same(np.concatenate([a, b]), whole) and same(st, st_w)
+
+
+def test_malformed_graphs_are_rejected():
+    with pytest.raises(F.FlowzError) as ei:
+        F.compile(~(F._1 + F._2))                      # delay-free loop
+    assert ei.value.code == _capi.FZ_E_GRAPH and "delay" in str(ei.value)
+    with pytest.raises(F.FlowzError):
+        F.compile(~F._1)                               # wire fed straight back to itself
+    with pytest.raises(F.FlowzError):
+        (F._1 | F._1) + F._2                           # arithmetic on a 2-wire bundle
+    with pytest.raises(F.FlowzError):
+        F._1[0]                                        # delay 0 is not a delay
+
+
+def test_kernel_source_and_jit_build_for_gfx950_without_gpu(tmp_path, monkeypatch):
+    monkeypatch.setenv("FLOWZ_HIP_CACHE", str(tmp_path))
+    p = F.compile(F.from_sexpr(G.df1_cascade(2)))
+    src = p.source(F.make_variant(2, 4))
+    assert "#define FZ_P 2" in src and "fz_block_kernel" in src and "struct fz_graph" in src
+    p.build(F.make_variant(2, 4))
+    objs = list(tmp_path.glob("*.hsaco"))
+    assert len(objs) == 1 and objs[0].stat().st_size > 1000
+    # cache hit: same key, no new file
+    F.compile(F.from_sexpr(G.df1_cascade(2))).build(F.make_variant(2, 4))
+    assert len(list(tmp_path.glob("*.hsaco"))) == 1
+
+
+def test_no_fma_contraction_in_generated_kernel(tmp_path, monkeypatch):
+    """contraction changes the 4th impulse-response sample."""
+    import subprocess
+    monkeypatch.setenv("FLOWZ_HIP_CACHE", str(tmp_path))
+    for P in (1, 2, 4):
+        F.compile(F.from_sexpr(G.df1_cascade(2))).build(F.make_variant(P, 4))
+    for obj in tmp_path.glob("*.hsaco"):
+        dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", str(obj)], text=True)
+        assert "v_pk_mul_f32" in dis or "v_mul_f32" in dis
+        assert not re.search(r"v_(pk_)?(fma|fmac|mad|mac)_", dis)
+        notes = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(obj)], text=True)
+        assert ".vgpr_spill_count: 0" in notes and ".private_segment_fixed_size: 0" in notes
+
+
+def test_product_fails_loudly_without_gpu():
+    if F.device_count() > 0:
+        pytest.skip("GPU present")
+    p = F.compile(F.from_sexpr(G.df1()))
+    with pytest.raises(F.NoDeviceError):
+        p.run_block_ptr(ctypes.c_void_p(256), ctypes.c_void_p(512), ctypes.c_void_p(1024), None, 64, 8)
+    bank = ctypes.c_void_p()
+    assert _capi.lib.fz_bank_create(p._h, 4, ctypes.byref(bank)) == _capi.FZ_E_NO_DEVICE
+    assert "no CPU fallback" in _capi.last_error()
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "zignal_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".inc", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("no CPU", ""), f"{f} mentions the oracle"
+    hdr = open(os.path.join(ROOT, "include", "flowz_hip.h")).read()
+    assert "oracle" not in hdr

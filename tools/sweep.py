@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): time kernel variants of a workload with HIP events, interleaved rounds.
+
+usage: tools/sweep.py [--graph cascade6] [--streams N] [--samples T] [--rounds R] variants...
+       variant = P,U[,block[,flags]]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graph", default="cascade6")
+    ap.add_argument("--streams", type=int, default=1 << 20)
+    ap.add_argument("--samples", type=int, default=4096)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("variants", nargs="*", default=["1,8", "2,8", "4,4"])
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+
+    import graphs as G
+    import workloads as W
+    from zignal_amd import flowz as F
+
+    graphs = {"cascade6": lambda: G.df1_cascade(6), "par4": G.par4_sum, "par4f": G.par4_sum_fanout,
+              "osc": lambda: G.osc_chain(6), "df1": G.df1}
+    prog = F.compile(F.from_sexpr(graphs[a.graph]()))
+    ns, T = a.streams, a.samples
+    x = torch.empty((T, ns, max(prog.n_in, 1)), dtype=torch.float32, device="cuda")
+    y = torch.empty((T, ns, prog.n_out), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, 20160512)
+    params = None
+    if prog.n_param:
+        params = torch.from_numpy(W.osc_chain_params(20160513, np.arange(ns))).cuda()
+    state = torch.zeros((max(prog.n_state, 1), ns), dtype=torch.float32, device="cuda")
+    b_alg = ns * (4 * T * (prog.n_in + prog.n_out) + 8 * prog.n_state + 4 * prog.n_param)
+    vs = []
+    for s in a.variants:
+        t = [int(v) for v in s.split(",")]
+        t += [0] * (4 - len(t))
+        vs.append((s, F.make_variant(*t)))
+    times = {s: [] for s, _ in vs}
+    for s, v in vs:                              # warm (JIT + first touch)
+        prog.run_block(x, state=state, params=params, out=y, variant=v)
+    torch.cuda.synchronize()
+    for _ in range(a.rounds):
+        for s, v in vs:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            prog.run_block(x, state=state, params=params, out=y, variant=v)
+            e1.record()
+            torch.cuda.synchronize()
+            times[s].append(e0.elapsed_time(e1))
+    # copy yardstick
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = min(x.numel(), y.numel())
+    xs, ys = x.view(-1)[:n], y.view(-1)[:n]
+    F.copy_probe(xs, ys)
+    e0.record()
+    F.copy_probe(xs, ys)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"# {a.graph} {ns} streams x {T} samples; B_alg = {b_alg / 1e9:.3f} GB; copy probe "
+          f"{2 * n * 4 / (e0.elapsed_time(e1) / 1e3) / 1e9:.0f} GB/s")
+    for s, _ in vs:
+        ts = sorted(times[s])
+        med, mn = ts[len(ts) // 2], ts[0]
+        print(json.dumps({"variant": s, "ms_med": round(med, 3), "ms_min": round(mn, 3),
+                          "GBs_med": round(b_alg / med / 1e6, 1), "Msamples_s": round(ns * T / med / 1e3, 1),
+                          "frac_8TBs": round(b_alg / med / 1e6 / 8000, 4)}))
+
+
+if __name__ == "__main__":
+    main()

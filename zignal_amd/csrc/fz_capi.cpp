@@ -1,0 +1,134 @@
+// extern "C" entry points of libflowz_hip that are pure host work: compile(), IR inspection,
+// kernel build (hiprtc needs no GPU), and the fz_run_block wrapper.
+#include <cstring>
+
+#include "fz_internal.hpp"
+
+using namespace fz;
+
+#define FZ_GUARD(...)                                                           \
+   try { __VA_ARGS__ }                                                                 \
+   catch (const fz::Error& er) { fz::set_error(er.msg); return er.code; }       \
+   catch (const std::exception& ex) { fz::set_error(ex.what()); return FZ_E_INVALID; }
+
+extern "C" {
+
+int fz_compile(const fz_expr* e, fz_program** out)
+{
+   FZ_GUARD(
+      if (!e || !out) fail(FZ_E_INVALID, "fz_compile: null argument");
+      auto* p = new fz_program();
+      try {
+         p->g = lower(e);
+      } catch (...) {
+         delete p;
+         throw;
+      }
+      *out = p;
+      return FZ_OK;)
+}
+
+void fz_program_destroy(fz_program* p) { delete p; }
+
+int fz_program_info(const fz_program* p, fz_info* info)
+{
+   FZ_GUARD(
+      if (!p || !info) fail(FZ_E_INVALID, "fz_program_info: null argument");
+      const Graph& g = p->g;
+      info->n_in = g.n_in;
+      info->n_out = g.n_out;
+      info->n_nodes = (uint32_t)g.nodes.size();
+      info->n_ops = g.n_ops;
+      info->n_lines = (uint32_t)g.lines.size();
+      info->n_state = g.n_state;
+      info->n_const = (uint32_t)g.consts.size();
+      info->n_param = g.n_param;
+      info->max_delay = g.max_delay;
+      info->n_lds_slots = g.n_lds_slots;
+      return FZ_OK;)
+}
+
+int fz_program_ir(const fz_program* p, fz_ir_node* nodes, uint32_t cap)
+{
+   if (!p) { set_error("null program"); return FZ_E_INVALID; }
+   const Graph& g = p->g;
+   for (size_t k = 0; k < g.nodes.size() && k < cap; ++k) {
+      nodes[k].kind = g.nodes[k].kind;
+      nodes[k].a = g.nodes[k].a;
+      nodes[k].b = g.nodes[k].b;
+      nodes[k].value = g.nodes[k].kind == FZ_IR_CONST ? g.consts[g.nodes[k].a] : 0.f;
+   }
+   return (int)g.nodes.size();
+}
+
+int fz_program_outputs(const fz_program* p, uint32_t* ids, uint32_t cap)
+{
+   if (!p) { set_error("null program"); return FZ_E_INVALID; }
+   for (size_t k = 0; k < p->g.outputs.size() && k < cap; ++k) ids[k] = p->g.outputs[k];
+   return (int)p->g.outputs.size();
+}
+
+int fz_program_lines(const fz_program* p, uint32_t* src, uint32_t* depth, uint32_t cap)
+{
+   if (!p) { set_error("null program"); return FZ_E_INVALID; }
+   for (size_t k = 0; k < p->g.lines.size() && k < cap; ++k) {
+      if (src) src[k] = p->g.lines[k].src;
+      if (depth) depth[k] = p->g.lines[k].depth;
+   }
+   return (int)p->g.lines.size();
+}
+
+int fz_program_get_const(const fz_program* p, uint32_t slot, float* value)
+{
+   FZ_GUARD(
+      if (!p || !value) fail(FZ_E_INVALID, "null argument");
+      if (slot >= p->g.consts.size()) fail(FZ_E_INVALID, "coefficient slot out of range");
+      *value = p->g.consts[slot];
+      return FZ_OK;)
+}
+
+int fz_program_set_const(fz_program* p, uint32_t slot, float value)
+{
+   FZ_GUARD(
+      if (!p) fail(FZ_E_INVALID, "null argument");
+      if (slot >= p->g.consts.size()) fail(FZ_E_INVALID, "coefficient slot out of range");
+      std::lock_guard<std::mutex> lock(p->mu);
+      p->g.consts[slot] = value;
+      return FZ_OK;)
+}
+
+int fz_program_build(fz_program* p, const fz_variant* v)
+{
+   FZ_GUARD(
+      if (!p) fail(FZ_E_INVALID, "null program");
+      // "auto" fields resolve as for a large stream count
+      (void)get_kernel(p, resolve_variant(p->g, v, 1ull << 20), false);
+      return FZ_OK;)
+}
+
+long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap)
+{
+   try {
+      if (!p) fail(FZ_E_INVALID, "null program");
+      const std::string s = full_source(p->g, resolve_variant(p->g, v, 1ull << 20));
+      if (buf && cap) {
+         const size_t n = std::min(cap - 1, s.size());
+         std::memcpy(buf, s.data(), n);
+         buf[n] = 0;
+      }
+      return (long)s.size();
+   } catch (const fz::Error& er) {
+      set_error(er.msg);
+      return er.code;
+   }
+}
+
+int fz_run_block(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+                 uint32_t n_samples, const fz_variant* v, void* hip_stream)
+{
+   FZ_GUARD(
+      if (!p) fail(FZ_E_INVALID, "null program");
+      return launch(p, in, out, state, params, n_streams, n_samples, v, hip_stream);)
+}
+
+}  // extern "C"

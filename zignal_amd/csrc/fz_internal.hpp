@@ -1,0 +1,113 @@
+// Internal structures of libflowz_hip: expression trees, the lowered per-sample DAG, programs.
+#pragma once
+
+#include <atomic>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "flowz_hip.h"
+
+namespace fz {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const std::string& msg);
+struct Error {
+   int code;
+   std::string msg;
+};
+[[noreturn]] void fail(int code, const std::string& msg);
+
+// ---- expression tree (the EDSL surface, flowz.hpp:68-93) ---------------------------------------
+enum class EK : uint8_t { Placeholder, Delayed, Literal, Param, Arith, Neg, Channel, Parallel, Sequence, Feedback };
+
+}  // namespace fz
+
+struct fz_expr {
+   std::atomic<int> refs{1};
+   fz::EK kind;
+   uint32_t i = 0;        // placeholder index / param index
+   uint32_t n = 0;        // delay
+   float value = 0.f;     // literal
+   fz_op op = FZ_OP_ADD;  // arith
+   fz_expr* a = nullptr;
+   fz_expr* b = nullptr;
+   int in_arity = 0;
+   int out_arity = 1;
+};
+
+namespace fz {
+
+// ---- lowered DAG ---------------------------------------------------------------------------------
+struct Node {
+   uint32_t kind;   // fz_ir_kind
+   uint32_t a = 0, b = 0;
+   float value = 0.f;
+};
+
+struct Line {
+   uint32_t src;     // node whose value is pushed every sample
+   uint32_t depth;   // deepest delayed read
+   uint32_t row0;    // first state row
+   bool in_lds;      // ring buffer in LDS instead of registers
+   uint32_t lds_slot0 = 0, lds_size = 0;   // ring placement (size is a power of two >= depth)
+};
+
+struct Graph {
+   uint32_t n_in = 0, n_out = 0, n_param = 0;
+   std::vector<Node> nodes;          // topological order
+   std::vector<uint32_t> outputs;    // node ids
+   std::vector<Line> lines;          // ordered by src
+   std::vector<float> consts;        // uniform coefficient slots
+   uint32_t n_state = 0, max_delay = 0, n_ops = 0, n_lds_slots = 0;
+   std::vector<int> line_of_node;    // node -> line index or -1
+};
+
+// register-resident delay lines up to this depth; deeper ones become LDS rings
+constexpr uint32_t kRegMaxDepth = 8;
+
+Graph lower(const fz_expr* e);   // throws Error
+std::vector<uint32_t> max_input_delays(const fz_expr* e);
+
+// ---- code generation -------------------------------------------------------------------------------
+struct Variant {
+   uint32_t P = 2, U = 8, block = 256, flags = 0;
+   bool operator<(const Variant& o) const {
+      if (P != o.P) return P < o.P;
+      if (U != o.U) return U < o.U;
+      if (block != o.block) return block < o.block;
+      return flags < o.flags;
+   }
+};
+
+std::string gen_config(const Graph& g, const Variant& v); // generated "fz_graph_config.h"
+std::string gen_body(const Graph& g, const Variant& v);   // generated "fz_graph_body.h"
+const char* skeleton_source();                            // hand-written kernel skeleton text
+std::string full_source(const Graph& g, const Variant& v);
+
+// ---- runtime ---------------------------------------------------------------------------------------------
+struct Kernel {
+   void* module = nullptr;     // hipModule_t
+   void* function = nullptr;   // hipFunction_t
+   std::vector<char> code;     // code object
+   bool loaded = false;
+};
+
+}  // namespace fz
+
+struct fz_program {
+   fz::Graph g;
+   std::mutex mu;
+   std::map<fz::Variant, std::shared_ptr<fz::Kernel>> kernels;
+};
+
+namespace fz {
+Variant resolve_variant(const Graph& g, const fz_variant* v, uint64_t n_streams);
+std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, bool need_load);
+int launch(fz_program* p, const float* in, float* out, float* state, const float* params,
+           uint64_t n_streams, uint32_t n_samples, const fz_variant* v, void* stream);
+int device_count();
+}  // namespace fz

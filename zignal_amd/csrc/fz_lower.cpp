@@ -1,0 +1,308 @@
+// compile(): expression tree -> flat per-sample DAG + delay-line (state) layout.
+//
+// What the reference does at C++ compile time with the front panel (flowz.hpp:261-277), the
+// canonicaliser (make_canonical / split_future_subexpr, :794-935: every `~x` becomes
+// binary_feedback(promise, future) so that an evaluation order exists) and build_state
+// (:685-725: nested tuples of std::array<float,D> per sequence/feedback node) is done here at
+// run time on a wire graph:
+//   1. wiring      -- every combinator routes wire ids per the arity table (sequence :974-999,
+//                     parallel :1087-1099, channel :765-768, feedback: the first out(a) inputs
+//                     of `a` are its own outputs, :1018-1027/:1043-1069);
+//   2. ordering    -- a delayed read `_i[_n]` is a *source* (it only reads state), so feedback
+//                     cycles are broken exactly where the reference splits promise/future; a
+//                     cycle with no delayed read is a delay-free loop and is rejected;
+//   3. sharing     -- value-identical nodes are merged (same op, same operands) and there is ONE
+//                     delay line per delayed wire, as deep as its deepest reader (max_input_delays
+//                     :502); a 6-stage DF1 cascade therefore carries 14 floats of state where the
+//                     reference's nested tuples carry 24 (TODO.md:59) -- values are unaffected;
+//   4. no algebra  -- nothing is re-associated, folded or simplified: one float32 rounding per
+//                     node of the user's tree (proto::_default, :769-772).
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <tuple>
+
+#include "fz_internal.hpp"
+
+namespace fz {
+namespace {
+
+constexpr uint32_t K_FWD = 100;   // forward reference of a fed-back wire (resolved before output)
+
+struct Raw {
+   uint32_t kind;
+   int a = -1, b = -1;
+   float value = 0.f;
+   uint32_t n = 0;
+};
+
+struct Elab {
+   std::vector<Raw> raw;
+
+   int add(uint32_t kind, int a = -1, int b = -1, float value = 0.f, uint32_t n = 0)
+   {
+      raw.push_back(Raw{kind, a, b, value, n});
+      return (int)raw.size() - 1;
+   }
+
+   static std::vector<int> slice(const std::vector<int>& v, size_t lo, size_t hi)
+   {
+      hi = std::min(hi, v.size());
+      if (lo >= hi) return {};
+      return std::vector<int>(v.begin() + (long)lo, v.begin() + (long)hi);
+   }
+
+   int one(const fz_expr* e, const std::vector<int>& ins)
+   {
+      auto w = run(e, ins);
+      if (w.size() != 1) fail(FZ_E_GRAPH, "arithmetic operand must have exactly one output wire");
+      return w[0];
+   }
+
+   std::vector<int> run(const fz_expr* e, const std::vector<int>& ins)
+   {
+      switch (e->kind) {
+         case EK::Placeholder:                                          // place_the_holder :941-948
+            if (e->i > ins.size()) fail(FZ_E_GRAPH, "placeholder _" + std::to_string(e->i) + " has no wire to bind to");
+            return {ins[e->i - 1]};
+         case EK::Delayed:                                              // place_delay :950-958
+            if (e->i > ins.size()) fail(FZ_E_GRAPH, "placeholder _" + std::to_string(e->i) + " has no wire to bind to");
+            return {add(FZ_IR_DELAY, ins[e->i - 1], -1, 0.f, e->n)};
+         case EK::Literal: return {add(FZ_IR_CONST, -1, -1, e->value)};
+         case EK::Param: return {add(FZ_IR_PARAM, -1, -1, 0.f, e->i)};
+         case EK::Arith: {                                              // _default<eval_it> :769-772
+            int a = one(e->a, ins), b = one(e->b, ins);
+            uint32_t k = e->op == FZ_OP_ADD ? FZ_IR_ADD : e->op == FZ_OP_SUB ? FZ_IR_SUB
+                       : e->op == FZ_OP_MUL ? FZ_IR_MUL : FZ_IR_DIV;
+            return {add(k, a, b)};
+         }
+         case EK::Neg: return {add(FZ_IR_NEG, one(e->a, ins))};
+         case EK::Channel: {                                            // :765-768 same inputs to both
+            auto l = run(e->a, ins), r = run(e->b, ins);
+            l.insert(l.end(), r.begin(), r.end());
+            return l;
+         }
+         case EK::Parallel: {                                           // :1087-1099 inputs split at in(a)
+            size_t na = (size_t)e->a->in_arity, nb = (size_t)e->b->in_arity;
+            if (na + nb > ins.size()) fail(FZ_E_GRAPH, "parallel box needs more input wires than it is given");
+            auto l = run(e->a, slice(ins, 0, na)), r = run(e->b, slice(ins, na, na + nb));
+            l.insert(l.end(), r.begin(), r.end());
+            return l;
+         }
+         case EK::Sequence: {                                           // :974-999
+            size_t na = (size_t)e->a->in_arity, nb = (size_t)e->b->in_arity;
+            if (na > ins.size()) fail(FZ_E_GRAPH, "sequence needs more input wires than it is given");
+            auto ao = run(e->a, slice(ins, 0, na));
+            std::vector<int> bi = ao;                                   // a_out ++ rest of the inputs
+            for (size_t k = na; k < ins.size(); ++k) bi.push_back(ins[k]);
+            auto bo = run(e->b, bi);
+            for (size_t k = nb; k < ao.size(); ++k) bo.push_back(ao[k]);   // wires around the next box
+            return bo;
+         }
+         case EK::Feedback: {                                           // :1031-1074, arity-table routing
+            size_t k = (size_t)e->a->out_arity;
+            std::vector<int> in2;
+            for (size_t j = 0; j < k; ++j) in2.push_back(add(K_FWD));
+            std::vector<int> fwd = in2;
+            in2.insert(in2.end(), ins.begin(), ins.end());
+            auto ao = run(e->a, in2);
+            if (ao.size() != k) fail(FZ_E_GRAPH, "feedback body arity mismatch");
+            for (size_t j = 0; j < k; ++j) raw[(size_t)fwd[j]].a = ao[j];
+            return ao;
+         }
+      }
+      fail(FZ_E_GRAPH, "unknown expression node");
+   }
+
+   int resolve(int id) const
+   {
+      size_t guard = 0;
+      while (raw[(size_t)id].kind == K_FWD) {
+         id = raw[(size_t)id].a;
+         if (id < 0 || ++guard > raw.size())
+            fail(FZ_E_GRAPH, "delay-free feedback loop (a fed-back wire is wired straight to itself)");
+      }
+      return id;
+   }
+};
+
+uint32_t bits_of(float f)
+{
+   uint32_t u;
+   std::memcpy(&u, &f, 4);
+   return u;
+}
+
+}  // namespace
+
+Graph lower(const fz_expr* e)
+{
+   if (!e) fail(FZ_E_INVALID, "null expression");
+   Elab el;
+   const uint32_t n_in = (uint32_t)e->in_arity;
+   std::vector<int> ins;
+   for (uint32_t i = 0; i < n_in; ++i) ins.push_back(el.add(FZ_IR_INPUT, -1, -1, 0.f, i));   // front panel
+   std::vector<int> outs = el.run(e, ins);
+   if ((int)outs.size() != e->out_arity) fail(FZ_E_GRAPH, "output arity mismatch between arity table and routing");
+   if (outs.empty()) fail(FZ_E_GRAPH, "graph has no output wire");
+
+   auto& raw = el.raw;
+   const size_t N = raw.size();
+   // resolve forward references in every operand
+   for (size_t i = 0; i < N; ++i) {
+      if (raw[i].kind == K_FWD) continue;
+      if (raw[i].a >= 0) raw[i].a = el.resolve(raw[i].a);
+      if (raw[i].b >= 0) raw[i].b = el.resolve(raw[i].b);
+   }
+   for (auto& o : outs) o = el.resolve(o);
+
+   // reachability: same-sample operands, plus the source of every reachable delayed read
+   std::vector<char> live(N, 0);
+   {
+      std::vector<int> work(outs.begin(), outs.end());
+      for (uint32_t i = 0; i < n_in; ++i) work.push_back(ins[i]);
+      while (!work.empty()) {
+         int v = work.back();
+         work.pop_back();
+         if (live[(size_t)v]) continue;
+         live[(size_t)v] = 1;
+         if (raw[(size_t)v].a >= 0) work.push_back(raw[(size_t)v].a);
+         if (raw[(size_t)v].b >= 0) work.push_back(raw[(size_t)v].b);
+      }
+   }
+
+   // topological order of the same-sample dependencies (delayed reads are sources)
+   std::vector<int> order;
+   {
+      std::vector<char> color(N, 0);   // 0 white, 1 on stack, 2 done
+      struct Frame { int v; int stage; };
+      auto visit = [&](int root) {
+         if (color[(size_t)root]) return;
+         std::vector<Frame> st;
+         st.push_back({root, 0});
+         color[(size_t)root] = 1;
+         while (!st.empty()) {
+            Frame& f = st.back();
+            const Raw& r = raw[(size_t)f.v];
+            int dep = -1;
+            if (r.kind != FZ_IR_DELAY) {
+               if (f.stage == 0) { dep = r.a; f.stage = 1; }
+               else if (f.stage == 1) { dep = r.b; f.stage = 2; }
+               else f.stage = 3;
+            } else f.stage = 3;
+            if (f.stage == 3) {
+               color[(size_t)f.v] = 2;
+               order.push_back(f.v);
+               st.pop_back();
+               continue;
+            }
+            if (dep < 0) continue;
+            if (color[(size_t)dep] == 1)
+               fail(FZ_E_GRAPH, "delay-free feedback loop: every cycle needs at least one delayed read _i[_n]");
+            if (color[(size_t)dep] == 0) {
+               color[(size_t)dep] = 1;
+               st.push_back({dep, 0});
+            }
+         }
+      };
+      for (uint32_t i = 0; i < n_in; ++i) visit(ins[i]);
+      for (int o : outs) visit(o);
+      // sources of delayed reads that are not otherwise needed this sample
+      for (size_t i = 0; i < N; ++i)
+         if (live[i] && raw[i].kind == FZ_IR_DELAY) visit(raw[i].a);
+      for (size_t i = 0; i < N; ++i)
+         if (live[i]) visit((int)i);
+   }
+
+   // uniform coefficient slots: one per distinct bit pattern
+   Graph g;
+   std::map<uint32_t, uint32_t> const_slot;
+   auto slot_of = [&](float v) {
+      auto it = const_slot.find(bits_of(v));
+      if (it != const_slot.end()) return it->second;
+      uint32_t s = (uint32_t)g.consts.size();
+      g.consts.push_back(v);
+      const_slot[bits_of(v)] = s;
+      return s;
+   };
+
+   // common-subexpression merging to a fixpoint (delayed reads may reference later nodes)
+   std::vector<int> rep(N);
+   for (size_t i = 0; i < N; ++i) rep[i] = (int)i;
+   for (bool changed = true; changed;) {
+      changed = false;
+      std::map<std::tuple<uint32_t, int, int, uint32_t>, int> seen;
+      for (int v : order) {
+         const Raw& r = raw[(size_t)v];
+         std::tuple<uint32_t, int, int, uint32_t> key;
+         switch (r.kind) {
+            case FZ_IR_INPUT: key = {r.kind, -1, -1, r.n}; break;
+            case FZ_IR_CONST: key = {r.kind, -1, -1, bits_of(r.value)}; break;
+            case FZ_IR_PARAM: key = {r.kind, -1, -1, r.n}; break;
+            case FZ_IR_DELAY: key = {r.kind, rep[(size_t)r.a], -1, r.n}; break;
+            case FZ_IR_NEG: key = {r.kind, rep[(size_t)r.a], -1, 0}; break;
+            default: key = {r.kind, rep[(size_t)r.a], rep[(size_t)r.b], 0}; break;
+         }
+         auto it = seen.find(key);
+         int nv = v;
+         if (it == seen.end()) seen[key] = v; else nv = it->second;
+         if (rep[(size_t)v] != nv) { rep[(size_t)v] = nv; changed = true; }
+      }
+   }
+
+   // renumber representatives in evaluation order
+   std::vector<int> newid(N, -1);
+   for (int v : order) {
+      if (rep[(size_t)v] != v) continue;
+      newid[(size_t)v] = (int)g.nodes.size();
+      g.nodes.push_back(Node{});
+   }
+   auto nid = [&](int rawid) { return (uint32_t)newid[(size_t)rep[(size_t)rawid]]; };
+   for (int v : order) {
+      if (rep[(size_t)v] != v) continue;
+      const Raw& r = raw[(size_t)v];
+      Node& n = g.nodes[(size_t)newid[(size_t)v]];
+      n.kind = r.kind;
+      switch (r.kind) {
+         case FZ_IR_INPUT: n.a = r.n; break;
+         case FZ_IR_CONST: n.a = slot_of(r.value); n.value = r.value; break;
+         case FZ_IR_PARAM: n.a = r.n; g.n_param = std::max(g.n_param, r.n + 1); break;
+         case FZ_IR_DELAY: n.a = nid(r.a); n.b = r.n; break;
+         case FZ_IR_NEG: n.a = nid(r.a); ++g.n_ops; break;
+         default: n.a = nid(r.a); n.b = nid(r.b); ++g.n_ops; break;
+      }
+   }
+   g.n_in = n_in;
+   g.n_out = (uint32_t)outs.size();
+   for (int o : outs) g.outputs.push_back(nid(o));
+
+   // delay lines: one per delayed wire, depth = deepest reader
+   std::map<uint32_t, uint32_t> depth;
+   for (const Node& n : g.nodes)
+      if (n.kind == FZ_IR_DELAY) depth[n.a] = std::max(depth[n.a], n.b);
+   g.line_of_node.assign(g.nodes.size(), -1);
+   uint32_t row = 0, lds = 0;
+   for (auto& kv : depth) {
+      Line l{};
+      l.src = kv.first;
+      l.depth = kv.second;
+      l.row0 = row;
+      l.in_lds = l.depth > kRegMaxDepth;
+      if (l.in_lds) {
+         uint32_t sz = 1;
+         while (sz < l.depth) sz <<= 1;
+         l.lds_slot0 = lds;
+         l.lds_size = sz;
+         lds += sz;
+      }
+      row += l.depth;
+      g.max_delay = std::max(g.max_delay, l.depth);
+      g.line_of_node[l.src] = (int)g.lines.size();
+      g.lines.push_back(l);
+   }
+   g.n_state = row;
+   g.n_lds_slots = lds;
+   return g;
+}
+
+}  // namespace fz

@@ -1,0 +1,415 @@
+// Runtime of libflowz_hip: hiprtc build + on-disk code-object cache, module loading, the launch
+// of the fused block kernel, device-resident closure state (fz_bank) and the AOT utility kernels
+// (synthetic input fill, copy-bandwidth probe).  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "fz_internal.hpp"
+
+namespace fz {
+
+#define FZ_HIP(call)                                                                            \
+   do {                                                                                         \
+      hipError_t e_ = (call);                                                                   \
+      if (e_ != hipSuccess)                                                                     \
+         fail(FZ_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                     \
+   } while (0)
+
+int device_count()
+{
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+   }
+   return n;
+}
+
+static void require_device()
+{
+   if (device_count() <= 0)
+      fail(FZ_E_NO_DEVICE, "no HIP device visible: libflowz_hip evaluates flow-graphs on an MI355X only "
+                           "(there is no CPU fallback in the product path)");
+}
+
+// ---- kernel cache -----------------------------------------------------------------------------------
+static const char* const kBuildOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                                            "-fhip-fp32-correctly-rounded-divide-sqrt"};
+constexpr int kNumBuildOptions = 5;
+
+static uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
+{
+   for (unsigned char ch : s) {
+      h ^= ch;
+      h *= 1099511628211ull;
+   }
+   return h;
+}
+
+static std::string cache_dir()
+{
+   if (const char* env = std::getenv("FLOWZ_HIP_CACHE")) return env;
+   Dl_info info;
+   if (dladdr((const void*)&cache_dir, &info) && info.dli_fname) {
+      std::string p = info.dli_fname;                // .../zignal_amd/lib/libflowz_hip.so
+      size_t s = p.rfind('/');
+      if (s != std::string::npos) p = p.substr(0, s);
+      s = p.rfind('/');
+      if (s != std::string::npos) p = p.substr(0, s);
+      return p + "/_kcache";
+   }
+   return "/tmp/flowz_hip_kcache";
+}
+
+static std::vector<char> jit_compile(const Graph& g, const Variant& v)
+{
+   const std::string cfg = gen_config(g, v), body = gen_body(g, v);
+   const char* headers[2] = {cfg.c_str(), body.c_str()};
+   const char* names[2] = {"fz_graph_config.h", "fz_graph_body.h"};
+   hiprtcProgram prog;
+   if (hiprtcCreateProgram(&prog, skeleton_source(), "fz_block_kernel.hip", 2, headers, names) != HIPRTC_SUCCESS)
+      fail(FZ_E_COMPILE, "hiprtcCreateProgram failed");
+   hiprtcResult r = hiprtcCompileProgram(prog, kNumBuildOptions, const_cast<const char**>(kBuildOptions));
+   if (r != HIPRTC_SUCCESS) {
+      size_t n = 0;
+      hiprtcGetProgramLogSize(prog, &n);
+      std::string log(n, ' ');
+      if (n) hiprtcGetProgramLog(prog, &log[0]);
+      hiprtcDestroyProgram(&prog);
+      fail(FZ_E_COMPILE, std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log);
+   }
+   size_t n = 0;
+   hiprtcGetCodeSize(prog, &n);
+   std::vector<char> code(n);
+   hiprtcGetCode(prog, code.data());
+   hiprtcDestroyProgram(&prog);
+   return code;
+}
+
+std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, bool need_load)
+{
+   std::lock_guard<std::mutex> lock(p->mu);
+   auto& slot = p->kernels[v];
+   if (!slot) {
+      auto k = std::make_shared<Kernel>();
+      std::string key_src = full_source(p->g, v);
+      for (int i = 0; i < kNumBuildOptions; ++i) key_src += kBuildOptions[i];
+      int rtc_major = 0, rtc_minor = 0;
+      hiprtcVersion(&rtc_major, &rtc_minor);
+      key_src += "hiprtc" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor);
+      char name[64];
+      std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)fnv1a(key_src));
+      const std::string dir = cache_dir(), path = dir + name;
+      bool hit = false;
+      if (!std::getenv("FLOWZ_HIP_NO_CACHE")) {
+         std::ifstream f(path, std::ios::binary);
+         if (f) {
+            k->code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+            hit = k->code.size() > 64;
+         }
+      }
+      if (!hit) {
+         k->code = jit_compile(p->g, v);
+         if (!std::getenv("FLOWZ_HIP_NO_CACHE")) {
+            ::mkdir(dir.c_str(), 0755);
+            const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+            std::ofstream f(tmp, std::ios::binary);
+            if (f) {
+               f.write(k->code.data(), (std::streamsize)k->code.size());
+               f.close();
+               ::rename(tmp.c_str(), path.c_str());
+            }
+         }
+      }
+      slot = k;
+   }
+   if (need_load && !slot->loaded) {
+      require_device();
+      hipModule_t mod;
+      FZ_HIP(hipModuleLoadData(&mod, slot->code.data()));
+      hipFunction_t fn;
+      FZ_HIP(hipModuleGetFunction(&fn, mod, "fz_block_kernel"));
+      slot->module = mod;
+      slot->function = fn;
+      slot->loaded = true;
+   }
+   return slot;
+}
+
+// ---- variant selection ---------------------------------------------------------------------------------
+Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams)
+{
+   Variant v;
+   const uint32_t reqP = uv ? uv->streams_per_lane : 0, reqU = uv ? uv->unroll : 0, reqB = uv ? uv->block_threads : 0;
+   v.flags = uv ? uv->flags : 0;
+   if (reqP != 0 && reqP != 1 && reqP != 2 && reqP != 4) fail(FZ_E_INVALID, "streams_per_lane must be 0, 1, 2 or 4");
+   if (reqU > 32) fail(FZ_E_INVALID, "unroll must be <= 32");
+   if (reqB != 0 && (reqB % 64 != 0 || reqB > 1024)) fail(FZ_E_INVALID, "block_threads must be a multiple of 64, <= 1024");
+   if (reqP) {
+      if (n_streams % reqP) fail(FZ_E_INVALID, "n_streams must be a multiple of streams_per_lane");
+      v.P = reqP;
+   } else {
+      // fill the chip first (256 CUs x 4 SIMDs, several waves each), then pack two streams per lane
+      v.P = (n_streams >= (1u << 19) && n_streams % 2 == 0) ? 2 : 1;
+   }
+   v.U = reqU ? reqU : 8;
+   v.block = reqB ? reqB : 256;
+   if (g.n_lds_slots) {
+      // LDS rings: slots * block * 4P bytes must fit the 64 KiB static limit
+      auto bytes = [&](const Variant& w) { return (uint64_t)g.n_lds_slots * w.block * 4u * w.P; };
+      while (bytes(v) > 65536 && !reqB && v.block > 64) v.block /= 2;
+      while (bytes(v) > 65536 && !reqP && v.P > 1) v.P /= 2;
+      if (bytes(v) > 65536)
+         fail(FZ_E_UNSUPPORTED, "delay lines too long for the LDS ring buffers of this build (" +
+                                   std::to_string(g.n_lds_slots) + " slots)");
+   }
+   return v;
+}
+
+// ---- launch ------------------------------------------------------------------------------------------------
+struct ArgsHeader {
+   const float* in;
+   float* out;
+   float* state;
+   const float* params;
+   unsigned long long n_streams;
+   unsigned int n_samples;
+   unsigned int n_groups;
+};
+
+int launch(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+           uint32_t n_samples, const fz_variant* uv, void* stream)
+{
+   const Graph& g = p->g;
+   if (n_streams == 0 || n_samples == 0) fail(FZ_E_INVALID, "n_streams and n_samples must be > 0");
+   if (!out) fail(FZ_E_INVALID, "out is null");
+   if (g.n_in && !in) fail(FZ_E_INVALID, "in is null but the graph has input wires");
+   if (g.n_state && !state) fail(FZ_E_INVALID, "state is null but the graph has delay lines");
+   if (g.n_param && !params) fail(FZ_E_INVALID, "params is null but the graph has per-stream coefficients");
+   auto mis = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
+   if (mis(in) || mis(out) || mis(state) || mis(params)) fail(FZ_E_INVALID, "device pointers must be 16-byte aligned");
+   const uint64_t wmax = std::max<uint64_t>(std::max(g.n_in, g.n_out), 1);
+   if (n_streams * wmax >= (1ull << 30)) fail(FZ_E_UNSUPPORTED, "row longer than 4 GiB: shard the streams");
+   require_device();
+   const Variant v = resolve_variant(g, uv, n_streams);
+   auto k = get_kernel(p, v, true);
+
+   std::vector<char> buf(sizeof(ArgsHeader) + sizeof(float) * std::max<size_t>(g.consts.size(), 1));
+   ArgsHeader h{in, out, state, params, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P)};
+   std::memcpy(buf.data(), &h, sizeof h);
+   {
+      std::lock_guard<std::mutex> lock(p->mu);
+      if (!g.consts.empty()) std::memcpy(buf.data() + sizeof h, g.consts.data(), sizeof(float) * g.consts.size());
+   }
+   size_t size = buf.size();
+   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+   const unsigned grid = (unsigned)((h.n_groups + v.block - 1) / v.block);
+   FZ_HIP(hipModuleLaunchKernel((hipFunction_t)k->function, grid, 1, 1, v.block, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
+   return FZ_OK;
+}
+
+// ---- AOT utility kernels ---------------------------------------------------------------------------------------
+typedef float fzr_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned fmix32(unsigned h)
+{
+   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+   return h;
+}
+
+// dst[t][s][w] for one row t per blockIdx.y; a thread produces 4 consecutive floats of the row
+__global__ void __launch_bounds__(256) fz_synth_fill_kernel(float* dst, unsigned long long row_floats, unsigned n_wires,
+                                                            unsigned seed, unsigned long long stream0,
+                                                            unsigned long long t0, unsigned n_rows)
+{
+   const unsigned long long i0 = ((unsigned long long)blockIdx.x * 256u + threadIdx.x) * 4ull;
+   if (i0 >= row_floats) return;
+   for (unsigned t = blockIdx.y; t < n_rows; t += gridDim.y) {
+      const unsigned tt = (unsigned)((t0 + t) * 0x85EBCA6Bull);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+         const unsigned long long sid = stream0 * n_wires + i0 + j;     // (stream0+s)*n_wires + w
+         const unsigned h = fmix32(fmix32(seed ^ (unsigned)(sid * 0x9E3779B9ull) ^ tt));
+         v[j] = (float)(int)(h >> 8) * 0x1p-23f - 1.0f;
+      }
+      float* row = dst + (size_t)t * row_floats;
+      if (i0 + 4 <= row_floats && (row_floats & 3ull) == 0) {   // rows stay 16-byte aligned
+         fzr_f4 q = {v[0], v[1], v[2], v[3]};
+         __builtin_nontemporal_store(q, reinterpret_cast<fzr_f4*>(row + i0));
+      } else {
+         for (int j = 0; j < 4 && i0 + j < row_floats; ++j) row[i0 + j] = v[j];
+      }
+   }
+}
+
+__global__ void __launch_bounds__(256) fz_copy_kernel(const fzr_f4* __restrict__ src, fzr_f4* __restrict__ dst,
+                                                      unsigned long long n4)
+{
+   unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+   const unsigned long long stride = (unsigned long long)gridDim.x * 256u;
+   for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+}  // namespace fz
+
+using namespace fz;
+
+#define FZ_GUARD(...)                                                           \
+   try { __VA_ARGS__ }                                                                 \
+   catch (const fz::Error& er) { fz::set_error(er.msg); return er.code; }       \
+   catch (const std::exception& ex) { fz::set_error(ex.what()); return FZ_E_INVALID; }
+
+struct fz_bank {
+   fz_program* prog = nullptr;
+   uint64_t n_streams = 0;
+   float* state = nullptr;
+   float* params = nullptr;
+   float* stage_in = nullptr;
+   float* stage_out = nullptr;
+   size_t stage_in_cap = 0, stage_out_cap = 0;
+};
+
+extern "C" {
+
+int fz_device_count(void) { return fz::device_count(); }
+
+int fz_synth_fill(float* dst, uint64_t n_streams, uint32_t n_samples, uint32_t n_wires, uint32_t seed,
+                  uint64_t stream0, uint64_t t0, void* hip_stream)
+{
+   FZ_GUARD(
+      if (!dst || !n_streams || !n_samples || !n_wires) fail(FZ_E_INVALID, "fz_synth_fill: bad arguments");
+      require_device();
+      const unsigned long long row = n_streams * n_wires;
+      dim3 grid((unsigned)((row + 1023) / 1024), std::min<uint32_t>(n_samples, 64u));
+      hipLaunchKernelGGL(fz_synth_fill_kernel, grid, dim3(256), 0, (hipStream_t)hip_stream, dst, row, n_wires, seed,
+                         (unsigned long long)stream0, (unsigned long long)t0, n_samples);
+      FZ_HIP(hipGetLastError());
+      return FZ_OK;)
+}
+
+int fz_copy_probe(const float* src, float* dst, uint64_t n_floats, void* hip_stream)
+{
+   FZ_GUARD(
+      if (!src || !dst || (n_floats & 3)) fail(FZ_E_INVALID, "fz_copy_probe: need non-null pointers and n_floats % 4 == 0");
+      require_device();
+      hipLaunchKernelGGL(fz_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)hip_stream,
+                         (const fzr_f4*)src, (fzr_f4*)dst, (unsigned long long)(n_floats / 4));
+      FZ_HIP(hipGetLastError());
+      return FZ_OK;)
+}
+
+// ---- fz_bank -------------------------------------------------------------------------------------------------
+int fz_bank_create(fz_program* p, uint64_t n_streams, fz_bank** out)
+{
+   FZ_GUARD(
+      if (!p || !out || !n_streams) fail(FZ_E_INVALID, "fz_bank_create: bad arguments");
+      require_device();
+      auto* b = new fz_bank();
+      b->prog = p;
+      b->n_streams = n_streams;
+      const size_t sb = std::max<size_t>((size_t)p->g.n_state * n_streams * 4, 16);
+      FZ_HIP(hipMalloc((void**)&b->state, sb));
+      FZ_HIP(hipMemset(b->state, 0, sb));                 // zero-initialised float state, flowz.hpp:1245
+      if (p->g.n_param) {
+         const size_t pb = (size_t)p->g.n_param * n_streams * 4;
+         FZ_HIP(hipMalloc((void**)&b->params, pb));
+         FZ_HIP(hipMemset(b->params, 0, pb));
+      }
+      *out = b;
+      return FZ_OK;)
+}
+
+int fz_bank_clone(const fz_bank* src, fz_bank** out)
+{
+   FZ_GUARD(
+      if (!src || !out) fail(FZ_E_INVALID, "fz_bank_clone: bad arguments");
+      fz_bank* b = nullptr;
+      int rc = fz_bank_create(src->prog, src->n_streams, &b);
+      if (rc != FZ_OK) return rc;
+      const size_t sb = (size_t)src->prog->g.n_state * src->n_streams * 4;
+      if (sb) FZ_HIP(hipMemcpy(b->state, src->state, sb, hipMemcpyDeviceToDevice));
+      if (src->params)
+         FZ_HIP(hipMemcpy(b->params, src->params, (size_t)src->prog->g.n_param * src->n_streams * 4, hipMemcpyDeviceToDevice));
+      *out = b;
+      return FZ_OK;)
+}
+
+void fz_bank_destroy(fz_bank* b)
+{
+   if (!b) return;
+   (void)hipFree(b->state);
+   (void)hipFree(b->params);
+   (void)hipFree(b->stage_in);
+   (void)hipFree(b->stage_out);
+   delete b;
+}
+
+int fz_bank_reset(fz_bank* b)
+{
+   FZ_GUARD(
+      if (!b) fail(FZ_E_INVALID, "null bank");
+      const size_t sb = (size_t)b->prog->g.n_state * b->n_streams * 4;
+      if (sb) FZ_HIP(hipMemset(b->state, 0, sb));
+      return FZ_OK;)
+}
+
+int fz_bank_set_params_host(fz_bank* b, const float* params)
+{
+   FZ_GUARD(
+      if (!b || !params) fail(FZ_E_INVALID, "fz_bank_set_params_host: bad arguments");
+      if (!b->params) fail(FZ_E_INVALID, "graph has no per-stream coefficients");
+      FZ_HIP(hipMemcpy(b->params, params, (size_t)b->prog->g.n_param * b->n_streams * 4, hipMemcpyHostToDevice));
+      return FZ_OK;)
+}
+
+float* fz_bank_state_device(fz_bank* b) { return b ? b->state : nullptr; }
+
+int fz_bank_process(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples, const fz_variant* v, void* hip_stream)
+{
+   FZ_GUARD(
+      if (!b) fail(FZ_E_INVALID, "null bank");
+      const Graph& g = b->prog->g;
+      return fz::launch(b->prog, in_dev, out_dev, g.n_state ? b->state : nullptr, b->params, b->n_streams, n_samples, v, hip_stream);)
+}
+
+int fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint32_t n_samples)
+{
+   FZ_GUARD(
+      if (!b || !out_host || !n_samples) fail(FZ_E_INVALID, "fz_bank_process_host: bad arguments");
+      const Graph& g = b->prog->g;
+      const size_t ib = (size_t)n_samples * b->n_streams * g.n_in * 4, ob = (size_t)n_samples * b->n_streams * g.n_out * 4;
+      if (ib > b->stage_in_cap) {
+         (void)hipFree(b->stage_in);
+         b->stage_in = nullptr;
+         FZ_HIP(hipMalloc((void**)&b->stage_in, ib));
+         b->stage_in_cap = ib;
+      }
+      if (ob > b->stage_out_cap) {
+         (void)hipFree(b->stage_out);
+         b->stage_out = nullptr;
+         FZ_HIP(hipMalloc((void**)&b->stage_out, ob));
+         b->stage_out_cap = ob;
+      }
+      if (ib) {
+         if (!in_host) fail(FZ_E_INVALID, "in_host is null but the graph has input wires");
+         FZ_HIP(hipMemcpy(b->stage_in, in_host, ib, hipMemcpyHostToDevice));
+      }
+      int rc = fz::launch(b->prog, g.n_in ? b->stage_in : nullptr, b->stage_out, g.n_state ? b->state : nullptr, b->params,
+                          b->n_streams, n_samples, nullptr, nullptr);
+      if (rc != FZ_OK) return rc;
+      FZ_HIP(hipMemcpy(out_host, b->stage_out, ob, hipMemcpyDeviceToHost));
+      return FZ_OK;)
+}
+
+}  // extern "C"

@@ -1,0 +1,31 @@
+"""Multi-GPU sharding of independent streams (one process per GPU, torch.distributed).
+
+Streams never exchange data (each is a private closure, flowz.hpp:1181-1230), so the data path
+has NO collective: rank r owns a contiguous range of global stream ids and generates / receives
+only those.  The single collective is the reduction of run statistics at the end (RCCL over
+xGMI when the backend is "nccl", gloo on CPU): a handful of doubles.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+
+def shard_range(n_streams_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [begin, end) of global stream ids for `rank`; sizes differ by at most one."""
+    q, r = divmod(int(n_streams_total), int(world))
+    begin = rank * q + min(rank, r)
+    return begin, begin + q + (1 if rank < r else 0)
+
+
+def reduce_stats(seconds: float, samples: float, checksum: float, device=None) -> Dict[str, float]:
+    """max(seconds), sum(samples), sum(checksum) over all ranks (identity when not distributed)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return {"seconds": float(seconds), "samples": float(samples), "checksum": float(checksum), "world": 1}
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    s = torch.tensor([samples, checksum], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    return {"seconds": float(t[0]), "samples": float(s[0]), "checksum": float(s[1]), "world": dist.get_world_size()}

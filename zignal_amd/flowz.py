@@ -1,0 +1,291 @@
+"""Python mirror of the Flowz EDSL (reference: flowz/flowz.hpp) over the C ABI of libflowz_hip.
+
+Same surface as the C++ front end in include/flowz/flowz.hpp, spelled with what Python's
+grammar allows:
+
+    reference (C++)            here
+    _1 .. _6                   _1 .. _6, placeholder(i)            flowz.hpp:1252-1257, :78-82
+    _1[_2]                     _1[_2]  (or _1[-2], _1[2])          :84-85
+    a , b                      chan(a, b, ...)  or a tuple (a, b)  :90
+    a | b                      a | b                               :91
+    a |= b                     a >> b  (`|=` is a statement in Python; `>>` is the sequence
+                               operator of the reference's first prototype,
+                               experimental_steps/wires_mono_only.cpp:37), seq(a, b, ...) for
+                               C++'s right-associative chaining
+    ~a                         ~a                                  :93
+    + - * / unary -            same; Python numbers become float32 literal terminals   :68-72, :769-772
+    std::ref(x)                param(k): per-stream, block-constant coefficient k (flowz/README.md:42-61)
+    compile(expr)              compile(expr) -> Program            :1233-1249
+
+A Program evaluates blocks on the GPU only (Program.run_block / Bank); there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Iterable, Optional, Sequence
+
+from . import _capi as C
+from ._capi import FlowzError, NoDeviceError, Variant  # noqa: F401  (re-exported)
+
+
+class Expr:
+    """Immutable handle of a Flowz expression tree (value semantics, flowz.hpp:46-61)."""
+
+    __slots__ = ("_h",)
+
+    def __init__(self, handle):
+        self._h = C.check_ptr(handle)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and C is not None:
+            try:
+                C.lib.fz_expr_release(h)
+            except Exception:
+                pass
+
+    # -- analysis (flowz.hpp:162-246, :443-506) ------------------------------------------
+    @property
+    def ins(self) -> int:
+        return C.check(C.lib.fz_input_arity(self._h))
+
+    @property
+    def outs(self) -> int:
+        return C.check(C.lib.fz_output_arity(self._h))
+
+    def max_input_delays(self):
+        n = C.check(C.lib.fz_max_input_delays(self._h, None, 0))
+        buf = (ctypes.c_uint32 * max(n, 1))()
+        C.check(C.lib.fz_max_input_delays(self._h, buf, n))
+        return tuple(buf[i] for i in range(n))
+
+    # -- arithmetic ------------------------------------------------------------------------
+    def _ar(self, op, other, swap=False):
+        o = as_expr(other)
+        a, b = (o, self) if swap else (self, o)
+        return Expr(C.lib.fz_arith(op, a._h, b._h))
+
+    def __add__(self, o): return self._ar(C.FZ_OP_ADD, o)
+    def __radd__(self, o): return self._ar(C.FZ_OP_ADD, o, True)
+    def __sub__(self, o): return self._ar(C.FZ_OP_SUB, o)
+    def __rsub__(self, o): return self._ar(C.FZ_OP_SUB, o, True)
+    def __mul__(self, o): return self._ar(C.FZ_OP_MUL, o)
+    def __rmul__(self, o): return self._ar(C.FZ_OP_MUL, o, True)
+    def __truediv__(self, o): return self._ar(C.FZ_OP_DIV, o)
+    def __rtruediv__(self, o): return self._ar(C.FZ_OP_DIV, o, True)
+    def __neg__(self): return Expr(C.lib.fz_arith(C.FZ_OP_NEG, self._h, None))
+
+    # -- combinators -----------------------------------------------------------------------
+    def __or__(self, o): return Expr(C.lib.fz_parallel(self._h, as_expr(o)._h))
+    def __ror__(self, o): return Expr(C.lib.fz_parallel(as_expr(o)._h, self._h))
+    def __rshift__(self, o): return Expr(C.lib.fz_sequence(self._h, as_expr(o)._h))
+    def __rrshift__(self, o): return Expr(C.lib.fz_sequence(as_expr(o)._h, self._h))
+    def __invert__(self): return Expr(C.lib.fz_feedback(self._h))
+
+
+class Placeholder(Expr):
+    __slots__ = ("index",)
+
+    def __init__(self, i: int):
+        super().__init__(C.lib.fz_placeholder(int(i)))
+        self.index = int(i)
+
+    def __getitem__(self, d):
+        """_i[_n] (reference syntax), _i[-n] (delay_expression.cpp:99-100 spelling) or _i[n]."""
+        n = d.index if isinstance(d, Placeholder) else abs(int(d))
+        return Expr(C.lib.fz_delayed(self.index, n))
+
+
+def placeholder(i: int) -> Placeholder:
+    return Placeholder(i)
+
+
+_1, _2, _3, _4, _5, _6 = (Placeholder(i) for i in range(1, 7))
+
+
+def lit(v: float) -> Expr:
+    return Expr(C.lib.fz_literal(float(v)))
+
+
+def param(k: int) -> Expr:
+    return Expr(C.lib.fz_stream_param(int(k)))
+
+
+def as_expr(x) -> Expr:
+    if isinstance(x, Expr):
+        return x
+    if isinstance(x, tuple):
+        return chan(*x)
+    if isinstance(x, (int, float)) or hasattr(x, "__float__"):
+        return lit(float(x))
+    raise TypeError(f"cannot use {type(x).__name__} in a Flowz expression")
+
+
+def chan(*xs) -> Expr:
+    """(a, b, c): C++ comma is left-associative."""
+    r = as_expr(xs[0])
+    for x in xs[1:]:
+        r = Expr(C.lib.fz_channel(r._h, as_expr(x)._h))
+    return r
+
+
+def par(*xs) -> Expr:
+    r = as_expr(xs[0])
+    for x in xs[1:]:
+        r = r | as_expr(x)
+    return r
+
+
+def seq(*xs) -> Expr:
+    """a |= b |= c: C++ `|=` is right-associative, a |= (b |= c)."""
+    r = as_expr(xs[-1])
+    for x in reversed(xs[:-1]):
+        r = as_expr(x) >> r
+    return r
+
+
+def from_sexpr(e) -> Expr:
+    """Build from the neutral s-expression notation shared with the test-suite."""
+    k = e[0]
+    if k == "in": return Placeholder(e[1])
+    if k == "del": return Placeholder(e[1])[int(e[2])]
+    if k == "lit": return lit(e[1])
+    if k == "param": return param(e[1])
+    if k == "neg": return -from_sexpr(e[1])
+    if k == "fb": return ~from_sexpr(e[1])
+    a, b = from_sexpr(e[1]), from_sexpr(e[2])
+    if k == "add": return a + b
+    if k == "sub": return a - b
+    if k == "mul": return a * b
+    if k == "div": return a / b
+    if k == "chan": return chan(a, b)
+    if k == "par": return a | b
+    if k == "seq": return a >> b
+    raise ValueError(f"unknown s-expression node {k!r}")
+
+
+def make_variant(streams_per_lane=0, unroll=0, block_threads=0, flags=0) -> Variant:
+    return Variant(int(streams_per_lane), int(unroll), int(block_threads), int(flags))
+
+
+class Program:
+    """compile() result: lowered graph + its fused gfx950 kernels (flowz.hpp:1233-1249)."""
+
+    def __init__(self, expr):
+        self.expr = as_expr(expr)
+        h = ctypes.c_void_p()
+        C.check(C.lib.fz_compile(self.expr._h, ctypes.byref(h)))
+        self._h = h
+        info = C.Info()
+        C.check(C.lib.fz_program_info(self._h, ctypes.byref(info)))
+        self.info = info
+        for f, _ in C.Info._fields_:
+            setattr(self, f, getattr(info, f))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and C is not None:
+            try:
+                C.lib.fz_program_destroy(h)
+            except Exception:
+                pass
+
+    # -- inspection ------------------------------------------------------------------------
+    def ir(self):
+        n = C.check(C.lib.fz_program_ir(self._h, None, 0))
+        buf = (C.IrNode * max(n, 1))()
+        C.check(C.lib.fz_program_ir(self._h, buf, n))
+        return [(C.IR_KINDS[buf[i].kind], buf[i].a, buf[i].b, buf[i].value) for i in range(n)]
+
+    def outputs(self):
+        buf = (ctypes.c_uint32 * max(self.n_out, 1))()
+        C.check(C.lib.fz_program_outputs(self._h, buf, self.n_out))
+        return [buf[i] for i in range(self.n_out)]
+
+    def lines(self):
+        n = self.n_lines
+        s, d = (ctypes.c_uint32 * max(n, 1))(), (ctypes.c_uint32 * max(n, 1))()
+        C.check(C.lib.fz_program_lines(self._h, s, d, n))
+        return [(s[i], d[i]) for i in range(n)]
+
+    def consts(self):
+        out = []
+        for k in range(self.n_const):
+            v = ctypes.c_float()
+            C.check(C.lib.fz_program_get_const(self._h, k, ctypes.byref(v)))
+            out.append(v.value)
+        return out
+
+    def set_const(self, slot: int, value: float):
+        C.check(C.lib.fz_program_set_const(self._h, int(slot), float(value)))
+
+    def source(self, variant: Optional[Variant] = None) -> str:
+        vp = ctypes.byref(variant) if variant is not None else None
+        n = C.check(C.lib.fz_program_source(self._h, vp, None, 0))
+        buf = ctypes.create_string_buffer(n + 1)
+        C.check(C.lib.fz_program_source(self._h, vp, buf, n + 1))
+        return buf.value.decode()
+
+    def build(self, variant: Optional[Variant] = None):
+        """JIT-compile (or fetch from the on-disk cache) the kernel of `variant`; needs no GPU."""
+        C.check(C.lib.fz_program_build(self._h, ctypes.byref(variant) if variant is not None else None))
+        return self
+
+    # -- the hot path ----------------------------------------------------------------------
+    def run_block_ptr(self, in_ptr, out_ptr, state_ptr, params_ptr, n_streams, n_samples,
+                      variant: Optional[Variant] = None, stream=None):
+        C.check(C.lib.fz_run_block(self._h, in_ptr, out_ptr, state_ptr, params_ptr, int(n_streams), int(n_samples),
+                                   ctypes.byref(variant) if variant is not None else None, stream))
+
+    def run_block(self, x, state=None, params=None, out=None, variant: Optional[Variant] = None):
+        """x: CUDA float32 tensor [T, n_streams, n_in] (time-major frames).  state: [n_state, n_streams]
+        in/out (allocated zeroed when None), params: [n_param, n_streams].  Launches on torch's
+        current stream; returns (out [T, n_streams, n_out], state)."""
+        import torch
+
+        if not x.is_cuda:
+            raise NoDeviceError(C.FZ_E_NO_DEVICE, "run_block needs CUDA (ROCm) tensors: zignal_amd has no CPU path")
+        if x.dim() == 2:
+            x = x.unsqueeze(-1)
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[2] == self.n_in, (x.shape, self.n_in)
+        T, ns = x.shape[0], x.shape[1]
+        if out is None:
+            out = torch.empty((T, ns, self.n_out), dtype=torch.float32, device=x.device)
+        if state is None:
+            state = torch.zeros((max(self.n_state, 1), ns), dtype=torch.float32, device=x.device)
+        assert state.is_contiguous() and out.is_contiguous()
+        pp = None
+        if self.n_param:
+            assert params is not None and params.is_contiguous() and tuple(params.shape) == (self.n_param, ns)
+            pp = params.data_ptr()
+        self.run_block_ptr(x.data_ptr() if self.n_in else None, out.data_ptr(),
+                           state.data_ptr() if self.n_state else None, pp, ns, T, variant,
+                           torch.cuda.current_stream().cuda_stream)
+        return out, state
+
+
+def compile(expr) -> Program:  # noqa: A001  (mirrors flowz::compile)
+    return Program(expr)
+
+
+def device_count() -> int:
+    return C.lib.fz_device_count()
+
+
+def synth_fill(dst, seed: int, stream0: int = 0, t0: int = 0):
+    """Fill CUDA tensor dst [T, n_streams, n_wires] with the deterministic hash noise."""
+    import torch
+
+    T, ns, nw = dst.shape
+    assert dst.is_cuda and dst.dtype == torch.float32 and dst.is_contiguous()
+    C.check(C.lib.fz_synth_fill(dst.data_ptr(), ns, T, nw, int(seed), int(stream0), int(t0),
+                                torch.cuda.current_stream().cuda_stream))
+    return dst
+
+
+def copy_probe(src, dst):
+    import torch
+
+    assert src.is_cuda and dst.is_cuda and src.numel() == dst.numel() and src.numel() % 4 == 0
+    C.check(C.lib.fz_copy_probe(src.data_ptr(), dst.data_ptr(), src.numel(),
+                                torch.cuda.current_stream().cuda_stream))
