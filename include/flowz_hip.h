@@ -125,7 +125,8 @@ typedef struct fz_variant {
 } fz_variant;
 
 enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores                   */
-       FZ_VF_XCD_REMAP = 2u };  /* contiguous stream range per XCD                              */
+       FZ_VF_XCD_REMAP = 2u,    /* contiguous stream range per XCD                              */
+       FZ_VF_SLP = 4u };        /* let the compiler's SLP vectoriser pair scalar ops (off by default) */
 
 int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */
 /* generated HIP source of a variant (skeleton + graph body); returns length, writes <= cap    */

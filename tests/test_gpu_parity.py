@@ -119,7 +119,7 @@ def test_graphs_vs_oracle_ragged(torch_cuda, F, name, P):
     g = GRAPHS[name]()
     prog = F.compile(F.from_sexpr(g))
     ns, T = 132, 101                      # 132 = 2 waves + 4 lanes: ragged last wave; T % unroll != 0
-    x = O.synth_input(SEED + 1, np.arange(ns), T, n_wires=max(prog.n_in, 1))
+    x = O.synth_input(SEED + 1, np.arange(ns), T, n_wires=prog.n_in)    # n_in == 0: frames of width 0
     want = O.compile(g, ns).run(x)
     got, _ = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(P, 8))
     assert ndiff(got, want) == 0

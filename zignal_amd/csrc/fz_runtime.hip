@@ -43,9 +43,16 @@ static void require_device()
 }
 
 // ---- kernel cache -----------------------------------------------------------------------------------
-static const char* const kBuildOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                                            "-fhip-fp32-correctly-rounded-divide-sqrt"};
-constexpr int kNumBuildOptions = 5;
+static std::vector<const char*> build_options(const Variant& v)
+{
+   // -ffp-contract=off: one rounding per graph node (no v_fma/v_fmac); IEEE division.
+   // The SLP vectoriser is off by default: with one stream per lane it pairs unrelated scalar
+   // mul/add into v_pk_* at the price of v_mov shuffles, a net VALU loss on gfx950.
+   std::vector<const char*> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                                 "-fhip-fp32-correctly-rounded-divide-sqrt"};
+   if (!(v.flags & FZ_VF_SLP)) o.push_back("-fno-slp-vectorize");
+   return o;
+}
 
 static uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
 {
@@ -79,7 +86,8 @@ static std::vector<char> jit_compile(const Graph& g, const Variant& v)
    hiprtcProgram prog;
    if (hiprtcCreateProgram(&prog, skeleton_source(), "fz_block_kernel.hip", 2, headers, names) != HIPRTC_SUCCESS)
       fail(FZ_E_COMPILE, "hiprtcCreateProgram failed");
-   hiprtcResult r = hiprtcCompileProgram(prog, kNumBuildOptions, const_cast<const char**>(kBuildOptions));
+   std::vector<const char*> opts = build_options(v);
+   hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
    if (r != HIPRTC_SUCCESS) {
       size_t n = 0;
       hiprtcGetProgramLogSize(prog, &n);
@@ -103,7 +111,7 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, bool need_lo
    if (!slot) {
       auto k = std::make_shared<Kernel>();
       std::string key_src = full_source(p->g, v);
-      for (int i = 0; i < kNumBuildOptions; ++i) key_src += kBuildOptions[i];
+      for (const char* o : build_options(v)) key_src += o;
       int rtc_major = 0, rtc_minor = 0;
       hiprtcVersion(&rtc_major, &rtc_minor);
       key_src += "hiprtc" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor);
@@ -147,6 +155,8 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, bool need_lo
 }
 
 // ---- variant selection ---------------------------------------------------------------------------------
+constexpr uint64_t kMaxLdsBytes = 160 * 1024;
+
 Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams)
 {
    Variant v;
@@ -165,11 +175,11 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    v.U = reqU ? reqU : 8;
    v.block = reqB ? reqB : 256;
    if (g.n_lds_slots) {
-      // LDS rings: slots * block * 4P bytes must fit the 64 KiB static limit
+      // LDS rings: slots * block * 4P bytes must fit the CU's 160 KiB of LDS (one workgroup may take it all)
       auto bytes = [&](const Variant& w) { return (uint64_t)g.n_lds_slots * w.block * 4u * w.P; };
-      while (bytes(v) > 65536 && !reqB && v.block > 64) v.block /= 2;
-      while (bytes(v) > 65536 && !reqP && v.P > 1) v.P /= 2;
-      if (bytes(v) > 65536)
+      while (bytes(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
+      while (bytes(v) > kMaxLdsBytes && !reqP && v.P > 1) v.P /= 2;
+      if (bytes(v) > kMaxLdsBytes)
          fail(FZ_E_UNSUPPORTED, "delay lines too long for the LDS ring buffers of this build (" +
                                    std::to_string(g.n_lds_slots) + " slots)");
    }
@@ -204,7 +214,8 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    const Variant v = resolve_variant(g, uv, n_streams);
    auto k = get_kernel(p, v, true);
 
-   std::vector<char> buf(sizeof(ArgsHeader) + sizeof(float) * std::max<size_t>(g.consts.size(), 1));
+   // kernarg image of `struct fz_args` (8-byte aligned: pad the coefficient tail)
+   std::vector<char> buf((sizeof(ArgsHeader) + sizeof(float) * std::max<size_t>(g.consts.size(), 1) + 7) & ~size_t(7));
    ArgsHeader h{in, out, state, params, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P)};
    std::memcpy(buf.data(), &h, sizeof h);
    {
@@ -215,6 +226,11 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
    const unsigned grid = (unsigned)((h.n_groups + v.block - 1) / v.block);
    FZ_HIP(hipModuleLaunchKernel((hipFunction_t)k->function, grid, 1, 1, v.block, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
+   if (std::getenv("FLOWZ_HIP_DEBUG")) {
+      FZ_HIP(hipStreamSynchronize((hipStream_t)stream));
+      std::fprintf(stderr, "[flowz_hip] launched grid=%u block=%u P=%u U=%u flags=%u n_streams=%llu n_samples=%u kernarg=%zu B\n",
+                   grid, v.block, v.P, v.U, v.flags, (unsigned long long)n_streams, n_samples, size);
+   }
    return FZ_OK;
 }
 
