@@ -1,0 +1,403 @@
+// flowz.hpp -- the Flowz EDSL front end for the MI355X evaluator (host side, plain C++14).
+//
+// Same surface as the reference header /root/reference/flowz/flowz.hpp, re-built without
+// Boost.Proto on top of the C ABI of libflowz_hip.so (include/flowz_hip.h):
+//
+//    using namespace flowz;
+//    _1 .. _6, make_placeholder<N>()                 flowz.hpp:1252-1257, :78-82
+//    _1[_2]            wire 1 delayed by 2           :84-85   (also _1[-2]: the spelling of
+//                                                    experimental_steps/delay_expression.cpp:99-100)
+//    a , b   a | b   a |= b   ~a                     :90-93   channel / parallel / sequence / feedback
+//    + - * / unary -   with literals                 :68-72, :769-772 (float32 terminals)
+//    std::ref(x)       external modulation           flowz/README.md:42-61 (read at every call / block)
+//    compile(expr)     -> callable closure           :1233-1249
+//    f(x1..xN) -> std::tuple<float x M>              :1225-1229, fewer args -> curried copy :1203-1212
+//
+// What differs, on purpose: the arities are still compile-time (so results are tuples), but
+// everything else happens at run time -- the expression is a tree of C-ABI handles, compile()
+// lowers it and builds ONE fused gfx950 kernel, and the closure's state lives in HBM.  The
+// per-sample call works (it launches the kernel for 1 stream x 1 sample), but the intended use
+// is the block API: f.bank(n_streams).process(in, out, n_samples) evaluates n_samples samples
+// of n_streams independent closures per launch.  There is no CPU evaluation path.
+// Malformed graphs throw flowz::error from compile() instead of failing template instantiation.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "flowz_hip.h"
+
+namespace flowz {
+
+struct error : std::runtime_error {
+   int code;
+   error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+namespace detail {
+
+inline void check(int rc)
+{
+   if (rc < 0) throw error(rc, fz_last_error());
+}
+
+// value-semantic owner of an fz_expr handle (copy = retain: trees are immutable)
+class handle {
+   fz_expr* p_ = nullptr;
+
+public:
+   handle() = default;
+   explicit handle(fz_expr* p) : p_(p)
+   {
+      if (!p_) throw error(FZ_E_INVALID, fz_last_error());
+   }
+   handle(const handle& o) : p_(o.p_) { fz_expr_retain(p_); }
+   handle(handle&& o) noexcept : p_(o.p_) { o.p_ = nullptr; }
+   handle& operator=(handle o) noexcept
+   {
+      std::swap(p_, o.p_);
+      return *this;
+   }
+   ~handle() { fz_expr_release(p_); }
+   fz_expr* get() const { return p_; }
+};
+
+// std::ref terminals: (uniform coefficient id, address of the referenced variable)
+using ref_list = std::vector<std::pair<uint32_t, const float*>>;
+
+inline uint32_t next_uniform_id()
+{
+   static uint32_t n = 0;
+   return n++;
+}
+
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+
+struct expr_tag {};
+
+}  // namespace detail
+
+// An expression with In input wires and Out output wires (input_arity / output_arity,
+// flowz.hpp:162-246, evaluated by the type system exactly like the reference does).
+template <int In, int Out>
+struct expr : detail::expr_tag {
+   static constexpr int ins = In;
+   static constexpr int outs = Out;
+   detail::handle h;
+   detail::ref_list refs;
+   expr(detail::handle hh, detail::ref_list r = {}) : h(std::move(hh)), refs(std::move(r)) {}
+};
+
+template <class T>
+using is_expr = std::is_base_of<detail::expr_tag, typename std::decay<T>::type>;
+
+namespace detail {
+
+inline ref_list merge(const ref_list& a, const ref_list& b)
+{
+   ref_list r = a;
+   r.insert(r.end(), b.begin(), b.end());
+   return r;
+}
+
+// literal terminals: arithmetic values are held by value as float32 (make_terminal, :68-72)
+template <class T, class = typename std::enable_if<std::is_arithmetic<T>::value>::type>
+expr<0, 1> as_expr(T v)
+{
+   return expr<0, 1>(handle(fz_literal(static_cast<float>(v))));
+}
+inline expr<0, 1> as_expr(std::reference_wrapper<float> r)
+{
+   const uint32_t id = next_uniform_id();
+   return expr<0, 1>(handle(fz_uniform(id, r.get())), ref_list{{id, &r.get()}});
+}
+inline expr<0, 1> as_expr(std::reference_wrapper<const float> r)
+{
+   const uint32_t id = next_uniform_id();
+   return expr<0, 1>(handle(fz_uniform(id, r.get())), ref_list{{id, &r.get()}});
+}
+template <int I, int O>
+const expr<I, O>& as_expr(const expr<I, O>& e)
+{
+   return e;
+}
+
+template <class T>
+struct is_operand : std::integral_constant<bool, std::is_arithmetic<typename std::decay<T>::type>::value ||
+                                                    std::is_same<typename std::decay<T>::type, std::reference_wrapper<float>>::value ||
+                                                    std::is_same<typename std::decay<T>::type, std::reference_wrapper<const float>>::value> {};
+
+template <class A, class B>
+using enable_binary = typename std::enable_if<(is_expr<A>::value && (is_expr<B>::value || is_operand<B>::value)) ||
+                                              (is_operand<A>::value && is_expr<B>::value)>::type;
+
+template <int Ia, int Oa, int Ib, int Ob>
+expr<imax(Ia, Ib), 1> arith(fz_op op, const expr<Ia, Oa>& a, const expr<Ib, Ob>& b)
+{
+   static_assert(Oa == 1 && Ob == 1, "flowz: an arithmetic operand must have exactly one output wire");
+   return expr<imax(Ia, Ib), 1>(handle(fz_arith(op, a.h.get(), b.h.get())), merge(a.refs, b.refs));
+}
+
+}  // namespace detail
+
+// ---- placeholders and delays -----------------------------------------------------------------------
+template <int I>
+struct placeholder : expr<I, 1> {
+   placeholder() : expr<I, 1>(detail::handle(fz_placeholder(I))) {}
+   template <int N>
+   expr<I, 1> operator[](const placeholder<N>&) const          // _i[_n]
+   {
+      return expr<I, 1>(detail::handle(fz_delayed(I, N)));
+   }
+   expr<I, 1> operator[](int n) const                            // _i[-n]
+   {
+      return expr<I, 1>(detail::handle(fz_delayed(I, static_cast<uint32_t>(n < 0 ? -n : n))));
+   }
+};
+
+template <int N>
+placeholder<N> make_placeholder()
+{
+   return placeholder<N>();
+}
+
+template <class X>
+auto make_terminal(X x) -> decltype(detail::as_expr(x))
+{
+   return detail::as_expr(x);
+}
+
+// per-stream, block-constant coefficient k: one value per stream (array given to the bank)
+inline expr<0, 1> stream_param(uint32_t k) { return expr<0, 1>(detail::handle(fz_stream_param(k))); }
+
+// ---- arithmetic (any C++ operator on evaluated children, proto::_default :769-772) --------------------------
+#define FLOWZ_BINARY_OP(SYM, OP)                                                                         \
+   template <class A, class B, class = detail::enable_binary<A, B>>                                      \
+   auto operator SYM(const A& a, const B& b)->decltype(detail::arith(OP, detail::as_expr(a), detail::as_expr(b))) \
+   {                                                                                                     \
+      return detail::arith(OP, detail::as_expr(a), detail::as_expr(b));                                  \
+   }
+FLOWZ_BINARY_OP(+, FZ_OP_ADD)
+FLOWZ_BINARY_OP(-, FZ_OP_SUB)
+FLOWZ_BINARY_OP(*, FZ_OP_MUL)
+FLOWZ_BINARY_OP(/, FZ_OP_DIV)
+#undef FLOWZ_BINARY_OP
+
+template <int I, int O>
+expr<I, 1> operator-(const expr<I, O>& a)
+{
+   static_assert(O == 1, "flowz: an arithmetic operand must have exactly one output wire");
+   return expr<I, 1>(detail::handle(fz_arith(FZ_OP_NEG, a.h.get(), nullptr)), a.refs);
+}
+
+// ---- block composition operators (flowz.hpp:90-93) --------------------------------------------------------------
+template <int Ia, int Oa, int Ib, int Ob>
+expr<detail::imax(Ia, Ib), Oa + Ob> operator,(const expr<Ia, Oa>& a, const expr<Ib, Ob>& b)        // channel
+{
+   return {detail::handle(fz_channel(a.h.get(), b.h.get())), detail::merge(a.refs, b.refs)};
+}
+
+template <int Ia, int Oa, int Ib, int Ob>
+expr<Ia + Ib, Oa + Ob> operator|(const expr<Ia, Oa>& a, const expr<Ib, Ob>& b)                      // parallel
+{
+   return {detail::handle(fz_parallel(a.h.get(), b.h.get())), detail::merge(a.refs, b.refs)};
+}
+
+template <int Ia, int Oa, int Ib, int Ob>
+expr<Ia + detail::imax(0, Ib - Oa), Ob + detail::imax(0, Oa - Ib)> operator|=(const expr<Ia, Oa>& a, const expr<Ib, Ob>& b)   // sequence
+{
+   return {detail::handle(fz_sequence(a.h.get(), b.h.get())), detail::merge(a.refs, b.refs)};
+}
+
+template <int I, int O>
+expr<detail::imax(0, I - O), O> operator~(const expr<I, O>& a)                                       // feedback
+{
+   return {detail::handle(fz_feedback(a.h.get())), a.refs};
+}
+
+// static analysis (flowz.hpp:162-246, :443-506)
+template <int I, int O>
+constexpr int input_arity(const expr<I, O>&) { return I; }
+template <int I, int O>
+constexpr int output_arity(const expr<I, O>&) { return O; }
+template <int I, int O>
+std::vector<uint32_t> max_input_delays(const expr<I, O>& e)
+{
+   std::vector<uint32_t> v(static_cast<size_t>(fz_max_input_delays(e.h.get(), nullptr, 0)));
+   if (!v.empty()) fz_max_input_delays(e.h.get(), v.data(), static_cast<uint32_t>(v.size()));
+   return v;
+}
+
+// ---- compiled graphs --------------------------------------------------------------------------------------------
+namespace detail {
+
+struct program_deleter {
+   void operator()(fz_program* p) const { fz_program_destroy(p); }
+};
+using program_ptr = std::shared_ptr<fz_program>;
+
+template <class Tuple, size_t... K>
+Tuple to_tuple(const float* v, std::index_sequence<K...>)
+{
+   return Tuple(v[K]...);
+}
+
+template <int N, class = std::make_index_sequence<N>>
+struct float_tuple;
+template <int N, size_t... K>
+struct float_tuple<N, std::index_sequence<K...>> {
+   template <size_t>
+   using f = float;
+   using type = std::tuple<f<K>...>;
+};
+
+}  // namespace detail
+
+// Device-resident state of n_streams independent closures of one compiled graph
+// (the `state_` of stateful_lambda, flowz.hpp:1190-1191, times n_streams, in HBM).
+class stream_bank {
+   detail::program_ptr prog_;
+   detail::ref_list refs_;
+   fz_bank* bank_ = nullptr;
+   uint64_t n_streams_ = 0;
+
+   void refresh_refs() const
+   {
+      for (const auto& r : refs_) detail::check(fz_program_set_uniform(prog_.get(), r.first, *r.second));
+   }
+
+public:
+   stream_bank(detail::program_ptr p, detail::ref_list refs, uint64_t n_streams)
+       : prog_(std::move(p)), refs_(std::move(refs)), n_streams_(n_streams)
+   {
+      detail::check(fz_bank_create(prog_.get(), n_streams, &bank_));
+   }
+   stream_bank(const stream_bank& o) : prog_(o.prog_), refs_(o.refs_), n_streams_(o.n_streams_)   // copy = snapshot (:1206)
+   {
+      detail::check(fz_bank_clone(o.bank_, &bank_));
+   }
+   stream_bank(stream_bank&& o) noexcept : prog_(std::move(o.prog_)), refs_(std::move(o.refs_)), bank_(o.bank_), n_streams_(o.n_streams_)
+   {
+      o.bank_ = nullptr;
+   }
+   stream_bank& operator=(stream_bank o) noexcept
+   {
+      std::swap(prog_, o.prog_);
+      std::swap(refs_, o.refs_);
+      std::swap(bank_, o.bank_);
+      std::swap(n_streams_, o.n_streams_);
+      return *this;
+   }
+   ~stream_bank() { fz_bank_destroy(bank_); }
+
+   uint64_t n_streams() const { return n_streams_; }
+   void reset() { detail::check(fz_bank_reset(bank_)); }
+   void set_stream_params(const float* host /* [n_param][n_streams] */) { detail::check(fz_bank_set_params_host(bank_, host)); }
+   float* state_device() { return fz_bank_state_device(bank_); }
+
+   // frames are time-major: in [n_samples][n_streams][n_in], out [n_samples][n_streams][n_out]
+   void process(const float* in_dev, float* out_dev, uint32_t n_samples, void* hip_stream = nullptr, const fz_variant* v = nullptr)
+   {
+      refresh_refs();
+      detail::check(fz_bank_process(bank_, in_dev, out_dev, n_samples, v, hip_stream));
+   }
+   void process_host(const float* in_host, float* out_host, uint32_t n_samples)
+   {
+      refresh_refs();
+      detail::check(fz_bank_process_host(bank_, in_host, out_host, n_samples));
+   }
+};
+
+// compile() result: the reference's stateful_lambda (flowz.hpp:1181-1230).
+template <int In, int Out>
+class stateful_lambda {
+   detail::program_ptr prog_;
+   detail::ref_list refs_;
+   std::unique_ptr<stream_bank> own_;     // lazily created 1-stream bank behind operator()
+
+   stream_bank& own()
+   {
+      if (!own_) own_.reset(new stream_bank(prog_, refs_, 1));
+      return *own_;
+   }
+
+   using result_t = typename detail::float_tuple<Out>::type;
+
+   template <class... Args>
+   result_t call(std::integral_constant<int, 0>, const Args&... args)
+   {
+      const float in[In > 0 ? In : 1] = {static_cast<float>(args)...};
+      float out[Out];
+      own().process_host(In > 0 ? in : nullptr, out, 1);
+      return detail::to_tuple<result_t>(out, std::make_index_sequence<Out>{});
+   }
+
+   template <int Missing, class... Args>
+   auto call(std::integral_constant<int, Missing>, const Args&... args)      // currying, flowz.hpp:1203-1212
+   {
+      return [args..., self = *this](const auto&... rest) mutable { return self(args..., rest...); };
+   }
+
+public:
+   static constexpr int ins = In;
+   static constexpr int outs = Out;
+
+   explicit stateful_lambda(const expr<In, Out>& e) : refs_(e.refs)
+   {
+      fz_program* p = nullptr;
+      detail::check(fz_compile(e.h.get(), &p));
+      prog_ = detail::program_ptr(p, detail::program_deleter());
+   }
+   stateful_lambda(const stateful_lambda& o) : prog_(o.prog_), refs_(o.refs_), own_(o.own_ ? new stream_bank(*o.own_) : nullptr) {}
+   stateful_lambda(stateful_lambda&&) = default;
+   stateful_lambda& operator=(stateful_lambda o)
+   {
+      std::swap(prog_, o.prog_);
+      std::swap(refs_, o.refs_);
+      std::swap(own_, o.own_);
+      return *this;
+   }
+
+   // one sample of one stream; fewer arguments return a curried copy of the closure
+   template <class... Args, class = typename std::enable_if<(sizeof...(Args) <= In)>::type>
+   auto operator()(const Args&... args)
+   {
+      return call(std::integral_constant<int, In - static_cast<int>(sizeof...(Args))>{}, args...);
+   }
+
+   // the block API: n_streams independent closures with zeroed state in HBM
+   stream_bank bank(uint64_t n_streams) const { return stream_bank(prog_, refs_, n_streams); }
+
+   fz_program* program() const { return prog_.get(); }
+   fz_info info() const
+   {
+      fz_info i;
+      detail::check(fz_program_info(prog_.get(), &i));
+      return i;
+   }
+};
+
+struct compile_fn {
+   template <int I, int O>
+   stateful_lambda<I, O> operator()(const expr<I, O>& e) const
+   {
+      return stateful_lambda<I, O>(e);
+   }
+};
+static const compile_fn compile{};
+
+static const placeholder<1> _1{};
+static const placeholder<2> _2{};
+static const placeholder<3> _3{};
+static const placeholder<4> _4{};
+static const placeholder<5> _5{};
+static const placeholder<6> _6{};
+
+}  // namespace flowz

@@ -51,6 +51,11 @@ fz_expr* fz_literal(float value);                    /* terminal held by value  
 fz_expr* fz_stream_param(uint32_t k);                /* per-stream, block-constant coefficient k:
                                                         the std::ref terminal of flowz/README.md:42-61,
                                                         one value per stream                          */
+fz_expr* fz_uniform(uint32_t k, float initial);      /* uniform run-time coefficient k (same value for
+                                                        all streams, constant during a block): what a
+                                                        std::ref(x) terminal is when the closure is called
+                                                        (flowz/README.md:42-61); set with
+                                                        fz_program_set_uniform between blocks             */
 fz_expr* fz_arith(fz_op op, fz_expr* a, fz_expr* b); /* any C++ arithmetic operator, _default :769-772;
                                                         b is ignored (may be NULL) for FZ_OP_NEG      */
 fz_expr* fz_channel (fz_expr* a, fz_expr* b);        /* a , b       channel_operator   :90           */
@@ -112,6 +117,8 @@ int fz_program_lines(const fz_program* p, uint32_t* src_nodes, uint32_t* depths,
 /* read / overwrite a uniform coefficient (literal terminal) between blocks */
 int fz_program_get_const(const fz_program* p, uint32_t slot, float* value);
 int fz_program_set_const(fz_program* p, uint32_t slot, float value);
+/* overwrite uniform run-time coefficient k (fz_uniform) between blocks */
+int fz_program_set_uniform(fz_program* p, uint32_t k, float value);
 
 /* ------------------------------------------------------------------------------------------
  * Kernel variants.  One fused HIP kernel per (graph, variant) is generated and built with
@@ -125,7 +132,7 @@ typedef struct fz_variant {
 } fz_variant;
 
 enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores                   */
-       FZ_VF_XCD_REMAP = 2u,    /* contiguous stream range per XCD                              */
+       FZ_VF_NO_XCD_REMAP = 2u, /* plain blockIdx order instead of one contiguous stream range per XCD */
        FZ_VF_SLP = 4u };        /* let the compiler's SLP vectoriser pair scalar ops (off by default) */
 
 int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */

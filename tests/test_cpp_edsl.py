@@ -1,0 +1,33 @@
+"""Build and run the C++ front-end tests (g++ -std=c++14, links libflowz_hip.so)."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+BUILD = os.path.join(HERE, "cpp", "_build")
+
+
+def build(name):
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, name)
+    libdir = os.path.join(ROOT, "zignal_amd", "lib")
+    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+           os.path.join(HERE, "cpp", name + ".cpp"), "-o", exe, "-L", libdir, "-lflowz_hip",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_cpp_edsl_host_checks():
+    out = subprocess.run([build("test_edsl_host")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all host EDSL checks passed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_edsl_reference_tests_on_gpu():
+    out = subprocess.run([build("test_edsl_gpu")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all GPU EDSL checks passed" in out.stdout

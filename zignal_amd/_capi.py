@@ -24,7 +24,7 @@ class NoDeviceError(FlowzError):
 
 FZ_OK, FZ_E_INVALID, FZ_E_GRAPH, FZ_E_NO_DEVICE, FZ_E_HIP, FZ_E_COMPILE, FZ_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 FZ_OP_ADD, FZ_OP_SUB, FZ_OP_MUL, FZ_OP_DIV, FZ_OP_NEG = 1, 2, 3, 4, 5
-FZ_VF_NO_NT, FZ_VF_XCD_REMAP, FZ_VF_SLP = 1, 2, 4
+FZ_VF_NO_NT, FZ_VF_NO_XCD_REMAP, FZ_VF_SLP = 1, 2, 4
 IR_KINDS = {1: "input", 2: "const", 3: "param", 4: "delay", 5: "add", 6: "sub", 7: "mul", 8: "div", 9: "neg"}
 
 
@@ -56,6 +56,8 @@ def _load():
         "fz_delayed": (P, [u32, u32]),
         "fz_literal": (P, [f32]),
         "fz_stream_param": (P, [u32]),
+        "fz_uniform": (P, [u32, f32]),
+        "fz_program_set_uniform": (ctypes.c_int, [P, u32, f32]),
         "fz_arith": (P, [ctypes.c_int, P, P]),
         "fz_channel": (P, [P, P]),
         "fz_parallel": (P, [P, P]),

@@ -97,6 +97,17 @@ int fz_program_set_const(fz_program* p, uint32_t slot, float value)
       return FZ_OK;)
 }
 
+int fz_program_set_uniform(fz_program* p, uint32_t k, float value)
+{
+   FZ_GUARD(
+      if (!p) fail(FZ_E_INVALID, "null argument");
+      auto it = p->g.uniform_slot.find(k);
+      if (it == p->g.uniform_slot.end()) fail(FZ_E_INVALID, "graph has no uniform coefficient with this index");
+      std::lock_guard<std::mutex> lock(p->mu);
+      p->g.consts[it->second] = value;
+      return FZ_OK;)
+}
+
 int fz_program_build(fz_program* p, const fz_variant* v)
 {
    FZ_GUARD(

@@ -22,7 +22,7 @@ struct Error {
 [[noreturn]] void fail(int code, const std::string& msg);
 
 // ---- expression tree (the EDSL surface, flowz.hpp:68-93) ---------------------------------------
-enum class EK : uint8_t { Placeholder, Delayed, Literal, Param, Arith, Neg, Channel, Parallel, Sequence, Feedback };
+enum class EK : uint8_t { Placeholder, Delayed, Literal, Uniform, Param, Arith, Neg, Channel, Parallel, Sequence, Feedback };
 
 }  // namespace fz
 
@@ -62,6 +62,7 @@ struct Graph {
    std::vector<uint32_t> outputs;    // node ids
    std::vector<Line> lines;          // ordered by src
    std::vector<float> consts;        // uniform coefficient slots
+   std::map<uint32_t, uint32_t> uniform_slot;   // fz_uniform id -> coefficient slot (never shared)
    uint32_t n_state = 0, max_delay = 0, n_ops = 0, n_lds_slots = 0;
    std::vector<int> line_of_node;    // node -> line index or -1
 };

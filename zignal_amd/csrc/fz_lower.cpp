@@ -69,6 +69,7 @@ struct Elab {
             if (e->i > ins.size()) fail(FZ_E_GRAPH, "placeholder _" + std::to_string(e->i) + " has no wire to bind to");
             return {add(FZ_IR_DELAY, ins[e->i - 1], -1, 0.f, e->n)};
          case EK::Literal: return {add(FZ_IR_CONST, -1, -1, e->value)};
+         case EK::Uniform: return {add(FZ_IR_CONST, -1, -1, e->value, e->i + 1)};   // n = id + 1: own slot
          case EK::Param: return {add(FZ_IR_PARAM, -1, -1, 0.f, e->i)};
          case EK::Arith: {                                              // _default<eval_it> :769-772
             int a = one(e->a, ins), b = one(e->b, ins);
@@ -217,7 +218,15 @@ Graph lower(const fz_expr* e)
    // uniform coefficient slots: one per distinct bit pattern
    Graph g;
    std::map<uint32_t, uint32_t> const_slot;
-   auto slot_of = [&](float v) {
+   auto slot_of = [&](float v, uint32_t uid1) {
+      if (uid1) {                                   // run-time uniform: one private slot per id
+         auto it = g.uniform_slot.find(uid1 - 1);
+         if (it != g.uniform_slot.end()) return it->second;
+         uint32_t s = (uint32_t)g.consts.size();
+         g.consts.push_back(v);
+         g.uniform_slot[uid1 - 1] = s;
+         return s;
+      }
       auto it = const_slot.find(bits_of(v));
       if (it != const_slot.end()) return it->second;
       uint32_t s = (uint32_t)g.consts.size();
@@ -237,7 +246,7 @@ Graph lower(const fz_expr* e)
          std::tuple<uint32_t, int, int, uint32_t> key;
          switch (r.kind) {
             case FZ_IR_INPUT: key = {r.kind, -1, -1, r.n}; break;
-            case FZ_IR_CONST: key = {r.kind, -1, -1, bits_of(r.value)}; break;
+            case FZ_IR_CONST: key = {r.kind, r.n ? (int)r.n : -1, -1, r.n ? 0u : bits_of(r.value)}; break;
             case FZ_IR_PARAM: key = {r.kind, -1, -1, r.n}; break;
             case FZ_IR_DELAY: key = {r.kind, rep[(size_t)r.a], -1, r.n}; break;
             case FZ_IR_NEG: key = {r.kind, rep[(size_t)r.a], -1, 0}; break;
@@ -265,7 +274,7 @@ Graph lower(const fz_expr* e)
       n.kind = r.kind;
       switch (r.kind) {
          case FZ_IR_INPUT: n.a = r.n; break;
-         case FZ_IR_CONST: n.a = slot_of(r.value); n.value = r.value; break;
+         case FZ_IR_CONST: n.a = slot_of(r.value, r.n); n.value = r.value; break;
          case FZ_IR_PARAM: n.a = r.n; g.n_param = std::max(g.n_param, r.n + 1); break;
          case FZ_IR_DELAY: n.a = nid(r.a); n.b = r.n; break;
          case FZ_IR_NEG: n.a = nid(r.a); ++g.n_ops; break;

@@ -170,9 +170,11 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       v.P = reqP;
    } else {
       // fill the chip first (256 CUs x 4 SIMDs, several waves each), then pack two streams per lane
+      // (v_pk_* issue at the scalar rate on gfx950: twice the lane-ops per cycle)
       v.P = (n_streams >= (1u << 19) && n_streams % 2 == 0) ? 2 : 1;
    }
-   v.U = reqU ? reqU : 8;
+   // prefetch depth: few waves -> deeper chunks to keep enough bytes in flight per CU
+   v.U = reqU ? reqU : (v.P == 1 ? 16 : 8);
    v.block = reqB ? reqB : 256;
    if (g.n_lds_slots) {
       // LDS rings: slots * block * 4P bytes must fit the CU's 160 KiB of LDS (one workgroup may take it all)

@@ -107,6 +107,11 @@ def lit(v: float) -> Expr:
     return Expr(C.lib.fz_literal(float(v)))
 
 
+def uniform(k: int, initial: float = 0.0) -> Expr:
+    """Uniform run-time coefficient k (the std::ref(x) terminal): Program.set_uniform(k, v)."""
+    return Expr(C.lib.fz_uniform(int(k), float(initial)))
+
+
 def param(k: int) -> Expr:
     return Expr(C.lib.fz_stream_param(int(k)))
 
@@ -151,6 +156,7 @@ def from_sexpr(e) -> Expr:
     if k == "del": return Placeholder(e[1])[int(e[2])]
     if k == "lit": return lit(e[1])
     if k == "param": return param(e[1])
+    if k == "uniform": return uniform(e[1], e[2])
     if k == "neg": return -from_sexpr(e[1])
     if k == "fb": return ~from_sexpr(e[1])
     a, b = from_sexpr(e[1]), from_sexpr(e[2])
@@ -218,6 +224,9 @@ class Program:
 
     def set_const(self, slot: int, value: float):
         C.check(C.lib.fz_program_set_const(self._h, int(slot), float(value)))
+
+    def set_uniform(self, k: int, value: float):
+        C.check(C.lib.fz_program_set_uniform(self._h, int(k), float(value)))
 
     def source(self, variant: Optional[Variant] = None) -> str:
         vp = ctypes.byref(variant) if variant is not None else None
