@@ -1,4 +1,4 @@
-"""Build and run the C++ front-end tests (g++ -std=c++14, links libflowz_hip.so)."""
+"""Build and run the C++ front-end tests (g++ -std=gnu++14 for hex-float literals; the header itself is plain C++14; links libflowz_hip.so)."""
 import os
 import subprocess
 
@@ -13,7 +13,7 @@ def build(name):
     os.makedirs(BUILD, exist_ok=True)
     exe = os.path.join(BUILD, name)
     libdir = os.path.join(ROOT, "zignal_amd", "lib")
-    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+    cmd = ["g++", "-std=gnu++14", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
            os.path.join(HERE, "cpp", name + ".cpp"), "-o", exe, "-L", libdir, "-lflowz_hip",
            f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
