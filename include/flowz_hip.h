@@ -156,6 +156,18 @@ long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap
 int fz_run_block(fz_program* p, const float* in, float* out, float* state, const float* params,
                  uint64_t n_streams, uint32_t n_samples, const fz_variant* v, void* hip_stream);
 
+/* Same hot path with STREAM-TILED frames, the layout recommended for HBM3E on MI355X:
+ *   in   [n_streams / tile_streams][n_samples][tile_streams][n_in]
+ *   out  [n_streams / tile_streams][n_samples][tile_streams][n_out]
+ * i.e. every tile of tile_streams adjacent streams is its own time-major block.  32 KiB row
+ * segments (tile_streams * n_in * 4 bytes; 8192 streams for one wire) measured +15...20 % over
+ * 4 MiB rows (profiles/r01/hbm_copy_patterns_microbench.txt).  n_streams must be a multiple of
+ * tile_streams and tile_streams a multiple of streams_per_lane * block_threads;
+ * tile_streams == 0 or == n_streams is fz_run_block.  state / params stay [rows][n_streams]. */
+int fz_run_block_tiled(fz_program* p, const float* in, float* out, float* state, const float* params,
+                       uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
+                       const fz_variant* v, void* hip_stream);
+
 /* ------------------------------------------------------------------------------------------
  * fz_bank -- device-resident closure state for n_streams streams: the `state_` member of
  * stateful_lambda (flowz.hpp:1190-1191).  clone == copying the closure (snapshot, :1206).
@@ -178,9 +190,10 @@ int  fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uin
  * Device utilities used by the measurement harness (bench.py) and tests.
  * ---------------------------------------------------------------------------------------- */
 int fz_device_count(void);                /* 0 when no GPU is visible                          */
-/* synthetic frames dst[t][s][w] = unit(hash32(seed, (stream0+s)*n_wires + w, t0+t)) in [-1,1) */
+/* synthetic frames (t, s, w) = unit(hash32(seed, (stream0+s)*n_wires + w, t0+t)) in [-1,1), stored
+ * time-major (tile_streams == 0) or stream-tiled as fz_run_block_tiled expects                */
 int fz_synth_fill(float* dst_dev, uint64_t n_streams, uint32_t n_samples, uint32_t n_wires,
-                  uint32_t seed, uint64_t stream0, uint64_t t0, void* hip_stream);
+                  uint32_t seed, uint64_t stream0, uint64_t t0, uint32_t tile_streams, void* hip_stream);
 /* plain float4 copy kernel: the measured-copy-bandwidth yardstick of the roofline report      */
 int fz_copy_probe(const float* src_dev, float* dst_dev, uint64_t n_floats, void* hip_stream);
 

@@ -312,3 +312,31 @@ def test_config5_shard_equals_global_stream_ids(torch_cuda, F):
         F.synth_fill(xs, SEED, stream0=r * shard)
         ys, _ = prog.run_block(xs)
         assert torch.equal(ys.view(torch.int32), y[:, r * shard:(r + 1) * shard].contiguous().view(torch.int32))
+
+
+# ---- stream-tiled frames (fz_run_block_tiled) ---------------------------------------------------------
+@pytest.mark.parametrize("P,tile", [(1, 256), (2, 512), (4, 1024), (0, 2048), (2, 1024)])
+def test_tiled_layout_equals_time_major(torch_cuda, F, P, tile):
+    torch = torch_cuda
+    ns, T = 4096, 77
+    for g in (G.df1_cascade(6), G.par4_sum(), G.cross_wire()):
+        prog = F.compile(F.from_sexpr(g))
+        x = torch.empty((T, ns, prog.n_in), dtype=torch.float32, device="cuda")
+        F.synth_fill(x, SEED)
+        y, st = prog.run_block(x, variant=F.make_variant(P, 8))
+        xt = torch.empty((ns // tile, T, tile, prog.n_in), dtype=torch.float32, device="cuda")
+        F.synth_fill(xt, SEED)                                         # tiled placement of the same values
+        assert torch.equal(xt, F.to_tiled(x, tile))
+        yt, stt = prog.run_block(xt, variant=F.make_variant(P, 8))
+        assert torch.equal(F.from_tiled(yt).contiguous().view(torch.int32), y.view(torch.int32))
+        assert torch.equal(stt.view(torch.int32), st.view(torch.int32))
+    want = O.compile(G.cross_wire(), 8).run(O.synth_input(SEED, np.arange(8), T))
+    assert ndiff(F.from_tiled(yt)[:, :8].cpu().numpy(), want) == 0
+
+
+def test_tiled_layout_rejects_bad_tiles(torch_cuda, F):
+    torch = torch_cuda
+    prog = F.compile(F.from_sexpr(G.df1()))
+    x = torch.zeros((4, 8, 96, 1), device="cuda")                       # tile of 96 streams: not a multiple of 64
+    with pytest.raises(F.FlowzError):
+        prog.run_block(x)

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1 << 20)
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--tile", type=int, default=0, help="streams per frame tile (0 = time-major)")
     ap.add_argument("variants", nargs="*", default=["1,8", "2,8", "4,4"])
     a = ap.parse_args()
     import numpy as np
@@ -33,8 +34,12 @@ def main():
               "osc": lambda: G.osc_chain(6), "df1": G.df1}
     prog = F.compile(F.from_sexpr(graphs[a.graph]()))
     ns, T = a.streams, a.samples
-    x = torch.empty((T, ns, max(prog.n_in, 1)), dtype=torch.float32, device="cuda")
-    y = torch.empty((T, ns, prog.n_out), dtype=torch.float32, device="cuda")
+    if a.tile:
+        x = torch.empty((ns // a.tile, T, a.tile, max(prog.n_in, 1)), dtype=torch.float32, device="cuda")
+        y = torch.empty((ns // a.tile, T, a.tile, prog.n_out), dtype=torch.float32, device="cuda")
+    else:
+        x = torch.empty((T, ns, max(prog.n_in, 1)), dtype=torch.float32, device="cuda")
+        y = torch.empty((T, ns, prog.n_out), dtype=torch.float32, device="cuda")
     F.synth_fill(x, 20160512)
     params = None
     if prog.n_param:
@@ -67,7 +72,7 @@ def main():
     F.copy_probe(xs, ys)
     e1.record()
     torch.cuda.synchronize()
-    print(f"# {a.graph} {ns} streams x {T} samples; B_alg = {b_alg / 1e9:.3f} GB; copy probe "
+    print(f"# {a.graph} {ns} streams x {T} samples, tile {a.tile}; B_alg = {b_alg / 1e9:.3f} GB; copy probe "
           f"{2 * n * 4 / (e0.elapsed_time(e1) / 1e3) / 1e9:.0f} GB/s")
     for s, _ in vs:
         ts = sorted(times[s])

@@ -79,6 +79,7 @@ def _load():
         "fz_program_build": (ctypes.c_int, [P, ctypes.POINTER(Variant)]),
         "fz_program_source": (ctypes.c_long, [P, ctypes.POINTER(Variant), ctypes.c_char_p, ctypes.c_size_t]),
         "fz_run_block": (ctypes.c_int, [P, P, P, P, P, u64, u32, ctypes.POINTER(Variant), P]),
+        "fz_run_block_tiled": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, ctypes.POINTER(Variant), P]),
         "fz_bank_create": (ctypes.c_int, [P, u64, ctypes.POINTER(P)]),
         "fz_bank_clone": (ctypes.c_int, [P, ctypes.POINTER(P)]),
         "fz_bank_destroy": (None, [P]),
@@ -88,7 +89,7 @@ def _load():
         "fz_bank_process": (ctypes.c_int, [P, P, P, u32, ctypes.POINTER(Variant), P]),
         "fz_bank_process_host": (ctypes.c_int, [P, P, P, u32]),
         "fz_device_count": (ctypes.c_int, []),
-        "fz_synth_fill": (ctypes.c_int, [P, u64, u32, u32, u32, u64, u64, P]),
+        "fz_synth_fill": (ctypes.c_int, [P, u64, u32, u32, u32, u64, u64, u32, P]),
         "fz_copy_probe": (ctypes.c_int, [P, P, u64, P]),
     }
     for name, (res, args) in sig.items():

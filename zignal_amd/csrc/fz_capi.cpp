@@ -139,7 +139,15 @@ int fz_run_block(fz_program* p, const float* in, float* out, float* state, const
 {
    FZ_GUARD(
       if (!p) fail(FZ_E_INVALID, "null program");
-      return launch(p, in, out, state, params, n_streams, n_samples, v, hip_stream);)
+      return launch(p, in, out, state, params, n_streams, n_samples, v, hip_stream, 0);)
+}
+
+int fz_run_block_tiled(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+                       uint32_t n_samples, uint32_t tile_streams, const fz_variant* v, void* hip_stream)
+{
+   FZ_GUARD(
+      if (!p) fail(FZ_E_INVALID, "null program");
+      return launch(p, in, out, state, params, n_streams, n_samples, v, hip_stream, tile_streams);)
 }
 
 }  // extern "C"

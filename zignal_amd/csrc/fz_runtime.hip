@@ -174,7 +174,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       v.P = (n_streams >= (1u << 19) && n_streams % 2 == 0) ? 2 : 1;
    }
    // prefetch depth: few waves -> deeper chunks to keep enough bytes in flight per CU
-   v.U = reqU ? reqU : (v.P == 1 ? 16 : 8);
+   v.U = reqU ? reqU : 16;
    v.block = reqB ? reqB : 256;
    if (g.n_lds_slots) {
       // LDS rings: slots * block * 4P bytes must fit the CU's 160 KiB of LDS (one workgroup may take it all)
@@ -197,10 +197,12 @@ struct ArgsHeader {
    unsigned long long n_streams;
    unsigned int n_samples;
    unsigned int n_groups;
+   unsigned int tile_streams;
+   unsigned int tile_blocks;
 };
 
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
-           uint32_t n_samples, const fz_variant* uv, void* stream)
+           uint32_t n_samples, const fz_variant* uv, void* stream, uint32_t tile_streams)
 {
    const Graph& g = p->g;
    if (n_streams == 0 || n_samples == 0) fail(FZ_E_INVALID, "n_streams and n_samples must be > 0");
@@ -211,14 +213,27 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    auto mis = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
    if (mis(in) || mis(out) || mis(state) || mis(params)) fail(FZ_E_INVALID, "device pointers must be 16-byte aligned");
    const uint64_t wmax = std::max<uint64_t>(std::max(g.n_in, g.n_out), 1);
-   if (n_streams * wmax >= (1ull << 30)) fail(FZ_E_UNSUPPORTED, "row longer than 4 GiB: shard the streams");
+   if (tile_streams == 0 || tile_streams >= n_streams) tile_streams = 0;    // one tile == plain time-major
+   const uint64_t row_streams = tile_streams ? tile_streams : n_streams;
+   if (row_streams * wmax >= (1ull << 30)) fail(FZ_E_UNSUPPORTED, "row longer than 4 GiB: shard or tile the streams");
+   if (n_streams >= (1ull << 32)) fail(FZ_E_UNSUPPORTED, "more than 2^32 streams per launch: shard the streams");
+   if (tile_streams && n_streams % tile_streams) fail(FZ_E_INVALID, "n_streams must be a multiple of tile_streams");
    require_device();
-   const Variant v = resolve_variant(g, uv, n_streams);
+   Variant v = resolve_variant(g, uv, n_streams);
+   if (tile_streams) {
+      // a workgroup must not straddle tiles: shrink the lane packing / block until it divides
+      const bool fixedP = uv && uv->streams_per_lane, fixedB = uv && uv->block_threads;
+      while (tile_streams % (v.P * v.block) && !fixedP && v.P > 1) v.P /= 2;
+      while (tile_streams % (v.P * v.block) && !fixedB && v.block > 64) v.block /= 2;
+      if (tile_streams % (v.P * v.block))
+         fail(FZ_E_INVALID, "tile_streams must be a multiple of streams_per_lane * block_threads");
+   }
    auto k = get_kernel(p, v, true);
 
    // kernarg image of `struct fz_args` (8-byte aligned: pad the coefficient tail)
    std::vector<char> buf((sizeof(ArgsHeader) + sizeof(float) * std::max<size_t>(g.consts.size(), 1) + 7) & ~size_t(7));
-   ArgsHeader h{in, out, state, params, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P)};
+   ArgsHeader h{in, out, state, params, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
+                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u};
    std::memcpy(buf.data(), &h, sizeof h);
    {
       std::lock_guard<std::mutex> lock(p->mu);
@@ -248,10 +263,15 @@ __device__ __forceinline__ unsigned fmix32(unsigned h)
 // dst[t][s][w] for one row t per blockIdx.y; a thread produces 4 consecutive floats of the row
 __global__ void __launch_bounds__(256) fz_synth_fill_kernel(float* dst, unsigned long long row_floats, unsigned n_wires,
                                                             unsigned seed, unsigned long long stream0,
-                                                            unsigned long long t0, unsigned n_rows)
+                                                            unsigned long long t0, unsigned n_rows,
+                                                            unsigned long long tile_floats)
 {
+   // row_floats = n_streams * n_wires of the logical time-major row; tile_floats = floats of one
+   // tile's row segment (== row_floats when untiled).  Logical element i of row t is stored at
+   // (i / tile_floats) * n_rows * tile_floats + t * tile_floats + i % tile_floats.
    const unsigned long long i0 = ((unsigned long long)blockIdx.x * 256u + threadIdx.x) * 4ull;
    if (i0 >= row_floats) return;
+   const unsigned long long tl = i0 / tile_floats, within = i0 - tl * tile_floats;
    for (unsigned t = blockIdx.y; t < n_rows; t += gridDim.y) {
       const unsigned tt = (unsigned)((t0 + t) * 0x85EBCA6Bull);
       float v[4];
@@ -261,12 +281,15 @@ __global__ void __launch_bounds__(256) fz_synth_fill_kernel(float* dst, unsigned
          const unsigned h = fmix32(fmix32(seed ^ (unsigned)(sid * 0x9E3779B9ull) ^ tt));
          v[j] = (float)(int)(h >> 8) * 0x1p-23f - 1.0f;
       }
-      float* row = dst + (size_t)t * row_floats;
-      if (i0 + 4 <= row_floats && (row_floats & 3ull) == 0) {   // rows stay 16-byte aligned
+      float* row = dst + (size_t)tl * n_rows * tile_floats + (size_t)t * tile_floats;
+      if (i0 + 4 <= row_floats && (tile_floats & 3ull) == 0) {   // segments stay 16-byte aligned
          fzr_f4 q = {v[0], v[1], v[2], v[3]};
-         __builtin_nontemporal_store(q, reinterpret_cast<fzr_f4*>(row + i0));
+         __builtin_nontemporal_store(q, reinterpret_cast<fzr_f4*>(row + within));
       } else {
-         for (int j = 0; j < 4 && i0 + j < row_floats; ++j) row[i0 + j] = v[j];
+         for (int j = 0; j < 4 && i0 + j < row_floats; ++j) {
+            const unsigned long long i = i0 + j, tj = i / tile_floats;
+            dst[(size_t)tj * n_rows * tile_floats + (size_t)t * tile_floats + (i - tj * tile_floats)] = v[j];
+         }
       }
    }
 }
@@ -303,15 +326,17 @@ extern "C" {
 int fz_device_count(void) { return fz::device_count(); }
 
 int fz_synth_fill(float* dst, uint64_t n_streams, uint32_t n_samples, uint32_t n_wires, uint32_t seed,
-                  uint64_t stream0, uint64_t t0, void* hip_stream)
+                  uint64_t stream0, uint64_t t0, uint32_t tile_streams, void* hip_stream)
 {
    FZ_GUARD(
       if (!dst || !n_streams || !n_samples || !n_wires) fail(FZ_E_INVALID, "fz_synth_fill: bad arguments");
       require_device();
       const unsigned long long row = n_streams * n_wires;
+      if (tile_streams && n_streams % tile_streams) fail(FZ_E_INVALID, "n_streams must be a multiple of tile_streams");
+      const unsigned long long tile_floats = (tile_streams && tile_streams < n_streams) ? (unsigned long long)tile_streams * n_wires : row;
       dim3 grid((unsigned)((row + 1023) / 1024), std::min<uint32_t>(n_samples, 64u));
       hipLaunchKernelGGL(fz_synth_fill_kernel, grid, dim3(256), 0, (hipStream_t)hip_stream, dst, row, n_wires, seed,
-                         (unsigned long long)stream0, (unsigned long long)t0, n_samples);
+                         (unsigned long long)stream0, (unsigned long long)t0, n_samples, tile_floats);
       FZ_HIP(hipGetLastError());
       return FZ_OK;)
 }
@@ -398,7 +423,7 @@ int fz_bank_process(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_
    FZ_GUARD(
       if (!b) fail(FZ_E_INVALID, "null bank");
       const Graph& g = b->prog->g;
-      return fz::launch(b->prog, in_dev, out_dev, g.n_state ? b->state : nullptr, b->params, b->n_streams, n_samples, v, hip_stream);)
+      return fz::launch(b->prog, in_dev, out_dev, g.n_state ? b->state : nullptr, b->params, b->n_streams, n_samples, v, hip_stream, 0);)
 }
 
 int fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint32_t n_samples)
@@ -424,7 +449,7 @@ int fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint
          FZ_HIP(hipMemcpy(b->stage_in, in_host, ib, hipMemcpyHostToDevice));
       }
       int rc = fz::launch(b->prog, g.n_in ? b->stage_in : nullptr, b->stage_out, g.n_state ? b->state : nullptr, b->params,
-                          b->n_streams, n_samples, nullptr, nullptr);
+                          b->n_streams, n_samples, nullptr, nullptr, 0);
       if (rc != FZ_OK) return rc;
       FZ_HIP(hipMemcpy(out_host, b->stage_out, ob, hipMemcpyDeviceToHost));
       return FZ_OK;)

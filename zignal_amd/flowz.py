@@ -242,35 +242,64 @@ class Program:
 
     # -- the hot path ----------------------------------------------------------------------
     def run_block_ptr(self, in_ptr, out_ptr, state_ptr, params_ptr, n_streams, n_samples,
-                      variant: Optional[Variant] = None, stream=None):
-        C.check(C.lib.fz_run_block(self._h, in_ptr, out_ptr, state_ptr, params_ptr, int(n_streams), int(n_samples),
-                                   ctypes.byref(variant) if variant is not None else None, stream))
+                      variant: Optional[Variant] = None, stream=None, tile_streams: int = 0):
+        vp = ctypes.byref(variant) if variant is not None else None
+        if tile_streams:
+            C.check(C.lib.fz_run_block_tiled(self._h, in_ptr, out_ptr, state_ptr, params_ptr, int(n_streams),
+                                             int(n_samples), int(tile_streams), vp, stream))
+        else:
+            C.check(C.lib.fz_run_block(self._h, in_ptr, out_ptr, state_ptr, params_ptr, int(n_streams),
+                                       int(n_samples), vp, stream))
 
     def run_block(self, x, state=None, params=None, out=None, variant: Optional[Variant] = None):
-        """x: CUDA float32 tensor [T, n_streams, n_in] (time-major frames).  state: [n_state, n_streams]
-        in/out (allocated zeroed when None), params: [n_param, n_streams].  Launches on torch's
-        current stream; returns (out [T, n_streams, n_out], state)."""
+        """x: CUDA float32 frames, either time-major [T, n_streams, n_in] or stream-tiled
+        [n_tiles, T, tile_streams, n_in] (the HBM-friendly layout, see fz_run_block_tiled).
+        state: [n_state, n_streams] in/out (allocated zeroed when None), params: [n_param, n_streams].
+        Launches on torch's current stream; returns (out, state), out laid out like x."""
         import torch
 
         if not x.is_cuda:
             raise NoDeviceError(C.FZ_E_NO_DEVICE, "run_block needs CUDA (ROCm) tensors: zignal_amd has no CPU path")
         if x.dim() == 2:
             x = x.unsqueeze(-1)
-        assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[2] == self.n_in, (x.shape, self.n_in)
-        T, ns = x.shape[0], x.shape[1]
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == self.n_in, (x.shape, self.n_in)
+        if x.dim() == 4:
+            n_tiles, T, tile, _ = x.shape
+            ns = n_tiles * tile
+            oshape = (n_tiles, T, tile, self.n_out)
+        else:
+            T, ns, _ = x.shape
+            tile = 0
+            oshape = (T, ns, self.n_out)
         if out is None:
-            out = torch.empty((T, ns, self.n_out), dtype=torch.float32, device=x.device)
+            out = torch.empty(oshape, dtype=torch.float32, device=x.device)
         if state is None:
             state = torch.zeros((max(self.n_state, 1), ns), dtype=torch.float32, device=x.device)
-        assert state.is_contiguous() and out.is_contiguous()
+        assert state.is_contiguous() and out.is_contiguous() and tuple(out.shape) == oshape
         pp = None
         if self.n_param:
             assert params is not None and params.is_contiguous() and tuple(params.shape) == (self.n_param, ns)
             pp = params.data_ptr()
         self.run_block_ptr(x.data_ptr() if self.n_in else None, out.data_ptr(),
                            state.data_ptr() if self.n_state else None, pp, ns, T, variant,
-                           torch.cuda.current_stream().cuda_stream)
+                           torch.cuda.current_stream().cuda_stream, tile)
         return out, state
+
+
+def to_tiled(x, tile_streams: int):
+    """time-major [T, n_streams, w] -> stream-tiled [n_tiles, T, tile_streams, w] (torch or numpy)."""
+    T, ns, w = x.shape
+    assert ns % tile_streams == 0
+    y = x.reshape(T, ns // tile_streams, tile_streams, w)
+    y = y.permute(1, 0, 2, 3).contiguous() if hasattr(y, "permute") else y.transpose(1, 0, 2, 3).copy()
+    return y
+
+
+def from_tiled(y):
+    """stream-tiled [n_tiles, T, tile_streams, w] -> time-major [T, n_streams, w]."""
+    n_tiles, T, tile, w = y.shape
+    z = y.permute(1, 0, 2, 3) if hasattr(y, "permute") else y.transpose(1, 0, 2, 3)
+    return z.reshape(T, n_tiles * tile, w)
 
 
 def compile(expr) -> Program:  # noqa: A001  (mirrors flowz::compile)
@@ -282,12 +311,18 @@ def device_count() -> int:
 
 
 def synth_fill(dst, seed: int, stream0: int = 0, t0: int = 0):
-    """Fill CUDA tensor dst [T, n_streams, n_wires] with the deterministic hash noise."""
+    """Fill CUDA tensor dst with the deterministic hash noise: time-major [T, n_streams, n_wires]
+    or stream-tiled [n_tiles, T, tile_streams, n_wires] (same values, tiled placement)."""
     import torch
 
-    T, ns, nw = dst.shape
+    if dst.dim() == 4:
+        n_tiles, T, tile, nw = dst.shape
+        ns = n_tiles * tile
+    else:
+        T, ns, nw = dst.shape
+        tile = 0
     assert dst.is_cuda and dst.dtype == torch.float32 and dst.is_contiguous()
-    C.check(C.lib.fz_synth_fill(dst.data_ptr(), ns, T, nw, int(seed), int(stream0), int(t0),
+    C.check(C.lib.fz_synth_fill(dst.data_ptr(), ns, T, nw, int(seed), int(stream0), int(t0), int(tile),
                                 torch.cuda.current_stream().cuda_stream))
     return dst
 
