@@ -117,6 +117,7 @@ def main():
     # first block from zero state: kept for the parity check
     prog.run_block(x, state=state, out=y, variant=variant)
     torch.cuda.synchronize()
+    first64_dev = None
     first64 = (y[0, :, :64, 0] if tile else y[:, :64, 0]).cpu().numpy() if rank == 0 else None
     for _ in range(max(args.warmup - 1, 0)):
         prog.run_block(x, state=state, out=y, variant=variant)
@@ -141,6 +142,26 @@ def main():
     checksum = float((y[:, -1] if tile else y[-1]).double().sum().item())      # last time step of every stream
     stats = zdist.reduce_stats(wall, float(ns) * T * args.steps, checksum, device=dev)
 
+    # the same workload on plain time-major frames [t][stream] (secondary figure, rank 0, N == 1)
+    tm = None
+    if tile and rank == 0 and world == 1:
+        del first64_dev
+        x2 = torch.empty((T, ns, 1), dtype=torch.float32, device=dev)
+        y2 = torch.empty((T, ns, 1), dtype=torch.float32, device=dev)
+        st2 = torch.zeros((prog.n_state, ns), dtype=torch.float32, device=dev)
+        F.synth_fill(x2, SEED, stream0=begin)
+        prog.run_block(x2, state=st2, out=y2, variant=variant)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            prog.run_block(x2, state=st2, out=y2, variant=variant)
+        e1.record()
+        torch.cuda.synchronize()
+        tm_ms = e0.elapsed_time(e1) / 5
+        tm = {"avg_launch_ms": round(tm_ms, 4), "Msamples_per_s": round(ns * T / tm_ms / 1e3, 1)}
+        del x2, y2, st2
+
     # copy-kernel yardstick (same bytes in + out), rank 0 only
     copy_gbs = None
     if rank == 0:
@@ -160,7 +181,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"cascade6_{ns}x{T}")
+            traffic = json.load(open(tpath)).get(f"cascade6_{ns}x{T}_" + (f"tile{tile}" if tile else "timemajor"))
         line = {
             "metric": "Msamples/sec/GPU + achieved HBM GB/s, 6-biquad cascade, 1M streams",
             "value": round(stats["samples"] / stats["seconds"] / 1e6, 1),
@@ -186,6 +207,10 @@ def main():
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None},
             "checksum": stats["checksum"],
         }
+        if tm is not None:
+            tm["achieved_GBs"] = round(b_alg / (tm["avg_launch_ms"] / 1e3) / 1e9, 1)
+            tm["frac"] = round(tm["achieved_GBs"] / HBM_PEAK_GBS, 4)
+            line["time_major_layout"] = tm
         if world == 1 and not args.no_cpu_baseline:
             base, parity = cpu_baseline(T, lambda k: first64[:, :k])
             line["cpu_baseline"] = base

@@ -168,6 +168,9 @@ int fz_run_block_tiled(fz_program* p, const float* in, float* out, float* state,
                        uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
                        const fz_variant* v, void* hip_stream);
 
+/* tile_streams that makes the row segments ~32 KiB for this graph's frame widths (power of two) */
+uint32_t fz_recommended_tile_streams(const fz_program* p);
+
 /* ------------------------------------------------------------------------------------------
  * fz_bank -- device-resident closure state for n_streams streams: the `state_` member of
  * stateful_lambda (flowz.hpp:1190-1191).  clone == copying the closure (snapshot, :1206).

@@ -80,6 +80,7 @@ def _load():
         "fz_program_source": (ctypes.c_long, [P, ctypes.POINTER(Variant), ctypes.c_char_p, ctypes.c_size_t]),
         "fz_run_block": (ctypes.c_int, [P, P, P, P, P, u64, u32, ctypes.POINTER(Variant), P]),
         "fz_run_block_tiled": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, ctypes.POINTER(Variant), P]),
+        "fz_recommended_tile_streams": (u32, [P]),
         "fz_bank_create": (ctypes.c_int, [P, u64, ctypes.POINTER(P)]),
         "fz_bank_clone": (ctypes.c_int, [P, ctypes.POINTER(P)]),
         "fz_bank_destroy": (None, [P]),

@@ -1,5 +1,6 @@
 // extern "C" entry points of libflowz_hip that are pure host work: compile(), IR inspection,
 // kernel build (hiprtc needs no GPU), and the fz_run_block wrapper.
+#include <cmath>
 #include <cstring>
 
 #include "fz_internal.hpp"
@@ -132,6 +133,18 @@ long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap
       set_error(er.msg);
       return er.code;
    }
+}
+
+uint32_t fz_recommended_tile_streams(const fz_program* p)
+{
+   if (!p) return 0;
+   // row segments of ~32 KiB stream best from HBM3E on MI355X (profiles/r01): with unequal frame
+   // widths aim the geometric mean of the input and output segment at 32 KiB
+   const double wi = p->g.n_in ? p->g.n_in : 1, wo = p->g.n_out ? p->g.n_out : 1;
+   double want = 8192.0 / std::sqrt(wi * wo);
+   uint32_t t = 1024;
+   while (t * 1.5 < want && t < 65536) t *= 2;
+   return t;
 }
 
 int fz_run_block(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,

@@ -171,7 +171,8 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    } else {
       // fill the chip first (256 CUs x 4 SIMDs, several waves each), then pack two streams per lane
       // (v_pk_* issue at the scalar rate on gfx950: twice the lane-ops per cycle)
-      v.P = (n_streams >= (1u << 19) && n_streams % 2 == 0) ? 2 : 1;
+      // -- unless the frames are already wide (>= 3 wires: 12+ bytes per lane with one stream)
+      v.P = (n_streams >= (1u << 19) && n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) ? 2 : 1;
    }
    // prefetch depth: few waves -> deeper chunks to keep enough bytes in flight per CU
    v.U = reqU ? reqU : 16;

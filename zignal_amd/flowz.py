@@ -228,6 +228,10 @@ class Program:
     def set_uniform(self, k: int, value: float):
         C.check(C.lib.fz_program_set_uniform(self._h, int(k), float(value)))
 
+    def recommended_tile_streams(self) -> int:
+        """Streams per frame tile that gives ~32 KiB row segments (see fz_run_block_tiled)."""
+        return int(C.lib.fz_recommended_tile_streams(self._h))
+
     def source(self, variant: Optional[Variant] = None) -> str:
         vp = ctypes.byref(variant) if variant is not None else None
         n = C.check(C.lib.fz_program_source(self._h, vp, None, 0))
