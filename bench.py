@@ -82,6 +82,8 @@ def main():
                     help="streams per frame tile (stream-tiled layout [tile][t][stream], the HBM-friendly "
                          "default); 0 = plain time-major [t][stream]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-major-too", action="store_true",
+                    help="also time the same workload on plain time-major frames (secondary figure)")
     args = ap.parse_args()
 
     import torch
@@ -144,7 +146,7 @@ def main():
 
     # the same workload on plain time-major frames [t][stream] (secondary figure, rank 0, N == 1)
     tm = None
-    if tile and rank == 0 and world == 1:
+    if args.time_major_too and tile and rank == 0 and world == 1:
         del first64_dev
         x2 = torch.empty((T, ns, 1), dtype=torch.float32, device=dev)
         y2 = torch.empty((T, ns, 1), dtype=torch.float32, device=dev)
