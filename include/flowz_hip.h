@@ -89,6 +89,7 @@ typedef struct fz_info {
    uint32_t n_param;     /* per-stream coefficients (highest fz_stream_param index + 1)       */
    uint32_t max_delay;   /* deepest delay line                                                */
    uint32_t n_lds_slots; /* ring-buffer slots kept in LDS (lines deeper than the register cap) */
+   uint32_t stage_packable; /* 1 when the graph is two isomorphic halves in series (FZ_VF_STAGE_PACK) */
 } fz_info;
 
 int  fz_compile(const fz_expr* e, fz_program** out);
@@ -133,7 +134,12 @@ typedef struct fz_variant {
 
 enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores                   */
        FZ_VF_NO_XCD_REMAP = 2u, /* plain blockIdx order instead of one contiguous stream range per XCD */
-       FZ_VF_SLP = 4u };        /* let the compiler's SLP vectoriser pair scalar ops (off by default) */
+       FZ_VF_SLP = 4u,          /* let the compiler's SLP vectoriser pair scalar ops (off by default) */
+       FZ_VF_STAGE_PACK = 8u,   /* one stream per lane, but pack the two isomorphic halves of a serial
+                                   graph (e.g. stages 1-3 | 4-6 of a cascade) into v_pk_* with the
+                                   second half running one sample behind; chosen automatically for
+                                   small stream counts when fz_info.stage_packable                  */
+       FZ_VF_NO_STAGE_PACK = 16u };
 
 int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */
 /* generated HIP source of a variant (skeleton + graph body); returns length, writes <= cap    */

@@ -340,3 +340,57 @@ def test_tiled_layout_rejects_bad_tiles(torch_cuda, F):
     x = torch.zeros((4, 8, 96, 1), device="cuda")                       # tile of 96 streams: not a multiple of 64
     with pytest.raises(F.FlowzError):
         prog.run_block(x)
+
+
+# ---- stage packing (FZ_VF_STAGE_PACK): halves of a serial graph in one v_pk_*, B one sample behind A ----
+STAGE_PACK = 8
+NO_STAGE_PACK = 16
+PACKABLE = {
+    "cascade6": lambda: G.df1_cascade(6),
+    "cascade2": lambda: G.df1_cascade(2),
+    "one_quad_chain": G.one_quad_chain,
+    "cascade4_distinct_coeffs": lambda: G.df1_cascade(4, [G.STABLE, G.PAR4_SETS[0], G.PAR4_SETS[1], G.PAR4_SETS[2]]),
+    "df2_pair": lambda: G.seq(G.df2(*G.STABLE), G.df2(*G.PAR4_SETS[3])),
+}
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 17, 101])
+@pytest.mark.parametrize("name", sorted(PACKABLE))
+def test_stage_packed_kernel_vs_oracle(torch_cuda, F, name, T):
+    g = PACKABLE[name]()
+    prog = F.compile(F.from_sexpr(g))
+    assert prog.stage_packable == 1
+    ns = 133
+    x = O.synth_input(SEED + 2, np.arange(ns), T)
+    want = O.compile(g, ns).run(x)
+    got, st = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, 8, 256, STAGE_PACK))
+    assert ndiff(got, want) == 0
+    ref, st_ref = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+    assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0       # canonical state after the epilogue
+
+
+def test_stage_packed_blocks_chain_with_any_variant(torch_cuda, F):
+    g = G.df1_cascade(6)
+    prog = F.compile(F.from_sexpr(g))
+    ns = 256
+    x = O.synth_input(8, np.arange(ns), 120)
+    want = C.df1_cascade([G.STABLE] * 6, x)
+    sk, plain, packed2 = F.make_variant(1, 16, 256, STAGE_PACK), F.make_variant(1, 8, 256, NO_STAGE_PACK), F.make_variant(2, 8)
+    a, st = run_gpu(torch_cuda, F, prog, x[:33], variant=sk)
+    b, st = run_gpu(torch_cuda, F, prog, x[33:34], variant=sk, state=st)       # a 1-sample block
+    c, st = run_gpu(torch_cuda, F, prog, x[34:70], variant=plain, state=st)
+    d, st = run_gpu(torch_cuda, F, prog, x[70:99], variant=sk, state=st)
+    e, st = run_gpu(torch_cuda, F, prog, x[99:], variant=packed2, state=st)
+    assert ndiff(np.concatenate([a, b, c, d, e]), want) == 0
+
+
+def test_stage_pack_is_automatic_for_few_streams_and_rejected_when_impossible(torch_cuda, F):
+    torch = torch_cuda
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    src = prog.source(F.make_variant(1, 16, 256, STAGE_PACK))
+    assert "#define FZ_SKEW 1" in src and "step2" in src
+    x = torch.zeros((4, 64, 1), device="cuda")
+    with pytest.raises(F.FlowzError):
+        F.compile(F.from_sexpr(G.df1_cascade(5))).run_block(x, variant=F.make_variant(1, 8, 256, STAGE_PACK))
+    with pytest.raises(F.FlowzError):
+        prog.run_block(x, variant=F.make_variant(2, 8, 256, STAGE_PACK))

@@ -24,13 +24,14 @@ class NoDeviceError(FlowzError):
 
 FZ_OK, FZ_E_INVALID, FZ_E_GRAPH, FZ_E_NO_DEVICE, FZ_E_HIP, FZ_E_COMPILE, FZ_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 FZ_OP_ADD, FZ_OP_SUB, FZ_OP_MUL, FZ_OP_DIV, FZ_OP_NEG = 1, 2, 3, 4, 5
-FZ_VF_NO_NT, FZ_VF_NO_XCD_REMAP, FZ_VF_SLP = 1, 2, 4
+FZ_VF_NO_NT, FZ_VF_NO_XCD_REMAP, FZ_VF_SLP, FZ_VF_STAGE_PACK, FZ_VF_NO_STAGE_PACK = 1, 2, 4, 8, 16
 IR_KINDS = {1: "input", 2: "const", 3: "param", 4: "delay", 5: "add", 6: "sub", 7: "mul", 8: "div", 9: "neg"}
 
 
 class Info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in
-                ("n_in", "n_out", "n_nodes", "n_ops", "n_lines", "n_state", "n_const", "n_param", "max_delay", "n_lds_slots")]
+                ("n_in", "n_out", "n_nodes", "n_ops", "n_lines", "n_state", "n_const", "n_param", "max_delay", "n_lds_slots",
+                 "stage_packable")]
 
 
 class IrNode(ctypes.Structure):

@@ -46,6 +46,7 @@ int fz_program_info(const fz_program* p, fz_info* info)
       info->n_param = g.n_param;
       info->max_delay = g.max_delay;
       info->n_lds_slots = g.n_lds_slots;
+      info->stage_packable = g.split.ok ? 1u : 0u;
       return FZ_OK;)
 }
 

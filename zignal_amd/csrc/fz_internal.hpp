@@ -41,6 +41,19 @@ struct fz_expr {
 
 namespace fz {
 
+// stage packing (fz_split.cpp): the graph is B after A with A isomorphic to B; every pair of
+// corresponding nodes is evaluated as one packed float2 operation, B running one sample behind A
+struct PackedLine {
+   uint32_t src_a, src_b;   // source nodes of the A-side and B-side delay line
+   uint32_t depth;
+};
+struct StageSplit {
+   bool ok = false;
+   uint32_t in_node = 0, cut_node = 0, out_node = 0;
+   std::vector<std::pair<uint32_t, uint32_t>> pairs;   // (A node, B node) in evaluation order
+   std::vector<PackedLine> lines;
+};
+
 // ---- lowered DAG ---------------------------------------------------------------------------------
 struct Node {
    uint32_t kind;   // fz_ir_kind
@@ -65,7 +78,10 @@ struct Graph {
    std::map<uint32_t, uint32_t> uniform_slot;   // fz_uniform id -> coefficient slot (never shared)
    uint32_t n_state = 0, max_delay = 0, n_ops = 0, n_lds_slots = 0;
    std::vector<int> line_of_node;    // node -> line index or -1
+   StageSplit split;                 // stage packing, when the graph allows it
 };
+
+StageSplit find_stage_split(const Graph& g);
 
 // register-resident delay lines up to this depth; deeper ones become LDS rings
 constexpr uint32_t kRegMaxDepth = 8;

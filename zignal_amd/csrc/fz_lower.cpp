@@ -311,6 +311,7 @@ Graph lower(const fz_expr* e)
    }
    g.n_state = row;
    g.n_lds_slots = lds;
+   g.split = find_stage_split(g);
    return g;
 }
 

@@ -176,6 +176,14 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    }
    // prefetch depth: few waves -> deeper chunks to keep enough bytes in flight per CU
    v.U = reqU ? reqU : 16;
+   // stage packing: one stream per lane, the two isomorphic halves of the graph in one v_pk_*
+   if (v.flags & FZ_VF_STAGE_PACK) {
+      if (!g.split.ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_STAGE_PACK: the graph is not two isomorphic halves in series");
+      if (v.P != 1) fail(FZ_E_INVALID, "FZ_VF_STAGE_PACK needs streams_per_lane == 1");
+   } else if (!reqP && v.P == 1 && g.split.ok && !(v.flags & FZ_VF_NO_STAGE_PACK)) {
+      v.flags |= FZ_VF_STAGE_PACK;
+   }
+   v.flags &= ~(uint32_t)FZ_VF_NO_STAGE_PACK;
    v.block = reqB ? reqB : 256;
    if (g.n_lds_slots) {
       // LDS rings: slots * block * 4P bytes must fit the CU's 160 KiB of LDS (one workgroup may take it all)
