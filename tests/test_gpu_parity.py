@@ -347,6 +347,8 @@ STAGE_PACK = 8
 NO_STAGE_PACK = 16
 PACKABLE = {
     "cascade6": lambda: G.df1_cascade(6),
+    "cascade8": lambda: G.df1_cascade(8),
+    "cascade12_two_stages_per_segment": lambda: G.df1_cascade(12),
     "cascade2": lambda: G.df1_cascade(2),
     "one_quad_chain": G.one_quad_chain,
     "cascade4_distinct_coeffs": lambda: G.df1_cascade(4, [G.STABLE, G.PAR4_SETS[0], G.PAR4_SETS[1], G.PAR4_SETS[2]]),
@@ -354,7 +356,7 @@ PACKABLE = {
 }
 
 
-@pytest.mark.parametrize("T", [1, 2, 3, 17, 101])
+@pytest.mark.parametrize("T", [1, 2, 3, 5, 6, 7, 9, 17, 101])
 @pytest.mark.parametrize("name", sorted(PACKABLE))
 def test_stage_packed_kernel_vs_oracle(torch_cuda, F, name, T):
     g = PACKABLE[name]()
@@ -388,7 +390,7 @@ def test_stage_pack_is_automatic_for_few_streams_and_rejected_when_impossible(to
     torch = torch_cuda
     prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
     src = prog.source(F.make_variant(1, 16, 256, STAGE_PACK))
-    assert "#define FZ_SKEW 1" in src and "step2" in src
+    assert "#define FZ_SKEW 5" in src and "#define FZ_NSEG 6" in src and "step2" in src     # 6 stages = 6 segments
     x = torch.zeros((4, 64, 1), device="cuda")
     with pytest.raises(F.FlowzError):
         F.compile(F.from_sexpr(G.df1_cascade(5))).run_block(x, variant=F.make_variant(1, 8, 256, STAGE_PACK))

@@ -41,16 +41,17 @@ struct fz_expr {
 
 namespace fz {
 
-// stage packing (fz_split.cpp): the graph is B after A with A isomorphic to B; every pair of
-// corresponding nodes is evaluated as one packed float2 operation, B running one sample behind A
+// stage packing (fz_split.cpp): the graph is K isomorphic segments in series; segment j runs at
+// time t-j and segments 2i, 2i+1 share one packed float2 operation per node
 struct PackedLine {
-   uint32_t src_a, src_b;   // source nodes of the A-side and B-side delay line
+   std::vector<uint32_t> srcs;   // per segment: the source node of this delay line
    uint32_t depth;
 };
 struct StageSplit {
    bool ok = false;
-   uint32_t in_node = 0, cut_node = 0, out_node = 0;
-   std::vector<std::pair<uint32_t, uint32_t>> pairs;   // (A node, B node) in evaluation order
+   uint32_t K = 0;                                  // number of segments (even)
+   std::vector<uint32_t> cuts;                      // c_0 = input node ... c_K = output node
+   std::vector<std::vector<uint32_t>> tuples;       // per node of segment 0: its partner in every segment, evaluation order
    std::vector<PackedLine> lines;
 };
 

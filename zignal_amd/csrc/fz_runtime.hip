@@ -172,10 +172,12 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // fill the chip first (256 CUs x 4 SIMDs, several waves each), then pack two streams per lane
       // (v_pk_* issue at the scalar rate on gfx950: twice the lane-ops per cycle)
       // -- unless the frames are already wide (>= 3 wires: 12+ bytes per lane with one stream)
-      v.P = (n_streams >= (1u << 19) && n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) ? 2 : 1;
+      // (measured crossover on the 6-biquad cascade: 2^18 streams, profiles/r01/sweep_stream_counts.txt)
+      v.P = (n_streams >= (1u << 18) && n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) ? 2 : 1;
    }
-   // prefetch depth: few waves -> deeper chunks to keep enough bytes in flight per CU
-   v.U = reqU ? reqU : 16;
+   // prefetch depth in time steps: 16 rows in flight per lane; 32 once the chip is oversubscribed
+   // with packed lanes (fewer, fatter waves: 2 per SIMD)
+   v.U = reqU ? reqU : ((v.P == 2 && n_streams >= (1u << 19) && g.n_in == 1 && g.n_out == 1) ? 32 : 16);
    // stage packing: one stream per lane, the two isomorphic halves of the graph in one v_pk_*
    if (v.flags & FZ_VF_STAGE_PACK) {
       if (!g.split.ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_STAGE_PACK: the graph is not two isomorphic halves in series");

@@ -1,17 +1,18 @@
-// Stage packing analysis: find a cut wire that splits a 1-in/1-out graph into two ISOMORPHIC
-// halves A (inputs -> cut) and B (cut -> output).
+// Stage packing analysis: cut a 1-in/1-out graph into K ISOMORPHIC segments in series,
+//     in = c_0 -> [S_0] -> c_1 -> [S_1] -> ... -> [S_{K-1}] -> c_K = out          (K even, 2..8)
 //
 // Why: with one stream per lane (few streams: one wave per SIMD is all there is) the kernel is
-// bound by the dependent scalar FP32 chain.  If the graph is a serial composition B after A of two
-// structurally identical halves -- e.g. stages 1-3 and 4-6 of a biquad cascade -- then half A at
-// time t and half B at time t-1 are independent, and because they are isomorphic every pair of
-// corresponding nodes is ONE v_pk_mul_f32 / v_pk_add_f32 on (A-value, B-value) with a packed
-// coefficient pair.  Same arithmetic, same order, same roundings per node; only the schedule is
-// skewed by one sample, so the instruction count and the dependent chain both halve.
-// This is a re-timing of the reference's per-sample evaluation order (sequence :960-1001 evaluates
-// left then right within a call); values are unaffected because B only ever consumes A's output.
+// bound by the dependent FP32 chain of the whole graph.  Re-timed so that segment j runs at time
+// t-j, all K segments are independent inside one step; and because they are isomorphic, segments
+// 2i and 2i+1 share ONE v_pk_mul_f32 / v_pk_add_f32 per node (with a packed coefficient pair).
+// A 6-stage biquad cascade becomes 3 independent packed instruction streams with a dependent
+// chain of 5 instead of one scalar chain of 30: half the instructions, six times the ILP.
+// Same arithmetic, same association order, same roundings per node: only the schedule is skewed
+// (segment j+1 consumes the value segment j produced one step earlier), which is a re-timing of
+// the reference's left-then-right evaluation inside one call (sequence, flowz.hpp:960-1001).
 #include <algorithm>
-#include <functional>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <set>
 
@@ -23,54 +24,63 @@ namespace {
 
 bool is_arith(uint32_t k) { return k == FZ_IR_ADD || k == FZ_IR_SUB || k == FZ_IR_MUL || k == FZ_IR_DIV || k == FZ_IR_NEG; }
 
+using Tuple = std::vector<uint32_t>;
+
 struct Matcher {
    const Graph& g;
-   uint32_t in, cut;
-   const std::vector<char>& inA;
-   std::map<std::pair<uint32_t, uint32_t>, int> pair_id;   // (a, b) -> index in pairs
-   std::vector<std::pair<uint32_t, uint32_t>> pairs;
-   std::map<uint32_t, uint32_t> a2b, b2a;                  // bijection on arithmetic nodes
+   const std::vector<uint32_t>& cuts;      // c_0 .. c_K
+   const std::vector<int>& seg_of;         // arithmetic node -> segment index
+   uint32_t K;
+   std::map<Tuple, int> id;                // tuple -> index (or -1 while being matched)
+   std::vector<Tuple> tuples;
+   std::vector<std::set<uint32_t>> used;   // per segment: arithmetic nodes already matched
 
-   bool match(uint32_t a, uint32_t b)
+   bool match(const Tuple& t)
    {
-      auto key = std::make_pair(a, b);
-      if (pair_id.count(key)) return true;
-      const Node& na = g.nodes[a];
-      const Node& nb = g.nodes[b];
-      if (na.kind == FZ_IR_INPUT) {
-         if (b != cut) return false;                        // A's input wire <-> B's input wire (the cut)
-         pair_id[key] = -1;
-         register_pair(key);
+      if (id.count(t)) return true;
+      const Node& n0 = g.nodes[t[0]];
+      if (n0.kind == FZ_IR_INPUT) {
+         for (uint32_t j = 1; j < K; ++j)
+            if (t[j] != cuts[j]) return false;           // a segment's input wire is the previous cut
+         add(t);
          return true;
       }
-      if (nb.kind == FZ_IR_INPUT) return false;
-      if (na.kind != nb.kind) return false;
-      if (is_arith(na.kind)) {
-         if (!inA[a] || inA[b]) return false;               // a in half A, b in half B
-         auto ia = a2b.find(a);
-         auto ib = b2a.find(b);
-         if (ia != a2b.end() || ib != b2a.end()) return false;   // (a,b) not paired before, so a clash
-         a2b[a] = b;
-         b2a[b] = a;
+      for (uint32_t j = 1; j < K; ++j) {
+         const Node& nj = g.nodes[t[j]];
+         if (nj.kind == FZ_IR_INPUT || nj.kind != n0.kind) return false;
       }
-      pair_id[key] = -1;                                    // provisional: breaks feedback cycles
+      if (is_arith(n0.kind)) {
+         for (uint32_t j = 0; j < K; ++j) {
+            if (seg_of[t[j]] != (int)j) return false;     // node j lives in segment j
+            if (!used[j].insert(t[j]).second) return false;   // bijection
+         }
+      }
+      id[t] = -1;                                          // provisional: breaks feedback cycles
+      auto operand = [&](bool second) {
+         Tuple o(K);
+         for (uint32_t j = 0; j < K; ++j) o[j] = second ? g.nodes[t[j]].b : g.nodes[t[j]].a;
+         return o;
+      };
       bool ok = true;
-      switch (na.kind) {
-         case FZ_IR_CONST: break;                           // values may differ: packed coefficient pair
-         case FZ_IR_PARAM: break;
-         case FZ_IR_DELAY: ok = na.b == nb.b && match(na.a, nb.a); break;
-         case FZ_IR_NEG: ok = match(na.a, nb.a); break;
-         default: ok = match(na.a, nb.a) && match(na.b, nb.b); break;
+      switch (n0.kind) {
+         case FZ_IR_CONST:
+         case FZ_IR_PARAM: break;                          // values may differ: packed coefficient pair
+         case FZ_IR_DELAY:
+            for (uint32_t j = 1; j < K; ++j) ok = ok && g.nodes[t[j]].b == n0.b;
+            ok = ok && match(operand(false));
+            break;
+         case FZ_IR_NEG: ok = match(operand(false)); break;
+         default: ok = match(operand(false)) && match(operand(true)); break;
       }
       if (!ok) return false;
-      register_pair(key);
+      add(t);
       return true;
    }
 
-   void register_pair(const std::pair<uint32_t, uint32_t>& key)
+   void add(const Tuple& t)
    {
-      pair_id[key] = (int)pairs.size();
-      pairs.push_back(key);
+      id[t] = (int)tuples.size();
+      tuples.push_back(t);
    }
 };
 
@@ -79,7 +89,7 @@ struct Matcher {
 StageSplit find_stage_split(const Graph& g)
 {
    StageSplit none;
-   if (g.n_in != 1 || g.n_out != 1 || g.n_lds_slots != 0 || g.n_ops < 2 || (g.n_ops & 1)) return none;
+   if (g.n_in != 1 || g.n_out != 1 || g.n_lds_slots != 0 || g.n_ops < 2) return none;
    const uint32_t N = (uint32_t)g.nodes.size();
    uint32_t in = N;
    for (uint32_t i = 0; i < N; ++i)
@@ -87,77 +97,118 @@ StageSplit find_stage_split(const Graph& g)
    const uint32_t out = g.outputs[0];
    if (in == N || !is_arith(g.nodes[out].kind)) return none;
 
-   for (uint32_t cut = 0; cut < N; ++cut) {
-      if (cut == out || !is_arith(g.nodes[cut].kind)) continue;
-      // half A = everything the cut wire depends on, through operands and delay lines
-      std::vector<char> inA(N, 0);
-      std::vector<uint32_t> work{cut};
-      uint32_t opsA = 0;
+   // backward closure (operands and delay lines) and its operation count, for every arithmetic node
+   std::vector<std::vector<char>> closure(N);
+   std::vector<uint32_t> cnt(N, 0);
+   for (uint32_t c = 0; c < N; ++c) {
+      if (!is_arith(g.nodes[c].kind)) continue;
+      std::vector<char>& in_c = closure[c];
+      in_c.assign(N, 0);
+      std::vector<uint32_t> work{c};
       while (!work.empty()) {
          uint32_t v = work.back();
          work.pop_back();
-         if (inA[v]) continue;
-         inA[v] = 1;
+         if (in_c[v]) continue;
+         in_c[v] = 1;
          const Node& n = g.nodes[v];
          if (is_arith(n.kind)) {
-            ++opsA;
+            ++cnt[c];
             work.push_back(n.a);
             if (n.kind != FZ_IR_NEG) work.push_back(n.b);
          } else if (n.kind == FZ_IR_DELAY) work.push_back(n.a);
       }
-      if (opsA * 2 != g.n_ops || inA[out]) continue;
-      // half B may touch half A only through the cut wire (now or delayed) and shared leaves
+   }
+   if (cnt[out] != g.n_ops) return none;
+
+   for (uint32_t K = 8; K >= 2; K -= 2) {
+      if (g.n_ops % K) continue;
+      const uint32_t unit = g.n_ops / K;
+      // cut wires: nested closures with j * unit operations
+      std::vector<uint32_t> cuts(K + 1, N);
+      cuts[0] = in;
+      cuts[K] = out;
+      bool found = true;
+      for (uint32_t j = K - 1; j >= 1 && found; --j) {
+         found = false;
+         // every node of a feedback loop has the same closure; the wire that leaves the segment is
+         // the topologically last one, so scan from the back
+         for (uint32_t c = N; c-- > 0 && !found;)
+            if (is_arith(g.nodes[c].kind) && cnt[c] == j * unit && closure[cuts[j + 1]][c] && c != cuts[j + 1]) {
+               cuts[j] = c;
+               found = true;
+            }
+      }
+      if (std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "K=%u unit=%u found=%d\n", K, unit, (int)found);
+      if (!found) continue;
+      // segment of every arithmetic node
+      std::vector<int> seg_of(N, -1);
+      for (uint32_t v = 0; v < N; ++v) {
+         if (!is_arith(g.nodes[v].kind)) continue;
+         for (uint32_t j = 0; j < K; ++j)
+            if (closure[cuts[j + 1]][v]) { seg_of[v] = (int)j; break; }
+      }
+      // a segment may touch earlier ones only through its input cut wire (now or delayed) and leaves
       bool clean = true;
-      auto b_operand_ok = [&](uint32_t o) {
+      auto operand_ok = [&](uint32_t o, int j) {
          const Node& n = g.nodes[o];
-         if (!inA[o]) return n.kind != FZ_IR_INPUT;
-         if (o == cut) return true;
          if (n.kind == FZ_IR_CONST || n.kind == FZ_IR_PARAM) return true;
-         return n.kind == FZ_IR_DELAY && n.a == cut;
+         if (n.kind == FZ_IR_INPUT) return j == 0;
+         if (n.kind == FZ_IR_DELAY) {
+            const Node& s = g.nodes[n.a];
+            if (s.kind == FZ_IR_INPUT) return j == 0;
+            return seg_of[n.a] == j || (j > 0 && n.a == cuts[(size_t)j]);
+         }
+         return seg_of[o] == j || (j > 0 && o == cuts[(size_t)j]);
       };
       for (uint32_t v = 0; v < N && clean; ++v) {
-         if (inA[v]) continue;
+         if (!is_arith(g.nodes[v].kind)) continue;
          const Node& n = g.nodes[v];
-         if (is_arith(n.kind)) clean = b_operand_ok(n.a) && (n.kind == FZ_IR_NEG || b_operand_ok(n.b));
-         else if (n.kind == FZ_IR_DELAY) clean = (!inA[n.a] || n.a == cut);
-         else if (n.kind == FZ_IR_INPUT) clean = false;
+         clean = operand_ok(n.a, seg_of[v]) && (n.kind == FZ_IR_NEG || operand_ok(n.b, seg_of[v]));
+         if (!clean && std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "  node %u kind %u a=%u b=%u seg=%d cuts1=%u\n", v, n.kind, n.a, n.b, seg_of[v], cuts[1]);
       }
+      if (std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "K=%u clean=%d\n", K, (int)clean);
       if (!clean) continue;
-      Matcher m{g, in, cut, inA, {}, {}, {}, {}};
-      if (!m.match(cut, out)) continue;
-      if (m.a2b.size() != opsA) continue;                    // every operation of A has its partner
-      // every delay line must be covered by a packed line (a source pair that is delayed somewhere)
+
+      Matcher m{g, cuts, seg_of, K, {}, {}, std::vector<std::set<uint32_t>>(K)};
+      Tuple root(K);
+      for (uint32_t j = 0; j < K; ++j) root[j] = cuts[j + 1];
+      const bool mok = m.match(root);
+      if (std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "K=%u match=%d used0=%zu\n", K, (int)mok, m.used[0].size());
+      if (!mok) continue;
+      if (m.used[0].size() != unit) continue;              // every operation of S_0 has its partners
+
       StageSplit s;
       s.ok = true;
-      s.in_node = in;
-      s.cut_node = cut;
-      s.out_node = out;
-      // evaluation order: by the A-side node's topological position; leaves and delays first
-      std::vector<std::pair<uint32_t, uint32_t>> ordered = m.pairs;
-      std::stable_sort(ordered.begin(), ordered.end(), [&](const auto& x, const auto& y) {
-         const bool ax = is_arith(g.nodes[x.first].kind), ay = is_arith(g.nodes[y.first].kind);
+      s.K = K;
+      s.cuts = cuts;
+      // evaluation order: leaves and delayed reads first, then by the S_0 node's topological position
+      s.tuples = m.tuples;
+      std::stable_sort(s.tuples.begin(), s.tuples.end(), [&](const Tuple& x, const Tuple& y) {
+         const bool ax = is_arith(g.nodes[x[0]].kind), ay = is_arith(g.nodes[y[0]].kind);
          if (ax != ay) return !ax;
-         return ax ? x.first < y.first : false;
+         return ax ? x[0] < y[0] : false;
       });
-      s.pairs = ordered;
-      std::map<std::pair<uint32_t, uint32_t>, uint32_t> line_depth;
-      for (auto& p : s.pairs)
-         if (g.nodes[p.first].kind == FZ_IR_DELAY) {
-            auto src = std::make_pair(g.nodes[p.first].a, g.nodes[p.second].a);
-            line_depth[src] = std::max(line_depth[src], g.nodes[p.first].b);
+      std::map<Tuple, uint32_t> line_depth;                // tuple of line sources -> depth
+      for (auto& t : s.tuples)
+         if (g.nodes[t[0]].kind == FZ_IR_DELAY) {
+            Tuple src(K);
+            for (uint32_t j = 0; j < K; ++j) src[j] = g.nodes[t[j]].a;
+            line_depth[src] = std::max(line_depth[src], g.nodes[t[0]].b);
          }
       std::set<uint32_t> covered;
       for (auto& kv : line_depth) {
-         const int la = g.line_of_node[kv.first.first], lb = g.line_of_node[kv.first.second];
-         if (la < 0 || lb < 0) { s.ok = false; break; }
          PackedLine pl;
-         pl.src_a = kv.first.first;
-         pl.src_b = kv.first.second;
-         pl.depth = std::max(g.lines[(size_t)la].depth, g.lines[(size_t)lb].depth);
-         if (pl.depth > kRegMaxDepth) { s.ok = false; break; }
+         pl.srcs = kv.first;
+         pl.depth = 0;
+         for (uint32_t j = 0; j < K && s.ok; ++j) {
+            const int l = g.line_of_node[pl.srcs[j]];
+            if (l < 0) { s.ok = false; break; }
+            pl.depth = std::max(pl.depth, g.lines[(size_t)l].depth);
+            covered.insert(pl.srcs[j]);
+         }
+         if (pl.depth > kRegMaxDepth) s.ok = false;
+         if (!s.ok) break;
          s.lines.push_back(pl);
-         covered.insert(pl.src_a);
-         covered.insert(pl.src_b);
       }
       if (!s.ok) continue;
       for (const Line& l : g.lines)
