@@ -100,9 +100,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the flow-graph evaluator has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     ns, T = args.streams, args.samples
     begin, end = zdist.shard_range(ns * world, rank, world)      # this rank's global stream ids
@@ -125,7 +127,7 @@ def main():
         prog.run_block(x, state=state, out=y, variant=variant)
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -218,7 +220,7 @@ def main():
             line["cpu_baseline"] = base
             line["parity"] = parity
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

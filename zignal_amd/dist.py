@@ -22,7 +22,7 @@ def reduce_stats(seconds: float, samples: float, checksum: float, device=None) -
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return {"seconds": float(seconds), "samples": float(samples), "checksum": float(checksum), "world": 1}
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     s = torch.tensor([samples, checksum], dtype=torch.float64, device=device)
