@@ -308,6 +308,15 @@ public:
       refresh_refs();
       detail::check(fz_bank_process(bank_, in_dev, out_dev, n_samples, v, hip_stream));
    }
+   // stream-tiled frames (the HBM-friendly layout): in [n_streams/tile][n_samples][tile][n_in], out alike;
+   // recommended_tile_streams() gives ~32 KiB row segments for this graph
+   void process_tiled(const float* in_dev, float* out_dev, uint32_t n_samples, uint32_t tile_streams,
+                      void* hip_stream = nullptr, const fz_variant* v = nullptr)
+   {
+      refresh_refs();
+      detail::check(fz_bank_process_tiled(bank_, in_dev, out_dev, n_samples, tile_streams, v, hip_stream));
+   }
+   uint32_t recommended_tile_streams() const { return fz_recommended_tile_streams(prog_.get()); }
    void process_host(const float* in_host, float* out_host, uint32_t n_samples)
    {
       refresh_refs();

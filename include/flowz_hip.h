@@ -193,6 +193,9 @@ int  fz_bank_set_params_host(fz_bank* b, const float* params /* [n_param][n_stre
 float* fz_bank_state_device(fz_bank* b);                                 /* [n_state][n_streams] */
 int  fz_bank_process(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples,
                      const fz_variant* v, void* hip_stream);
+/* fz_bank_process with stream-tiled frames (see fz_run_block_tiled) */
+int  fz_bank_process_tiled(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples,
+                           uint32_t tile_streams, const fz_variant* v, void* hip_stream);
 int  fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint32_t n_samples);
 
 /* ------------------------------------------------------------------------------------------

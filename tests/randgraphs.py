@@ -1,0 +1,82 @@
+"""Seeded random Flowz graphs (s-expressions) for fuzzing the lowering and the kernels.
+
+Graphs are built from the reference's combinators with their arity rules; all
+feedback paths go through small coefficients so that responses stay bounded."""
+import numpy as np
+
+from graphs import DEL, IN, add, chan, fb, lit, mul, par, seq, sub
+
+
+def _coef(rng, lo=0.05, hi=0.45):
+    c = rng.uniform(lo, hi)
+    return lit(c if rng.random() < 0.5 else -c)
+
+
+def _leaf(rng, n_in, delayed_only=()):
+    i = int(rng.integers(1, n_in + 1))
+    if i in delayed_only or rng.random() < 0.45:
+        return DEL(i, int(rng.integers(1, 5)))
+    return IN(i)
+
+
+def box(rng, n_in, delayed_only=(), must_use=None):
+    """arithmetic box over _1.._n_in with one output"""
+    terms = []
+    uses = list(range(1, n_in + 1)) if must_use is None else list(must_use)
+    rng.shuffle(uses)
+    n_terms = max(len(uses), int(rng.integers(1, 4)))
+    for k in range(n_terms):
+        if k < len(uses):
+            i = uses[k]
+            leaf = DEL(i, int(rng.integers(1, 5))) if (i in delayed_only or rng.random() < 0.4) else IN(i)
+        else:
+            leaf = _leaf(rng, n_in, delayed_only)
+        t = mul(_coef(rng), leaf) if rng.random() < 0.8 else leaf
+        if rng.random() < 0.15:
+            t = ("neg", t)
+        terms.append(t)
+    e = terms[0]
+    for t in terms[1:]:
+        e = add(e, t) if rng.random() < 0.7 else sub(e, t)
+    if rng.random() < 0.1:
+        e = ("div", e, lit(rng.uniform(1.5, 3.0)))
+    return e
+
+
+def graph(rng, n_in, depth):
+    """random graph with exactly n_in input wires; returns (sexpr, n_out)"""
+    r = rng.random()
+    if depth <= 0 or r < 0.25:
+        return box(rng, n_in), 1
+    if r < 0.45:                                     # a |= b
+        a, oa = graph(rng, n_in, depth - 1)
+        b, ob = graph(rng, oa, depth - 1)
+        return seq(a, b), ob
+    if r < 0.6 and n_in >= 2:                        # a | b
+        k = int(rng.integers(1, n_in))
+        a, oa = graph(rng, k, depth - 1)
+        b, ob = graph(rng, n_in - k, depth - 1)
+        return par(a, b), oa + ob
+    if r < 0.75:                                     # a , b  (same inputs)
+        a, oa = graph(rng, n_in, depth - 1)
+        b, ob = graph(rng, n_in, depth - 1)
+        return chan(a, b), oa + ob
+    if r < 0.9:                                      # ~( feedback of one wire through a delayed read )
+        body = box(rng, n_in + 1, delayed_only=(1,), must_use=range(1, n_in + 2))
+        g = fb(body)
+        if rng.random() < 0.5:
+            post, op = graph(rng, 1, depth - 1)
+            return seq(g, post), op
+        return g, 1
+    # two cross-coupled fed-back wires (the cross_wire pattern, multi_wires_feedback.cpp:721)
+    inner = chan(DEL(2, int(rng.integers(1, 3))), *[IN(2 + k) for k in range(1, n_in + 1)], DEL(1, int(rng.integers(1, 3))))
+    left = box(rng, 1 + n_in, must_use=range(1, n_in + 2))
+    right = mul(_coef(rng), IN(1))
+    return fb(seq(inner, par(left, right))), 2
+
+
+def make(seed, max_in=3, depth=3):
+    rng = np.random.default_rng(seed)
+    n_in = int(rng.integers(1, max_in + 1))
+    g, n_out = graph(rng, n_in, depth)
+    return g, n_in, n_out

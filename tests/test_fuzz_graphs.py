@@ -1,0 +1,75 @@
+"""Randomised graphs: lowering vs oracle on the CPU (IR interpreter, tests only) and the fused
+kernels vs the oracle on the GPU."""
+import numpy as np
+import pytest
+
+import randgraphs as R
+from ir_interp import run_ir
+from oracle import flowz_oracle as O
+from zignal_amd import flowz as F
+
+
+def same_or_both_nan(a, b):
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    nan = np.isnan(a) & np.isnan(b)
+    return np.array_equal(np.where(nan, 0, a).view(np.uint32), np.where(nan, 0, b).view(np.uint32))
+
+
+def usable(seed):
+    g, n_in, n_out = R.make(seed)
+    try:
+        ok = O.input_arity(g) == n_in and O.output_arity(g) == n_out
+        O.compile(g, 1)
+    except O.GraphError:
+        return None
+    return (g, n_in, n_out) if ok else None
+
+
+def test_generator_yields_mostly_valid_graphs():
+    assert sum(usable(s) is not None for s in range(200)) > 150
+
+
+@pytest.mark.parametrize("chunk", range(8))
+def test_lowering_matches_oracle_on_random_graphs(chunk):
+    n = 0
+    for seed in range(chunk * 25, chunk * 25 + 25):
+        u = usable(seed)
+        if u is None:
+            continue
+        g, n_in, n_out = u
+        p = F.compile(F.from_sexpr(g))
+        assert (p.n_in, p.n_out) == (n_in, n_out)
+        x = O.synth_input(seed, np.arange(2), 40, n_wires=n_in)
+        want = O.compile(g, 2).run(x)
+        got, _ = run_ir(p, x)
+        assert same_or_both_nan(got, want), f"seed {seed}: {g}"
+        assert np.isfinite(want).all(), f"seed {seed} blew up"
+        n += 1
+    assert n >= 15
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", range(6))
+def test_kernels_match_oracle_on_random_graphs(chunk):
+    import torch
+    ns, T = 136, 45
+    n = 0
+    for seed in range(1000 + chunk * 20, 1000 + chunk * 20 + 20):
+        u = usable(seed)
+        if u is None:
+            continue
+        g, n_in, n_out = u
+        p = F.compile(F.from_sexpr(g))
+        x = O.synth_input(seed, np.arange(ns), T, n_wires=n_in)
+        want = O.compile(g, ns).run(x)
+        xd = torch.from_numpy(x).cuda()
+        for P in (1, 2, 4):
+            y, _ = p.run_block(xd, variant=F.make_variant(P, 8))
+            assert same_or_both_nan(y.cpu().numpy(), want), f"seed {seed} P={P}: {g}"
+        # split into two chained blocks at an odd point
+        ya, st = p.run_block(xd[:19].contiguous())
+        yb, st = p.run_block(xd[19:].contiguous(), state=st)
+        assert same_or_both_nan(torch.cat([ya, yb]).cpu().numpy(), want), f"seed {seed} chained"
+        n += 1
+    assert n >= 10

@@ -89,6 +89,7 @@ def _load():
         "fz_bank_set_params_host": (ctypes.c_int, [P, P]),
         "fz_bank_state_device": (P, [P]),
         "fz_bank_process": (ctypes.c_int, [P, P, P, u32, ctypes.POINTER(Variant), P]),
+        "fz_bank_process_tiled": (ctypes.c_int, [P, P, P, u32, u32, ctypes.POINTER(Variant), P]),
         "fz_bank_process_host": (ctypes.c_int, [P, P, P, u32]),
         "fz_device_count": (ctypes.c_int, []),
         "fz_synth_fill": (ctypes.c_int, [P, u64, u32, u32, u32, u64, u64, u32, P]),

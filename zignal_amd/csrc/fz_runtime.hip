@@ -437,6 +437,16 @@ int fz_bank_process(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_
       return fz::launch(b->prog, in_dev, out_dev, g.n_state ? b->state : nullptr, b->params, b->n_streams, n_samples, v, hip_stream, 0);)
 }
 
+int fz_bank_process_tiled(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples, uint32_t tile_streams,
+                          const fz_variant* v, void* hip_stream)
+{
+   FZ_GUARD(
+      if (!b) fail(FZ_E_INVALID, "null bank");
+      const Graph& g = b->prog->g;
+      return fz::launch(b->prog, in_dev, out_dev, g.n_state ? b->state : nullptr, b->params, b->n_streams, n_samples, v,
+                        hip_stream, tile_streams);)
+}
+
 int fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint32_t n_samples)
 {
    FZ_GUARD(
