@@ -156,6 +156,7 @@ long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap
  *   state  [n_state][n_streams]  in/out; zero it before the first block (flowz.hpp:1245);
  *          carries the closure state from block to block (may be NULL iff n_state == 0)
  *   params [n_param][n_streams]  (NULL iff n_param == 0)
+ * n_samples == 0 or n_streams == 0 is an empty block: FZ_OK, nothing is touched.
  * Asynchronous on `hip_stream` (hipStream_t, NULL = default stream); the caller synchronises.
  * `v` may be NULL (all defaults).  A program may run concurrently on different state buffers.
  * ---------------------------------------------------------------------------------------- */

@@ -396,3 +396,58 @@ def test_stage_pack_is_automatic_for_few_streams_and_rejected_when_impossible(to
         F.compile(F.from_sexpr(G.df1_cascade(5))).run_block(x, variant=F.make_variant(1, 8, 256, STAGE_PACK))
     with pytest.raises(F.FlowzError):
         prog.run_block(x, variant=F.make_variant(2, 8, 256, STAGE_PACK))
+
+
+# ---- empty blocks, maximum sizes -------------------------------------------------------------------------
+def test_empty_block_is_a_noop(torch_cuda, F):
+    torch = torch_cuda
+    prog = F.compile(F.from_sexpr(G.df1_cascade(2)))
+    x = O.synth_input(1, np.arange(64), 10)
+    y, st = run_gpu(torch, F, prog, x)
+    before = st.clone()
+    prog.run_block_ptr(None, y.ctypes.data if hasattr(y, "ctypes") else 0, st.data_ptr(), None, 64, 0)   # 0 samples
+    prog.run_block_ptr(None, None, None, None, 0, 16)                                                      # 0 streams
+    torch.cuda.synchronize()
+    assert torch.equal(before, st)
+
+
+def test_headline_workload_1M_x_4096_tiled_full_size(torch_cuda, F):
+    """bench.py's workload itself: 6-stage cascade, 1 048 576 streams x 4096 samples, tile 8192
+    (16 GiB in, 16 GiB out).  Sampled streams (first/last tiles included) bitwise vs the compiled
+    oracle over the full length; a second variant bit-identical on the whole output."""
+    torch = torch_cuda
+    ns, T, tile = 1 << 20, 4096, 8192
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    x = torch.empty((ns // tile, T, tile, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED)
+    y, st = prog.run_block(x)
+    ids = _sample_ids(ns, 256, 5)
+    xh = O.synth_input(SEED, ids, T)
+    want = C.df1_cascade([G.STABLE] * 6, xh)
+    tl, within = torch.from_numpy(ids // tile).cuda(), torch.from_numpy(ids % tile).cuda()
+    got = y[tl, :, within, 0].T.cpu().numpy()                      # [T, n_ids]
+    assert ndiff(got[:, :, None], want) == 0
+    assert ndiff(x[tl, :, within, 0].T.cpu().numpy()[:, :, None], xh) == 0
+    y2, st2 = prog.run_block(x, variant=F.make_variant(4, 4))
+    assert torch.equal(y.view(torch.int32), y2.view(torch.int32))
+    assert torch.equal(st.view(torch.int32), st2.view(torch.int32))
+
+
+def test_many_streams_16M(torch_cuda, F):
+    """16 777 216 streams x 24 samples: 64 MiB rows (time-major) and 2048 tiles; checks the 64-bit row /
+    tile addressing at the far end of the buffers."""
+    torch = torch_cuda
+    ns, T = 1 << 24, 24
+    prog = F.compile(F.from_sexpr(G.df1_cascade(2)))
+    ids = np.unique(np.concatenate([[0, 1, ns - 1, ns - 2, ns - 8193, 12345678], np.random.default_rng(7).integers(0, ns, 64)]))
+    xh = O.synth_input(SEED, ids, T)
+    want = C.df1_cascade([G.STABLE] * 2, xh)
+    idt = torch.from_numpy(ids).cuda()
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED)
+    y, _ = prog.run_block(x)
+    assert ndiff(y[:, idt].cpu().numpy(), want) == 0
+    xt = torch.empty((ns // 8192, T, 8192, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(xt, SEED)
+    yt, _ = prog.run_block(xt)
+    assert torch.equal(F.from_tiled(yt).contiguous().view(torch.int32), y.view(torch.int32))

@@ -216,7 +216,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
            uint32_t n_samples, const fz_variant* uv, void* stream, uint32_t tile_streams)
 {
    const Graph& g = p->g;
-   if (n_streams == 0 || n_samples == 0) fail(FZ_E_INVALID, "n_streams and n_samples must be > 0");
+   if (n_streams == 0 || n_samples == 0) return FZ_OK;      // an empty block: nothing to evaluate, state unchanged
    if (!out) fail(FZ_E_INVALID, "out is null");
    if (g.n_in && !in) fail(FZ_E_INVALID, "in is null but the graph has input wires");
    if (g.n_state && !state) fail(FZ_E_INVALID, "state is null but the graph has delay lines");
