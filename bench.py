@@ -8,7 +8,8 @@ already resident in HBM.  Rank 0 prints ONE JSON line.
 
   value      whole-job Msamples/s = streams(all ranks) * 4096 * K / max-over-ranks wall time
   roofline   dominant kernel fz_block_kernel: algorithmic bytes per launch / its average launch
-             duration measured with HIP events on the launch stream inside the timed region;
+             duration = HIP-event time over the K back-to-back launches of the timed region / K,
+             events recorded on the launch stream (torch's current stream, which run_block uses);
              peak = 8000 GB/s (HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md)
   cpu_baseline  the compiled scalar oracle (one closure per stream, one call per sample: what
              the reference's compile()-callable does) timed on this box's host cores on a
@@ -131,17 +132,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the launch stream around the K back-to-back launches (one pair: an event per
+    # launch costs tens of microseconds of GPU time each, visible on sub-millisecond kernels)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
+    ev0.record()
     for k in range(args.steps):
-        ev[k][0].record()
         prog.run_block(x, state=state, out=y, variant=variant)
-        ev[k][1].record()
+    ev1.record()
     barrier()
     wall = time.perf_counter() - t0
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
-    kern_avg_s = sum(kern_ms) / len(kern_ms) / 1e3
+    kern_avg_s = ev0.elapsed_time(ev1) / args.steps / 1e3
 
     checksum = float((y[:, -1] if tile else y[-1]).double().sum().item())      # last time step of every stream
     stats = zdist.reduce_stats(wall, float(ns) * T * args.steps, checksum, device=dev)
