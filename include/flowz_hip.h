@@ -140,6 +140,8 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
                                    second half running one sample behind; chosen automatically for
                                    small stream counts when fz_info.stage_packable                  */
        FZ_VF_NO_STAGE_PACK = 16u };
+/* bits 8..11 of flags: minimum waves per SIMD requested from the register allocator (0 = none) */
+#define FZ_VF_MIN_WAVES(n) (((uint32_t)(n) & 15u) << 8)
 
 int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */
 /* generated HIP source of a variant (skeleton + graph body); returns length, writes <= cap    */

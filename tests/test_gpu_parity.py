@@ -451,3 +451,35 @@ def test_many_streams_16M(torch_cuda, F):
     F.synth_fill(xt, SEED)
     yt, _ = prog.run_block(xt)
     assert torch.equal(F.from_tiled(yt).contiguous().view(torch.int32), y.view(torch.int32))
+
+
+def test_one_program_many_states_concurrently(torch_cuda, F):
+    """A program handle is re-entrant for concurrent fz_run_block calls on different state buffers
+    (SURVEY 8b): two host threads, two HIP streams, interleaved blocks."""
+    import threading
+    torch = torch_cuda
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    ns, T, nblk = 4096, 64, 12
+    xs = [O.synth_input(40 + k, np.arange(ns), T * nblk) for k in range(2)]
+    want = [C.df1_cascade([G.STABLE] * 6, x) for x in xs]
+    outs = [None, None]
+
+    def worker(k):
+        torch.cuda.set_device(0)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            xd = torch.from_numpy(xs[k]).cuda()
+            st = torch.zeros((prog.n_state, ns), device="cuda")
+            ys = []
+            for b in range(nblk):
+                y, st = prog.run_block(xd[b * T:(b + 1) * T].contiguous(), state=st,
+                                       variant=F.make_variant(1 + k, 8))
+                ys.append(y)
+            stream.synchronize()
+            outs[k] = torch.cat(ys).cpu().numpy()
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(2):
+        assert ndiff(outs[k], want[k]) == 0
