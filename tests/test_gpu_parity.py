@@ -348,6 +348,10 @@ NO_STAGE_PACK = 16
 PACKABLE = {
     "cascade6": lambda: G.df1_cascade(6),
     "cascade8": lambda: G.df1_cascade(8),
+    "cascade3_prefix_plus_2": lambda: G.df1_cascade(3),
+    "cascade5_prefix_plus_4": lambda: G.df1_cascade(5),
+    "cascade7_prefix_plus_6": lambda: G.df1_cascade(7, [G.STABLE, G.PAR4_SETS[0], G.PAR4_SETS[1], G.STABLE, G.PAR4_SETS[3], G.STABLE, G.PAR4_SETS[2]]),
+    "integrator_then_cascade2": lambda: G.seq(G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 1)), G.IN(2))), G.df1_cascade(2)),
     "cascade12_two_stages_per_segment": lambda: G.df1_cascade(12),
     "cascade2": lambda: G.df1_cascade(2),
     "one_quad_chain": G.one_quad_chain,
@@ -369,6 +373,26 @@ def test_stage_packed_kernel_vs_oracle(torch_cuda, F, name, T):
     assert ndiff(got, want) == 0
     ref, st_ref = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
     assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0       # canonical state after the epilogue
+
+
+@pytest.mark.parametrize("T", [1, 4, 7, 64])
+def test_stage_packed_osc_chain_with_scalar_prefix_and_per_stream_coefficients(torch_cuda, F, T):
+    """resonator (scalar prefix) -> 6 DF1 stages (6 packed segments), 31 per-stream coefficients."""
+    ns = 200
+    prog = F.compile(F.from_sexpr(G.osc_chain(6)))
+    assert prog.stage_packable == 1
+    P = W.osc_chain_params(SEED + 3, np.arange(ns))
+    x = np.zeros((T, ns, 1), np.float32)
+    x[0] = 1.0
+    got, st = run_gpu(torch_cuda, F, prog, x, params=P, variant=F.make_variant(1, 8, 256, STAGE_PACK))
+    assert ndiff(got, C.osc_chain(P, x)) == 0
+    ref, st_ref = run_gpu(torch_cuda, F, prog, x, params=P, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+    assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0
+    # next block continues from the canonical state with the other variant
+    x2 = np.zeros((9, ns, 1), np.float32)
+    a, _ = run_gpu(torch_cuda, F, prog, x2, params=P, variant=F.make_variant(2, 8), state=st)
+    b, _ = run_gpu(torch_cuda, F, prog, x2, params=P, variant=F.make_variant(1, 8, 256, STAGE_PACK), state=st_ref)
+    assert ndiff(a, b) == 0
 
 
 def test_stage_packed_blocks_chain_with_any_variant(torch_cuda, F):
@@ -393,7 +417,7 @@ def test_stage_pack_is_automatic_for_few_streams_and_rejected_when_impossible(to
     assert "#define FZ_SKEW 5" in src and "#define FZ_NSEG 6" in src and "step2" in src     # 6 stages = 6 segments
     x = torch.zeros((4, 64, 1), device="cuda")
     with pytest.raises(F.FlowzError):
-        F.compile(F.from_sexpr(G.df1_cascade(5))).run_block(x, variant=F.make_variant(1, 8, 256, STAGE_PACK))
+        F.compile(F.from_sexpr(G.par4_sum_fanout())).run_block(x, variant=F.make_variant(1, 8, 256, STAGE_PACK))
     with pytest.raises(F.FlowzError):
         prog.run_block(x, variant=F.make_variant(2, 8, 256, STAGE_PACK))
 

@@ -184,8 +184,8 @@ def test_product_never_imports_the_oracle():
 def test_stage_split_detection_and_packed_kernel_builds(tmp_path, monkeypatch):
     import subprocess
     monkeypatch.setenv("FLOWZ_HIP_CACHE", str(tmp_path))
-    want = {"cascade6": (G.df1_cascade(6), 1), "cascade2": (G.df1_cascade(2), 1), "cascade5": (G.df1_cascade(5), 0),
-            "df1": (G.df1(), 0), "osc": (G.osc_chain(6), 0), "one_quad_chain": (G.one_quad_chain(), 1),
+    want = {"cascade6": (G.df1_cascade(6), 1), "cascade2": (G.df1_cascade(2), 1), "cascade5": (G.df1_cascade(5), 1),
+            "df1": (G.df1(), 0), "osc": (G.osc_chain(6), 1), "one_quad_chain": (G.one_quad_chain(), 1),
             "par4": (G.par4_sum(), 0), "cross_wire": (G.cross_wire(), 0)}
     for name, (g, ok) in want.items():
         assert F.compile(F.from_sexpr(g)).stage_packable == ok, name
@@ -194,5 +194,6 @@ def test_stage_split_detection_and_packed_kernel_builds(tmp_path, monkeypatch):
     (obj,) = tmp_path.glob("*.hsaco")
     dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", str(obj)], text=True)
     assert dis.count("v_pk_mul_f32") > 100 and not re.search(r"v_(pk_)?(fma|fmac|mad|mac)_", dis)
+    F.compile(F.from_sexpr(G.osc_chain(6))).build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))   # scalar prefix + 6 segments
     with pytest.raises(F.FlowzError):
-        F.compile(F.from_sexpr(G.df1_cascade(5))).build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))
+        F.compile(F.from_sexpr(G.df1())).build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))

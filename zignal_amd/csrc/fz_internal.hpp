@@ -53,6 +53,8 @@ struct StageSplit {
    std::vector<uint32_t> cuts;                      // c_0 = input node ... c_K = output node
    std::vector<std::vector<uint32_t>> tuples;       // per node of segment 0: its partner in every segment, evaluation order
    std::vector<PackedLine> lines;
+   std::vector<uint32_t> prefix;                    // scalar prefix (nodes cuts[0] depends on), evaluation order
+   std::vector<uint32_t> prefix_lines;              // delay lines private to the prefix (indices into Graph::lines)
 };
 
 // ---- lowered DAG ---------------------------------------------------------------------------------

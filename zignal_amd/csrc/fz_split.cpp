@@ -39,12 +39,13 @@ struct Matcher {
    {
       if (id.count(t)) return true;
       const Node& n0 = g.nodes[t[0]];
-      if (n0.kind == FZ_IR_INPUT) {
+      if (t[0] == cuts[0]) {                               // the chain's input wire (graph input or prefix output)
          for (uint32_t j = 1; j < K; ++j)
             if (t[j] != cuts[j]) return false;           // a segment's input wire is the previous cut
          add(t);
          return true;
       }
+      if (n0.kind == FZ_IR_INPUT) return false;
       for (uint32_t j = 1; j < K; ++j) {
          const Node& nj = g.nodes[t[j]];
          if (nj.kind == FZ_IR_INPUT || nj.kind != n0.kind) return false;
@@ -120,12 +121,19 @@ StageSplit find_stage_split(const Graph& g)
    }
    if (cnt[out] != g.n_ops) return none;
 
+   // chain input candidates: the graph input itself (no prefix), then every arithmetic wire p whose
+   // closure is a scalar PREFIX evaluated at the time of segment 0 (e.g. an oscillator in front of a cascade)
+   std::vector<uint32_t> starts{in};
+   for (uint32_t c = 0; c < N; ++c)
+      if (is_arith(g.nodes[c].kind) && c != out && cnt[c] * 2 <= g.n_ops) starts.push_back(c);
+   for (uint32_t p0 : starts)
    for (uint32_t K = 8; K >= 2; K -= 2) {
-      if (g.n_ops % K) continue;
-      const uint32_t unit = g.n_ops / K;
+      const uint32_t base = p0 == in ? 0u : cnt[p0];
+      if ((g.n_ops - base) % K) continue;
+      const uint32_t unit = (g.n_ops - base) / K;
       // cut wires: nested closures with j * unit operations
       std::vector<uint32_t> cuts(K + 1, N);
-      cuts[0] = in;
+      cuts[0] = p0;
       cuts[K] = out;
       bool found = true;
       for (uint32_t j = K - 1; j >= 1 && found; --j) {
@@ -133,7 +141,7 @@ StageSplit find_stage_split(const Graph& g)
          // every node of a feedback loop has the same closure; the wire that leaves the segment is
          // the topologically last one, so scan from the back
          for (uint32_t c = N; c-- > 0 && !found;)
-            if (is_arith(g.nodes[c].kind) && cnt[c] == j * unit && closure[cuts[j + 1]][c] && c != cuts[j + 1]) {
+            if (is_arith(g.nodes[c].kind) && cnt[c] == base + j * unit && closure[cuts[j + 1]][c] && c != cuts[j + 1] && (p0 == in || closure[c][p0])) {
                cuts[j] = c;
                found = true;
             }
@@ -141,9 +149,10 @@ StageSplit find_stage_split(const Graph& g)
       if (std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "K=%u unit=%u found=%d\n", K, unit, (int)found);
       if (!found) continue;
       // segment of every arithmetic node
-      std::vector<int> seg_of(N, -1);
+      std::vector<int> seg_of(N, -1);                      // -2: prefix
       for (uint32_t v = 0; v < N; ++v) {
          if (!is_arith(g.nodes[v].kind)) continue;
+         if (p0 != in && closure[p0][v]) { seg_of[v] = -2; continue; }
          for (uint32_t j = 0; j < K; ++j)
             if (closure[cuts[j + 1]][v]) { seg_of[v] = (int)j; break; }
       }
@@ -152,16 +161,13 @@ StageSplit find_stage_split(const Graph& g)
       auto operand_ok = [&](uint32_t o, int j) {
          const Node& n = g.nodes[o];
          if (n.kind == FZ_IR_CONST || n.kind == FZ_IR_PARAM) return true;
-         if (n.kind == FZ_IR_INPUT) return j == 0;
-         if (n.kind == FZ_IR_DELAY) {
-            const Node& s = g.nodes[n.a];
-            if (s.kind == FZ_IR_INPUT) return j == 0;
-            return seg_of[n.a] == j || (j > 0 && n.a == cuts[(size_t)j]);
-         }
-         return seg_of[o] == j || (j > 0 && o == cuts[(size_t)j]);
+         if (o == cuts[(size_t)j]) return true;            // the segment's input wire
+         if (n.kind == FZ_IR_INPUT) return false;
+         if (n.kind == FZ_IR_DELAY) return n.a == cuts[(size_t)j] || (is_arith(g.nodes[n.a].kind) && seg_of[n.a] == j);
+         return seg_of[o] == j;
       };
       for (uint32_t v = 0; v < N && clean; ++v) {
-         if (!is_arith(g.nodes[v].kind)) continue;
+         if (!is_arith(g.nodes[v].kind) || seg_of[v] == -2) continue;
          const Node& n = g.nodes[v];
          clean = operand_ok(n.a, seg_of[v]) && (n.kind == FZ_IR_NEG || operand_ok(n.b, seg_of[v]));
          if (!clean && std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "  node %u kind %u a=%u b=%u seg=%d cuts1=%u\n", v, n.kind, n.a, n.b, seg_of[v], cuts[1]);
@@ -176,6 +182,7 @@ StageSplit find_stage_split(const Graph& g)
       if (std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "K=%u match=%d used0=%zu\n", K, (int)mok, m.used[0].size());
       if (!mok) continue;
       if (m.used[0].size() != unit) continue;              // every operation of S_0 has its partners
+      if (std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "split: K=%u prefix_ops=%u start=%u\n", K, base, p0);
 
       StageSplit s;
       s.ok = true;
@@ -211,8 +218,17 @@ StageSplit find_stage_split(const Graph& g)
          s.lines.push_back(pl);
       }
       if (!s.ok) continue;
-      for (const Line& l : g.lines)
-         if (!covered.count(l.src)) s.ok = false;
+      // prefix: every node the chain input depends on, in evaluation order; its private delay lines
+      if (p0 != in)
+         for (uint32_t v = 0; v < N; ++v)
+            if (closure[p0][v]) s.prefix.push_back(v);
+      for (size_t l = 0; l < g.lines.size(); ++l) {
+         const uint32_t src = g.lines[l].src;
+         if (covered.count(src)) continue;
+         const bool in_prefix = p0 != in && (src == in || closure[p0][src]);
+         if (!in_prefix) { s.ok = false; break; }
+         s.prefix_lines.push_back((uint32_t)l);
+      }
       if (!s.ok) continue;
       return s;
    }
