@@ -4,15 +4,15 @@
 // Why: with one stream per lane (few streams: one wave per SIMD is all there is) the kernel is
 // bound by the dependent FP32 chain of the whole graph.  Re-timed so that segment j runs at time
 // t-j, all K segments are independent inside one step; and because they are isomorphic, segments
-// 2i and 2i+1 share ONE v_pk_mul_f32 / v_pk_add_f32 per node (with a packed coefficient pair).
+// i and i+K/2 share ONE v_pk_mul_f32 / v_pk_add_f32 per node (with a packed coefficient pair).
+// c_0 may also be an internal wire: everything it depends on is then a scalar PREFIX that runs
+// un-packed together with segment 0 (an oscillator in front of a cascade, an odd first stage).
 // A 6-stage biquad cascade becomes 3 independent packed instruction streams with a dependent
 // chain of 5 instead of one scalar chain of 30: half the instructions, six times the ILP.
 // Same arithmetic, same association order, same roundings per node: only the schedule is skewed
 // (segment j+1 consumes the value segment j produced one step earlier), which is a re-timing of
 // the reference's left-then-right evaluation inside one call (sequence, flowz.hpp:960-1001).
 #include <algorithm>
-#include <cstdio>
-#include <cstdlib>
 #include <map>
 #include <set>
 
@@ -146,7 +146,6 @@ StageSplit find_stage_split(const Graph& g)
                found = true;
             }
       }
-      if (std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "K=%u unit=%u found=%d\n", K, unit, (int)found);
       if (!found) continue;
       // segment of every arithmetic node
       std::vector<int> seg_of(N, -1);                      // -2: prefix
@@ -170,19 +169,14 @@ StageSplit find_stage_split(const Graph& g)
          if (!is_arith(g.nodes[v].kind) || seg_of[v] == -2) continue;
          const Node& n = g.nodes[v];
          clean = operand_ok(n.a, seg_of[v]) && (n.kind == FZ_IR_NEG || operand_ok(n.b, seg_of[v]));
-         if (!clean && std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "  node %u kind %u a=%u b=%u seg=%d cuts1=%u\n", v, n.kind, n.a, n.b, seg_of[v], cuts[1]);
       }
-      if (std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "K=%u clean=%d\n", K, (int)clean);
       if (!clean) continue;
 
       Matcher m{g, cuts, seg_of, K, {}, {}, std::vector<std::set<uint32_t>>(K)};
       Tuple root(K);
       for (uint32_t j = 0; j < K; ++j) root[j] = cuts[j + 1];
-      const bool mok = m.match(root);
-      if (std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "K=%u match=%d used0=%zu\n", K, (int)mok, m.used[0].size());
-      if (!mok) continue;
+      if (!m.match(root)) continue;
       if (m.used[0].size() != unit) continue;              // every operation of S_0 has its partners
-      if (std::getenv("FLOWZ_SPLIT_DEBUG")) std::fprintf(stderr, "split: K=%u prefix_ops=%u start=%u\n", K, base, p0);
 
       StageSplit s;
       s.ok = true;
