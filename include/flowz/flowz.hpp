@@ -8,7 +8,8 @@
 //    _1[_2]            wire 1 delayed by 2           :84-85   (also _1[-2]: the spelling of
 //                                                    experimental_steps/delay_expression.cpp:99-100)
 //    a , b   a | b   a |= b   ~a                     :90-93   channel / parallel / sequence / feedback
-//    + - * / unary -   with literals                 :68-72, :769-772 (float32 terminals)
+//    + - * / unary -   with literals                 :68-72, :769-772 (float terminals; a `double` literal
+//                                                    makes the operators above it evaluate in float64)
 //    std::ref(x)       external modulation           flowz/README.md:42-61 (read at every call / block)
 //    compile(expr)     -> callable closure           :1233-1249
 //    f(x1..xN) -> std::tuple<float x M>              :1225-1229, fewer args -> curried copy :1203-1212
@@ -107,10 +108,14 @@ inline ref_list merge(const ref_list& a, const ref_list& b)
    return r;
 }
 
-// literal terminals: arithmetic values are held by value as float32 (make_terminal, :68-72)
+// literal terminals are held by value (make_terminal, :68-72).  A C++ `double` literal stays a
+// double: the operators above it evaluate in float64 exactly as the built-in operators of the
+// reference do (proto::_default :769-772); everything else (float, integers) is a float32 terminal.
 template <class T, class = typename std::enable_if<std::is_arithmetic<T>::value>::type>
 expr<0, 1> as_expr(T v)
 {
+   if (std::is_same<T, double>::value || std::is_same<T, long double>::value)
+      return expr<0, 1>(handle(fz_literal_f64(static_cast<double>(v))));
    return expr<0, 1>(handle(fz_literal(static_cast<float>(v))));
 }
 inline expr<0, 1> as_expr(std::reference_wrapper<float> r)

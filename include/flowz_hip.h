@@ -48,6 +48,10 @@ typedef enum fz_op { FZ_OP_ADD = 1, FZ_OP_SUB = 2, FZ_OP_MUL = 3, FZ_OP_DIV = 4,
 fz_expr* fz_placeholder(uint32_t i);                 /* _i          make_placeholder<i>() :78-82   */
 fz_expr* fz_delayed(uint32_t i, uint32_t n);         /* _i[_n]      delayed_placeholder   :84-85   */
 fz_expr* fz_literal(float value);                    /* terminal held by value  make_terminal :68-72 */
+fz_expr* fz_literal_f64(double value);               /* a C++ `double` literal terminal: the operators above
+                                                        it evaluate in double (usual arithmetic conversions,
+                                                        proto::_default :769-772; test/tests.cpp:200-231),
+                                                        delay lines and output frames stay float32 (:1245) */
 fz_expr* fz_stream_param(uint32_t k);                /* per-stream, block-constant coefficient k:
                                                         the std::ref terminal of flowz/README.md:42-61,
                                                         one value per stream                          */
@@ -85,11 +89,12 @@ typedef struct fz_info {
    uint32_t n_ops;       /* arithmetic nodes = float32 operations per stream-sample           */
    uint32_t n_lines;     /* delay lines (one per delayed wire, shared by all its readers)     */
    uint32_t n_state;     /* floats of state per stream = sum of line depths                   */
-   uint32_t n_const;     /* distinct uniform coefficients (literal terminals)                 */
+   uint32_t n_const;     /* distinct uniform float32 coefficients (literal terminals)         */
    uint32_t n_param;     /* per-stream coefficients (highest fz_stream_param index + 1)       */
    uint32_t max_delay;   /* deepest delay line                                                */
    uint32_t n_lds_slots; /* ring-buffer slots kept in LDS (lines deeper than the register cap) */
-   uint32_t stage_packable; /* 1 when the graph is two isomorphic halves in series (FZ_VF_STAGE_PACK) */
+   uint32_t stage_packable; /* 1 when the graph is a series of isomorphic segments (FZ_VF_STAGE_PACK) */
+   uint32_t n_const64;   /* distinct float64 literal terminals                                */
 } fz_info;
 
 int  fz_compile(const fz_expr* e, fz_program** out);
@@ -106,7 +111,12 @@ typedef enum fz_ir_kind {
    FZ_IR_NEG = 9      /* -a                                                                    */
 } fz_ir_kind;
 
-typedef struct fz_ir_node { uint32_t kind, a, b; float value; } fz_ir_node;
+typedef struct fz_ir_node {
+   uint32_t kind, a, b;
+   float value;        /* FZ_IR_CONST, dtype 0 */
+   uint32_t dtype;     /* 0 = float32, 1 = float64 (the node's C++ arithmetic type) */
+   double value64;     /* FZ_IR_CONST, dtype 1 */
+} fz_ir_node;
 
 /* nodes are in evaluation (topological) order; writes min(n, cap), returns n */
 int fz_program_ir(const fz_program* p, fz_ir_node* nodes, uint32_t cap);

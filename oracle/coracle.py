@@ -115,6 +115,15 @@ def osc_chain(params, x, n_stage=6, stream_major=False):
     return _run("fzo_osc_chain", (_p(params), _pd(params.shape[1]), ctypes.c_int(n_stage)), x, 1, 1, stream_major)
 
 
+def one_pole_readme(a, x, stream_major=False):
+    return _run("fzo_one_pole_readme", (ctypes.c_float(float(F32(a))),), x, 1, 1, stream_major)
+
+
+def mixed_precision_biquad(x, b=(0.05, -0.075, 0.275), a=(0.2, -0.8), stream_major=False):
+    pre = tuple(ctypes.c_double(float(v)) for v in b) + tuple(ctypes.c_float(float(F32(v))) for v in a)
+    return _run("fzo_mixed_precision_biquad", pre, x, 1, 1, stream_major)
+
+
 def synth_fill(seed, stream0, n_streams, T, n_wires=1, t0=0, stream_major=False):
     out = np.empty((n_streams, T, n_wires) if stream_major else (T, n_streams, n_wires), F32)
     ss, ts = _strides(T, n_streams, n_wires, stream_major)

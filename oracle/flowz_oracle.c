@@ -210,6 +210,43 @@ void fzo_osc_chain(const float* params, ptrdiff_t pss, int n_stage,
    }
 }
 
+/* ---- one-pole of flowz/README.md:52  `~( a*_1[_1] + 0.1*_2 )`: `0.1` is a DOUBLE literal, so by the
+ * usual arithmetic conversions of the built-in operators (flowz.hpp:769-772) 0.1*x and the sum are
+ * double; the fed-back value is truncated to float when pushed into the delay line (:130-137, :1245) */
+void fzo_one_pole_readme(float a, const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                         float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      float y1 = 0.f;
+      for (long t = 0; t < T; ++t) {
+         float x0 = x[s * xss + t * xts];
+         double o = a * y1 + 0.1 * x0;          /* float*float + double*float -> double */
+         y1 = (float)o;
+         y[s * yss + t * yts] = (float)o;        /* output frames are float32 */
+      }
+   }
+}
+
+/* ---- DF1 whose feed-forward coefficients are double literals: f in double, feedback products in
+ * float, y = (f + (double)(a1*y1)) + (double)(a2*y2) in double, truncated to float for the delay
+ * line and the frame (tests/graphs.py: mixed_precision_biquad)                                   */
+void fzo_mixed_precision_biquad(double b0, double b1, double b2, float a1, float a2,
+                                const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                                float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      float x1 = 0.f, x2 = 0.f, y1 = 0.f, y2 = 0.f;
+      for (long t = 0; t < T; ++t) {
+         float x0 = x[s * xss + t * xts];
+         double f = (b0 * x0 + b1 * x1) + b2 * x2;
+         double o = (f + a1 * y1) + a2 * y2;     /* a1*y1 is a float product, then promoted */
+         x2 = x1; x1 = x0;
+         y2 = y1; y1 = (float)o;
+         y[s * yss + t * yts] = (float)o;
+      }
+   }
+}
+
 /* ---- synthetic input, identical to oracle/flowz_oracle.py: synth_input -------------- */
 static inline uint32_t fmix32(uint32_t h)
 {

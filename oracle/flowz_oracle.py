@@ -44,6 +44,11 @@ Graph notation ("s-expressions", plain nested tuples; a shared data format, no c
     ('in', i)            placeholder _i                     flowz.hpp:1252-1257
     ('del', i, n)        delayed placeholder _i[_n]         flowz.hpp:84-85
     ('lit', v)           literal terminal (float32)         flowz.hpp:68-72
+    ('lit64', v)         C++ `double` literal terminal: operators above it evaluate in float64
+                         (usual arithmetic conversions applied by the built-in operators,
+                         flowz.hpp:769-772; test/tests.cpp:200-231); the value is truncated to
+                         float when it enters a delay line (rotate_push_back :130-137, state is
+                         float :1245) and when it leaves the graph (float32 output frames)
     ('param', k)         per-stream coefficient k (block-constant std::ref analogue,
                          flowz/README.md:42-61)
     ('add'|'sub'|'mul'|'div', a, b), ('neg', a)             flowz.hpp:769-772
@@ -73,7 +78,7 @@ def input_arity(e) -> int:
     k = e[0]
     if k in ("in", "del"):
         return int(e[1])                      # :163-170  arity of _i is i
-    if k in ("lit", "param"):
+    if k in ("lit", "lit64", "param"):
         return 0                              # :171-174
     if k == "fb":                             # :175-181
         return max(0, input_arity(e[1]) - output_arity(e[1]))
@@ -117,7 +122,7 @@ def max_input_delays(e) -> tuple:
         return (0,) * (e[1] - 1) + (int(e[2]),)
     if k == "in":
         return (0,) * e[1]
-    if k in ("lit", "param"):
+    if k in ("lit", "lit64", "param"):
         return ()
     if k == "fb":                             # :459-465
         return max_input_delays(e[1])[output_arity(e[1]):]
@@ -222,6 +227,9 @@ class FlowzOracle:
         if k == "lit":
             c = F32(e[1])
             return [self._new(lambda c=c: np.full(self.n_streams, c, F32))]
+        if k == "lit64":
+            c64 = np.float64(e[1])
+            return [self._new(lambda c64=c64: np.full(self.n_streams, c64, np.float64))]
         if k == "param":
             idx = int(e[1])
             return [self._new(lambda idx=idx: self._params[idx])]

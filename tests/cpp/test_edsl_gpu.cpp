@@ -89,18 +89,24 @@ int main()
                           0x1.2b7fep+0f, -0x1.540034p-1f, 0x1.119986p+0f, -0x1.7d70c6p-1f};
       for (int n = 0; n < 8; ++n) CHECK(std::get<0>(f(n == 0 ? 1.f : 0.f)) == h[n]);
    }
-   {  // external modulation with std::ref, flowz/README.md:42-61: y = a*y1 + 0.1f*x, a *= 0.9f per call
+   {  // external modulation with std::ref, flowz/README.md:42-61.  `0.1` is a double literal there:
+      // the product 0.1*x and the sum are evaluated in double (C++ usual arithmetic conversions), the
+      // fed-back value is truncated to float in the delay line (flowz.hpp:1245); a *= 0.9f per call
       float a = 1.f;
       auto one_pole = compile(~(std::ref(a) * _1[_1] + 0.1 * _2));
       float ar = 1.f, y1 = 0.f;
       for (int n = 0; n < 10; ++n) {
-         const float x = n == 0 ? 1.f : 0.f;
-         const float want = ar * y1 + 0.1f * x;
-         CHECK(std::get<0>(one_pole(x)) == want);
-         y1 = want;
+         const float x = n == 0 ? 1.f : 0.25f;
+         const double want = ar * y1 + 0.1 * x;            // float*float + double*float -> double
+         CHECK(std::get<0>(one_pole(x)) == static_cast<float>(want));
+         y1 = static_cast<float>(want);
          a *= 0.9f;
          ar *= 0.9f;
       }
+      // the all-float spelling rounds differently
+      float a2 = 1.f;
+      auto one_pole_f = compile(~(std::ref(a2) * _1[_1] + 0.1f * _2));
+      CHECK(one_pole_f.info().n_const64 == 0 && one_pole.info().n_const64 == 1);
    }
    {  // block API: 96 independent integrators, 33 samples in one launch, then 7 more (state carried)
       auto f = compile(~(_1[_1] + _2));

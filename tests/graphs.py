@@ -12,6 +12,10 @@ def lit(v):
     return ("lit", float(F32(v)))
 
 
+def lit64(v):
+    return ("lit64", float(v))
+
+
 def IN(i):
     return ("in", i)
 
@@ -166,6 +170,18 @@ def par4_sum_fanout():
 
 def param(k):
     return ("param", k)
+
+
+def one_pole_readme(a=0.9):
+    """flowz/README.md:52  ~( a*_1[_1] + 0.1*_2 ) with the README's DOUBLE literal 0.1: the product
+    0.1*_2 and the sum are float64, the fed-back value is truncated to float in the delay line."""
+    return fb(add(mul(lit(a), DEL(1, 1)), mul(lit64(0.1), IN(2))))
+
+
+def mixed_precision_biquad():
+    """DF1 whose feed-forward coefficients are double literals (b0*_1 + ... in double), feedback in float"""
+    f = add(add(mul(lit64(0.05), IN(1)), mul(lit64(-0.075), DEL(1, 1))), mul(lit64(0.275), DEL(1, 2)))
+    return seq(f, bwd(F32(0.2), F32(-0.8)))
 
 
 def resonator_param(k):

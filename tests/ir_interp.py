@@ -16,6 +16,7 @@ def run_ir(prog, x, params=None, state=None):
         x = x[:, :, None]
     T, ns, _ = x.shape
     ir = prog.ir()
+    dts = prog.ir_dtypes()
     outs = prog.outputs()
     lines = prog.lines()
     row0, r = {}, 0
@@ -34,7 +35,7 @@ def run_ir(prog, x, params=None, state=None):
                 if kind == "input":
                     v[i] = x[t, :, a]
                 elif kind == "const":
-                    v[i] = np.full(ns, F32(val), F32)
+                    v[i] = np.full(ns, val, np.float64) if dts[i] == "f64" else np.full(ns, F32(val), F32)
                 elif kind == "param":
                     v[i] = np.asarray(params[a], F32)
                 elif kind == "delay":

@@ -110,6 +110,9 @@ GRAPHS = {
                                     G.fb(G.add(G.mul(G.lit(0.7), G.DEL(1, 23)), G.IN(2)))),
     "depth8_regs": lambda: G.add(G.mul(G.lit(0.5), G.DEL(1, 8)), G.sub(G.DEL(1, 3), G.IN(1))),
     "div_neg": lambda: ("div", ("neg", G.IN(1)), G.add(G.lit(2.5), G.mul(G.DEL(1, 1), G.DEL(1, 1)))),
+    "one_pole_double_literal": G.one_pole_readme,                      # flowz/README.md:52
+    "mixed_precision_biquad": G.mixed_precision_biquad,
+    "double_div": lambda: ("div", G.add(G.IN(1), G.lit64(1.5)), G.add(G.lit64(3.0), G.mul(G.DEL(1, 1), G.DEL(1, 1)))),
 }
 
 
@@ -177,6 +180,20 @@ def test_osc_chain_per_stream_coefficients(torch_cuda, F):
     for lanes in (1, 2, 4):
         got, _ = run_gpu(torch_cuda, F, prog, x, params=P, variant=F.make_variant(lanes, 8))
         assert ndiff(got, C.osc_chain(P, x)) == 0
+
+
+def test_double_literal_graphs_vs_compiled_c(torch_cuda, F):
+    """float64 sub-expressions (C++ double literals) at a few thousand streams, vs compiled C."""
+    ns, T = 3000, 300
+    x = O.synth_input(SEED + 9, np.arange(ns), T)
+    p1 = F.compile(F.from_sexpr(G.one_pole_readme(0.9)))
+    p2 = F.compile(F.from_sexpr(G.mixed_precision_biquad()))
+    assert p1.n_const64 == 1 and p2.n_const64 == 3 and p1.stage_packable == 0
+    for P in (1, 2, 4):
+        got, _ = run_gpu(torch_cuda, F, p1, x, variant=F.make_variant(P, 8))
+        assert ndiff(got, C.one_pole_readme(0.9, x)) == 0
+        got, _ = run_gpu(torch_cuda, F, p2, x, variant=F.make_variant(P, 8))
+        assert ndiff(got, C.mixed_precision_biquad(x)) == 0
 
 
 def test_denormals_and_specials_are_kept(torch_cuda, F):

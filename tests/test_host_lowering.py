@@ -76,6 +76,9 @@ GRAPHS = {
     "long_delay": lambda: G.seq(G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 40))),
                                 G.fb(G.add(G.mul(G.lit(0.7), G.DEL(1, 23)), G.IN(2)))),
     "div_neg": lambda: ("div", ("neg", G.IN(1)), G.add(G.lit(2.5), G.mul(G.DEL(1, 1), G.DEL(1, 1)))),
+    "one_pole_double_literal": G.one_pole_readme,                      # flowz/README.md:52
+    "mixed_precision_biquad": G.mixed_precision_biquad,
+    "double_div": lambda: ("div", G.add(G.IN(1), G.lit64(1.5)), G.add(G.lit64(3.0), G.mul(G.DEL(1, 1), G.DEL(1, 1)))),
 }
 
 

@@ -86,3 +86,13 @@ def test_stable_set_stays_bounded_over_block():
     x = O.synth_input(20160512, np.arange(8), 4096)
     y = C.df1_cascade([G.STABLE] * 6, x)
     assert np.isfinite(y).all() and np.abs(y).max() < 4.0
+
+
+def test_double_literals_follow_cpp_usual_arithmetic_conversions():
+    """`0.1*_2` with a double literal (flowz/README.md:52): the generic oracle's float64 promotion
+    equals compiled C with the same types, and differs from the all-float spelling."""
+    x = O.synth_input(21, np.arange(NS), T)
+    assert same(C.one_pole_readme(0.9, x), O.compile(G.one_pole_readme(0.9), NS).run(x))
+    assert same(C.mixed_precision_biquad(x), O.compile(G.mixed_precision_biquad(), NS).run(x))
+    allf = ("fb", ("add", ("mul", G.lit(0.9), G.DEL(1, 1)), ("mul", G.lit(0.1), G.IN(2))))
+    assert not same(O.compile(allf, NS).run(x), O.compile(G.one_pole_readme(0.9), NS).run(x))

@@ -47,6 +47,7 @@ int fz_program_info(const fz_program* p, fz_info* info)
       info->max_delay = g.max_delay;
       info->n_lds_slots = g.n_lds_slots;
       info->stage_packable = g.split.ok ? 1u : 0u;
+      info->n_const64 = (uint32_t)g.consts64.size();
       return FZ_OK;)
 }
 
@@ -58,7 +59,10 @@ int fz_program_ir(const fz_program* p, fz_ir_node* nodes, uint32_t cap)
       nodes[k].kind = g.nodes[k].kind;
       nodes[k].a = g.nodes[k].a;
       nodes[k].b = g.nodes[k].b;
-      nodes[k].value = g.nodes[k].kind == FZ_IR_CONST ? g.consts[g.nodes[k].a] : 0.f;
+      const bool c = g.nodes[k].kind == FZ_IR_CONST;
+      nodes[k].dtype = g.nodes[k].f64 ? 1u : 0u;
+      nodes[k].value = (c && !g.nodes[k].f64) ? g.consts[g.nodes[k].a] : 0.f;
+      nodes[k].value64 = (c && g.nodes[k].f64) ? g.consts64[g.nodes[k].a] : 0.0;
    }
    return (int)g.nodes.size();
 }

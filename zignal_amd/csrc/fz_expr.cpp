@@ -138,6 +138,16 @@ fz_expr* fz_literal(float value)
    return e;
 }
 
+fz_expr* fz_literal_f64(double value)
+{
+   auto* e = mk(EK::Literal);
+   e->value = (float)value;
+   e->value64 = value;
+   e->f64 = true;
+   e->in_arity = 0;
+   return e;
+}
+
 fz_expr* fz_uniform(uint32_t k, float initial)
 {
    FZ_GUARD_PTR(

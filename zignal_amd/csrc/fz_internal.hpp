@@ -32,6 +32,8 @@ struct fz_expr {
    uint32_t i = 0;        // placeholder index / param index
    uint32_t n = 0;        // delay
    float value = 0.f;     // literal
+   double value64 = 0.0;  // float64 literal
+   bool f64 = false;      // literal is a C++ double
    fz_op op = FZ_OP_ADD;  // arith
    fz_expr* a = nullptr;
    fz_expr* b = nullptr;
@@ -62,6 +64,8 @@ struct Node {
    uint32_t kind;   // fz_ir_kind
    uint32_t a = 0, b = 0;
    float value = 0.f;
+   bool f64 = false;   // the node's arithmetic type is double (a double literal is among its ancestors)
+   double value64 = 0.0;
 };
 
 struct Line {
@@ -78,6 +82,7 @@ struct Graph {
    std::vector<uint32_t> outputs;    // node ids
    std::vector<Line> lines;          // ordered by src
    std::vector<float> consts;        // uniform coefficient slots
+   std::vector<double> consts64;     // float64 literal terminals
    std::map<uint32_t, uint32_t> uniform_slot;   // fz_uniform id -> coefficient slot (never shared)
    uint32_t n_state = 0, max_delay = 0, n_ops = 0, n_lds_slots = 0;
    std::vector<int> line_of_node;    // node -> line index or -1

@@ -34,6 +34,8 @@ struct Raw {
    int a = -1, b = -1;
    float value = 0.f;
    uint32_t n = 0;
+   bool f64 = false;        // literal: C++ double; arithmetic: decided after the forward references resolve
+   double value64 = 0.0;
 };
 
 struct Elab {
@@ -41,7 +43,7 @@ struct Elab {
 
    int add(uint32_t kind, int a = -1, int b = -1, float value = 0.f, uint32_t n = 0)
    {
-      raw.push_back(Raw{kind, a, b, value, n});
+      raw.push_back(Raw{kind, a, b, value, n, false, 0.0});
       return (int)raw.size() - 1;
    }
 
@@ -68,7 +70,12 @@ struct Elab {
          case EK::Delayed:                                              // place_delay :950-958
             if (e->i > ins.size()) fail(FZ_E_GRAPH, "placeholder _" + std::to_string(e->i) + " has no wire to bind to");
             return {add(FZ_IR_DELAY, ins[e->i - 1], -1, 0.f, e->n)};
-         case EK::Literal: return {add(FZ_IR_CONST, -1, -1, e->value)};
+         case EK::Literal: {
+            int id = add(FZ_IR_CONST, -1, -1, e->value);
+            raw[(size_t)id].f64 = e->f64;
+            raw[(size_t)id].value64 = e->value64;
+            return {id};
+         }
          case EK::Uniform: return {add(FZ_IR_CONST, -1, -1, e->value, e->i + 1)};   // n = id + 1: own slot
          case EK::Param: return {add(FZ_IR_PARAM, -1, -1, 0.f, e->i)};
          case EK::Arith: {                                              // _default<eval_it> :769-772
@@ -131,6 +138,13 @@ uint32_t bits_of(float f)
 {
    uint32_t u;
    std::memcpy(&u, &f, 4);
+   return u;
+}
+
+uint64_t bits_of64(double f)
+{
+   uint64_t u;
+   std::memcpy(&u, &f, 8);
    return u;
 }
 
@@ -215,8 +229,31 @@ Graph lower(const fz_expr* e)
          if (live[i]) visit((int)i);
    }
 
+   // arithmetic types (C++ usual arithmetic conversions): double if any operand is double; wires
+   // read from delay lines, inputs and per-stream coefficients are float (state is float, flowz.hpp:1245)
+   for (int v : order) {
+      Raw& r = raw[(size_t)v];
+      switch (r.kind) {
+         case FZ_IR_ADD: case FZ_IR_SUB: case FZ_IR_MUL: case FZ_IR_DIV:
+            r.f64 = raw[(size_t)r.a].f64 || raw[(size_t)r.b].f64;
+            break;
+         case FZ_IR_NEG: r.f64 = raw[(size_t)r.a].f64; break;
+         case FZ_IR_CONST: break;
+         default: r.f64 = false; break;
+      }
+   }
+
    // uniform coefficient slots: one per distinct bit pattern
    Graph g;
+   std::map<uint64_t, uint32_t> const_slot64;
+   auto slot_of64 = [&](double v) {
+      auto it = const_slot64.find(bits_of64(v));
+      if (it != const_slot64.end()) return it->second;
+      uint32_t s = (uint32_t)g.consts64.size();
+      g.consts64.push_back(v);
+      const_slot64[bits_of64(v)] = s;
+      return s;
+   };
    std::map<uint32_t, uint32_t> const_slot;
    auto slot_of = [&](float v, uint32_t uid1) {
       if (uid1) {                                   // run-time uniform: one private slot per id
@@ -240,13 +277,16 @@ Graph lower(const fz_expr* e)
    for (size_t i = 0; i < N; ++i) rep[i] = (int)i;
    for (bool changed = true; changed;) {
       changed = false;
-      std::map<std::tuple<uint32_t, int, int, uint32_t>, int> seen;
+      std::map<std::tuple<uint32_t, int, int, uint64_t>, int> seen;
       for (int v : order) {
          const Raw& r = raw[(size_t)v];
-         std::tuple<uint32_t, int, int, uint32_t> key;
+         std::tuple<uint32_t, int, int, uint64_t> key;
          switch (r.kind) {
             case FZ_IR_INPUT: key = {r.kind, -1, -1, r.n}; break;
-            case FZ_IR_CONST: key = {r.kind, r.n ? (int)r.n : -1, -1, r.n ? 0u : bits_of(r.value)}; break;
+            case FZ_IR_CONST:
+               if (r.f64) key = {r.kind, -2, -1, bits_of64(r.value64)};
+               else key = {r.kind, r.n ? (int)r.n : -1, -1, r.n ? 0u : bits_of(r.value)};
+               break;
             case FZ_IR_PARAM: key = {r.kind, -1, -1, r.n}; break;
             case FZ_IR_DELAY: key = {r.kind, rep[(size_t)r.a], -1, r.n}; break;
             case FZ_IR_NEG: key = {r.kind, rep[(size_t)r.a], -1, 0}; break;
@@ -272,9 +312,13 @@ Graph lower(const fz_expr* e)
       const Raw& r = raw[(size_t)v];
       Node& n = g.nodes[(size_t)newid[(size_t)v]];
       n.kind = r.kind;
+      n.f64 = r.f64;
       switch (r.kind) {
          case FZ_IR_INPUT: n.a = r.n; break;
-         case FZ_IR_CONST: n.a = slot_of(r.value, r.n); n.value = r.value; break;
+         case FZ_IR_CONST:
+            if (r.f64) { n.a = slot_of64(r.value64); n.value64 = r.value64; n.value = r.value; }
+            else { n.a = slot_of(r.value, r.n); n.value = r.value; }
+            break;
          case FZ_IR_PARAM: n.a = r.n; g.n_param = std::max(g.n_param, r.n + 1); break;
          case FZ_IR_DELAY: n.a = nid(r.a); n.b = r.n; break;
          case FZ_IR_NEG: n.a = nid(r.a); ++g.n_ops; break;

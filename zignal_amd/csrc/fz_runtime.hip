@@ -242,13 +242,15 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    auto k = get_kernel(p, v, true);
 
    // kernarg image of `struct fz_args` (8-byte aligned: pad the coefficient tail)
-   std::vector<char> buf((sizeof(ArgsHeader) + sizeof(float) * std::max<size_t>(g.consts.size(), 1) + 7) & ~size_t(7));
+   const size_t off64 = (sizeof(ArgsHeader) + sizeof(float) * std::max<size_t>(g.consts.size(), 1) + 7) & ~size_t(7);
+   std::vector<char> buf(off64 + sizeof(double) * std::max<size_t>(g.consts64.size(), 1));
    ArgsHeader h{in, out, state, params, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
                 (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u};
    std::memcpy(buf.data(), &h, sizeof h);
    {
       std::lock_guard<std::mutex> lock(p->mu);
       if (!g.consts.empty()) std::memcpy(buf.data() + sizeof h, g.consts.data(), sizeof(float) * g.consts.size());
+      if (!g.consts64.empty()) std::memcpy(buf.data() + off64, g.consts64.data(), sizeof(double) * g.consts64.size());
    }
    size_t size = buf.size();
    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};

@@ -107,6 +107,12 @@ def lit(v: float) -> Expr:
     return Expr(C.lib.fz_literal(float(v)))
 
 
+def lit64(v: float) -> Expr:
+    """A C++ `double` literal terminal: the operators above it evaluate in float64 (usual arithmetic
+    conversions); delay lines and frames stay float32.  Plain Python numbers are float32 literals."""
+    return Expr(C.lib.fz_literal_f64(float(v)))
+
+
 def uniform(k: int, initial: float = 0.0) -> Expr:
     """Uniform run-time coefficient k (the std::ref(x) terminal): Program.set_uniform(k, v)."""
     return Expr(C.lib.fz_uniform(int(k), float(initial)))
@@ -155,6 +161,7 @@ def from_sexpr(e) -> Expr:
     if k == "in": return Placeholder(e[1])
     if k == "del": return Placeholder(e[1])[int(e[2])]
     if k == "lit": return lit(e[1])
+    if k == "lit64": return lit64(e[1])
     if k == "param": return param(e[1])
     if k == "uniform": return uniform(e[1], e[2])
     if k == "neg": return -from_sexpr(e[1])
@@ -201,7 +208,15 @@ class Program:
         n = C.check(C.lib.fz_program_ir(self._h, None, 0))
         buf = (C.IrNode * max(n, 1))()
         C.check(C.lib.fz_program_ir(self._h, buf, n))
-        return [(C.IR_KINDS[buf[i].kind], buf[i].a, buf[i].b, buf[i].value) for i in range(n)]
+        return [(C.IR_KINDS[buf[i].kind], buf[i].a, buf[i].b, buf[i].value64 if buf[i].dtype else buf[i].value)
+                for i in range(n)]
+
+    def ir_dtypes(self):
+        """per IR node: 'f32' or 'f64' (the node's C++ arithmetic type)"""
+        n = C.check(C.lib.fz_program_ir(self._h, None, 0))
+        buf = (C.IrNode * max(n, 1))()
+        C.check(C.lib.fz_program_ir(self._h, buf, n))
+        return ["f64" if buf[i].dtype else "f32" for i in range(n)]
 
     def outputs(self):
         buf = (ctypes.c_uint32 * max(self.n_out, 1))()
