@@ -130,7 +130,7 @@ struct fz_program {
 };
 
 namespace fz {
-Variant resolve_variant(const Graph& g, const fz_variant* v, uint64_t n_streams);
+Variant resolve_variant(const Graph& g, const fz_variant* v, uint64_t n_streams, uint32_t n_samples = 1u << 20);
 std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, bool need_load);
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params,
            uint64_t n_streams, uint32_t n_samples, const fz_variant* v, void* stream, uint32_t tile_streams = 0);

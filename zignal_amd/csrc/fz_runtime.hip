@@ -157,7 +157,7 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, bool need_lo
 // ---- variant selection ---------------------------------------------------------------------------------
 constexpr uint64_t kMaxLdsBytes = 160 * 1024;
 
-Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams)
+Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples)
 {
    Variant v;
    const uint32_t reqP = uv ? uv->streams_per_lane : 0, reqU = uv ? uv->unroll : 0, reqB = uv ? uv->block_threads : 0;
@@ -182,7 +182,10 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    if (v.flags & FZ_VF_STAGE_PACK) {
       if (!g.split.ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_STAGE_PACK: the graph is not two isomorphic halves in series");
       if (v.P != 1) fail(FZ_E_INVALID, "FZ_VF_STAGE_PACK needs streams_per_lane == 1");
-   } else if (!reqP && v.P == 1 && g.split.ok && !(v.flags & FZ_VF_NO_STAGE_PACK)) {
+   } else if (!reqP && v.P == 1 && g.split.ok && !(v.flags & FZ_VF_NO_STAGE_PACK) &&
+              n_samples >= 32u * (g.split.K - 1)) {
+      // automatic below 2^18 streams, unless the block is so short that the K-1 masked steps at
+      // either end would dominate
       v.flags |= FZ_VF_STAGE_PACK;
    }
    v.flags &= ~(uint32_t)FZ_VF_NO_STAGE_PACK;
@@ -230,7 +233,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    if (n_streams >= (1ull << 32)) fail(FZ_E_UNSUPPORTED, "more than 2^32 streams per launch: shard the streams");
    if (tile_streams && n_streams % tile_streams) fail(FZ_E_INVALID, "n_streams must be a multiple of tile_streams");
    require_device();
-   Variant v = resolve_variant(g, uv, n_streams);
+   Variant v = resolve_variant(g, uv, n_streams, n_samples);
    if (tile_streams) {
       // a workgroup must not straddle tiles: shrink the lane packing / block until it divides
       const bool fixedP = uv && uv->streams_per_lane, fixedB = uv && uv->block_threads;
