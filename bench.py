@@ -83,6 +83,7 @@ def main():
                     help="streams per frame tile (stream-tiled layout [tile][t][stream], the HBM-friendly "
                          "default); 0 = plain time-major [t][stream]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config2", action="store_true", help="skip the secondary 65 536-stream measurement")
     ap.add_argument("--time-major-too", action="store_true",
                     help="also time the same workload on plain time-major frames (secondary figure)")
     args = ap.parse_args()
@@ -168,6 +169,34 @@ def main():
         tm = {"avg_launch_ms": round(tm_ms, 4), "Msamples_per_s": round(ns * T / tm_ms / 1e3, 1)}
         del x2, y2, st2
 
+    # BASELINE config 2 (65 536 streams x 4096) in the same run, rank 0, N == 1: a different kernel
+    # variant (own symbol in the rocprof stats), 1 GiB of frames
+    cfg2 = None
+    if rank == 0 and world == 1 and not args.no_config2 and ns != 65536:
+        ns2 = 65536
+        t2 = tile if tile and ns2 % tile == 0 else 0
+        shp = (ns2 // t2, T, t2, 1) if t2 else (T, ns2, 1)
+        x2 = torch.empty(shp, dtype=torch.float32, device=dev)
+        y2 = torch.empty(shp, dtype=torch.float32, device=dev)
+        st2 = torch.zeros((prog.n_state, ns2), dtype=torch.float32, device=dev)
+        F.synth_fill(x2, SEED)
+        for _ in range(3):
+            prog.run_block(x2, state=st2, out=y2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(50):
+            prog.run_block(x2, state=st2, out=y2)
+        e1.record()
+        torch.cuda.synchronize()
+        ms2 = e0.elapsed_time(e1) / 50
+        b2 = ns2 * (4 * T * 2 + 8 * prog.n_state)
+        cfg2 = {"workload": f"6-stage DF1 cascade, {ns2} streams x {T}-sample block (BASELINE configs[1])",
+                "avg_launch_ms": round(ms2, 4), "Msamples_per_s": round(ns2 * T / ms2 / 1e3, 1),
+                "achieved_GBs": round(b2 / ms2 / 1e6, 1), "frac": round(b2 / ms2 / 1e6 / HBM_PEAK_GBS, 4),
+                "kernel": prog.kernel_name(None, ns2, T)}
+        del x2, y2, st2
+
     # copy-kernel yardstick (same bytes in + out), rank 0 only
     copy_gbs = None
     if rank == 0:
@@ -207,12 +236,14 @@ def main():
                                           "block_threads": args.block, "flags": args.flags}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "fz_block_kernel", "algorithmic_bytes_per_launch": b_alg,
+                         "kernel": prog.kernel_name(variant, ns, T), "algorithmic_bytes_per_launch": b_alg,
                          "avg_launch_ms": round(kern_avg_s * 1e3, 4),
                          "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None},
             "checksum": stats["checksum"],
         }
+        if cfg2 is not None:
+            line["config2_65536_streams"] = cfg2
         if tm is not None:
             tm["achieved_GBs"] = round(b_alg / (tm["avg_launch_ms"] / 1e3) / 1e9, 1)
             tm["frac"] = round(tm["achieved_GBs"] / HBM_PEAK_GBS, 4)

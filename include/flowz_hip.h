@@ -154,6 +154,10 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
 #define FZ_VF_MIN_WAVES(n) (((uint32_t)(n) & 15u) << 8)
 
 int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */
+/* symbol of the variant's kernel as profilers show it, e.g. "fz_block_kernel_p2u32b256f0"; the
+ * variant is resolved as fz_run_block would for (n_streams, n_samples); returns length          */
+long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples,
+                            char* buf, size_t cap);
 /* generated HIP source of a variant (skeleton + graph body); returns length, writes <= cap    */
 long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap);
 

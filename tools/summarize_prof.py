@@ -16,6 +16,7 @@ shutil.copy(os.path.join(base, "trace", "bench_kernel_stats.csv"), os.path.join(
 line = [l for l in open(os.path.join(base, "bench_trace.log")) if l.startswith("{")][-1]
 open(os.path.join(outdir, f"bench_line_under_rocprof_{tag}.json"), "w").write(line)
 bench = json.loads(line)
+KN = bench["roofline"]["kernel"]                 # symbol of the headline variant
 summ = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py   (PMC: separate runs with "
                    "--pmc <counters> only, bench.py --steps 3 --warmup 1 --no-cpu-baseline)",
         "workload": bench["config"]["workload"], "kernels": {}}
@@ -23,11 +24,11 @@ stats = {r["Name"].split("(")[0]: r for r in csv.DictReader(open(os.path.join(ba
 summ["kernel_trace"] = {k: {"calls": int(v["Calls"]), "avg_ms": float(v["AverageNs"]) / 1e6, "min_ms": float(v["MinNs"]) / 1e6,
                             "max_ms": float(v["MaxNs"]) / 1e6} for k, v in stats.items() if "fz" in k}
 # steady-state launches only (the trace CSV has every dispatch)
-tr = [r for r in csv.DictReader(open(os.path.join(base, "trace", "bench_kernel_trace.csv"))) if r["Kernel_Name"].startswith("fz_block_kernel")]
+tr = [r for r in csv.DictReader(open(os.path.join(base, "trace", "bench_kernel_trace.csv"))) if r["Kernel_Name"] == KN]
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr]
 steps = bench["steps"]
-summ["kernel_trace"]["fz_block_kernel"]["timed_region_avg_ms"] = sum(durs[-steps:]) / steps
-summ["kernel_trace"]["fz_block_kernel"]["bench_event_avg_ms"] = bench["roofline"]["avg_launch_ms"]
+summ["kernel_trace"][KN]["timed_region_avg_ms"] = sum(durs[-steps:]) / steps
+summ["kernel_trace"][KN]["bench_event_avg_ms"] = bench["roofline"]["avg_launch_ms"]
 for d in sorted(os.listdir(base)):
     f = os.path.join(base, d, "bench_counter_collection.csv")
     if not d.startswith("pmc_") or not os.path.exists(f):
@@ -44,7 +45,7 @@ for d in sorted(os.listdir(base)):
 for k in summ["kernels"].values():
     for c in k["counters"].values():
         c["mean"] = sum(c["per_launch"]) / len(c["per_launch"])
-blk = summ["kernels"]["fz_block_kernel"]["counters"]
+blk = summ["kernels"][KN]["counters"]
 cp = summ["kernels"]["fz::fz_copy_kernel"]["counters"]
 copy_bytes = bench["config"]["streams_per_gpu"] * bench["config"]["block_samples"] * 4
 b_alg = bench["roofline"]["algorithmic_bytes_per_launch"]
@@ -56,7 +57,7 @@ summ["hbm_traffic"] = {
               "FETCH_SIZE counts 1/2 of a coalesced streaming read -> x2; calibrated in the same runs on fz_copy_kernel "
               "(exactly %d bytes each way)" % copy_bytes,
     "calibration_copy_kernel": {"read_factor": round(rf, 4), "write_factor": round(wf, 4)},
-    "fz_block_kernel": {"FETCH_SIZE_KiB": blk["FETCH_SIZE"]["mean"], "WRITE_SIZE_KiB": blk["WRITE_SIZE"]["mean"],
+    KN: {"FETCH_SIZE_KiB": blk["FETCH_SIZE"]["mean"], "WRITE_SIZE_KiB": blk["WRITE_SIZE"]["mean"],
                         "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": b_alg,
                         "traffic_over_algorithmic": round(traffic / b_alg, 5)}}
 if "SQ_INSTS_VALU" in blk:

@@ -80,6 +80,7 @@ def _load():
         "fz_program_get_const": (ctypes.c_int, [P, u32, ctypes.POINTER(f32)]),
         "fz_program_set_const": (ctypes.c_int, [P, u32, f32]),
         "fz_program_build": (ctypes.c_int, [P, ctypes.POINTER(Variant)]),
+        "fz_program_kernel_name": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, ctypes.c_char_p, ctypes.c_size_t]),
         "fz_program_source": (ctypes.c_long, [P, ctypes.POINTER(Variant), ctypes.c_char_p, ctypes.c_size_t]),
         "fz_run_block": (ctypes.c_int, [P, P, P, P, P, u64, u32, ctypes.POINTER(Variant), P]),
         "fz_run_block_tiled": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, ctypes.POINTER(Variant), P]),

@@ -123,6 +123,23 @@ int fz_program_build(fz_program* p, const fz_variant* v)
       return FZ_OK;)
 }
 
+long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, char* buf, size_t cap)
+{
+   try {
+      if (!p) fail(FZ_E_INVALID, "null program");
+      const std::string s = kernel_name(p->g, resolve_variant(p->g, v, n_streams ? n_streams : (1ull << 20), n_samples ? n_samples : (1u << 20)));
+      if (buf && cap) {
+         const size_t n = std::min(cap - 1, s.size());
+         std::memcpy(buf, s.data(), n);
+         buf[n] = 0;
+      }
+      return (long)s.size();
+   } catch (const fz::Error& er) {
+      set_error(er.msg);
+      return er.code;
+   }
+}
+
 long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap)
 {
    try {

@@ -108,6 +108,7 @@ struct Variant {
    }
 };
 
+std::string kernel_name(const Graph& g, const Variant& v);
 std::string gen_config(const Graph& g, const Variant& v); // generated "fz_graph_config.h"
 std::string gen_body(const Graph& g, const Variant& v);   // generated "fz_graph_body.h"
 const char* skeleton_source();                            // hand-written kernel skeleton text

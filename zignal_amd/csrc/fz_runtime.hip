@@ -146,7 +146,7 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, bool need_lo
       hipModule_t mod;
       FZ_HIP(hipModuleLoadData(&mod, slot->code.data()));
       hipFunction_t fn;
-      FZ_HIP(hipModuleGetFunction(&fn, mod, "fz_block_kernel"));
+      FZ_HIP(hipModuleGetFunction(&fn, mod, kernel_name(p->g, v).c_str()));
       slot->module = mod;
       slot->function = fn;
       slot->loaded = true;

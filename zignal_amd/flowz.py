@@ -247,6 +247,13 @@ class Program:
         """Streams per frame tile that gives ~32 KiB row segments (see fz_run_block_tiled)."""
         return int(C.lib.fz_recommended_tile_streams(self._h))
 
+    def kernel_name(self, variant: Optional[Variant] = None, n_streams: int = 0, n_samples: int = 0) -> str:
+        """Symbol of the kernel that run_block would launch for this variant and size."""
+        vp = ctypes.byref(variant) if variant is not None else None
+        buf = ctypes.create_string_buffer(128)
+        C.check(C.lib.fz_program_kernel_name(self._h, vp, int(n_streams), int(n_samples), buf, 128))
+        return buf.value.decode()
+
     def source(self, variant: Optional[Variant] = None) -> str:
         vp = ctypes.byref(variant) if variant is not None else None
         n = C.check(C.lib.fz_program_source(self._h, vp, None, 0))
