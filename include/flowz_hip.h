@@ -223,6 +223,17 @@ int fz_device_count(void);                /* 0 when no GPU is visible           
  * time-major (tile_streams == 0) or stream-tiled as fz_run_block_tiled expects                */
 int fz_synth_fill(float* dst_dev, uint64_t n_streams, uint32_t n_samples, uint32_t n_wires,
                   uint32_t seed, uint64_t stream0, uint64_t t0, uint32_t tile_streams, void* hip_stream);
+/* Per-stream biquad coefficients on the device: the RBJ low-pass equations of the reference's
+ * reactive_equations/reactive_filter_coeff.cpp:38-58 with its parameter types (every PARAMETER is
+ * float, the literals `1.`, `2.` are double):
+ *     w0 = two_pi*freq/sr (float)   cosw0 = cos(w0)   alpha = sin(w0)/(2.*Q)
+ *     b0 = (1.-cosw0)/2.   b1 = 1.-cosw0   b2 = (1.-cosw0)/2.   a0 = 1.+alpha   a1 = -2.*cosw0   a2 = 1.-alpha
+ * sin/cos are evaluated in double and rounded to float (within 1 ULP of the reference's
+ * std::sin/std::cos on float).  raw6 [6][n_streams] receives a0 a1 a2 b0 b1 b2 (may be NULL);
+ * df1 [5][n_streams] receives the rows a Flowz DF1 stage with fz_stream_param coefficients reads,
+ * b0/a0 b1/a0 b2/a0 -a1/a0 -a2/a0 in float (may be NULL): pass a pointer into the `params` buffer. */
+int fz_rbj_lowpass(const float* freq_dev, const float* q_dev, float sample_rate, uint64_t n_streams,
+                   float* raw6_dev, float* df1_dev, void* hip_stream);
 /* plain float4 copy kernel: the measured-copy-bandwidth yardstick of the roofline report      */
 int fz_copy_probe(const float* src_dev, float* dst_dev, uint64_t n_floats, void* hip_stream);
 

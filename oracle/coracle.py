@@ -124,6 +124,20 @@ def mixed_precision_biquad(x, b=(0.05, -0.075, 0.275), a=(0.2, -0.8), stream_maj
     return _run("fzo_mixed_precision_biquad", pre, x, 1, 1, stream_major)
 
 
+def rbj_lowpass(freq, q, sr, libmf=False):
+    """-> (raw6 [6,n], df1 [5,n]); libmf=True: the reference's own float sinf/cosf spelling (raw6 only)."""
+    freq = np.ascontiguousarray(freq, F32)
+    q = np.ascontiguousarray(q, F32)
+    n = len(freq)
+    raw6 = np.empty((6, n), F32)
+    if libmf:
+        lib().fzo_rbj_lowpass_libmf(_p(freq), _p(q), ctypes.c_float(sr), ctypes.c_long(n), _p(raw6))
+        return raw6
+    df1 = np.empty((5, n), F32)
+    lib().fzo_rbj_lowpass(_p(freq), _p(q), ctypes.c_float(sr), ctypes.c_long(n), _p(raw6), _p(df1))
+    return raw6, df1
+
+
 def synth_fill(seed, stream0, n_streams, T, n_wires=1, t0=0, stream_major=False):
     out = np.empty((n_streams, T, n_wires) if stream_major else (T, n_streams, n_wires), F32)
     ss, ts = _strides(T, n_streams, n_wires, stream_major)

@@ -247,6 +247,50 @@ void fzo_mixed_precision_biquad(double b0, double b1, double b2, float a1, float
    }
 }
 
+/* ---- RBJ low-pass coefficients, reactive_equations/reactive_filter_coeff.cpp:38-58, with the
+ * reference's types: every PARAMETER is float, `1.` `2.` are double literals; std::cos/std::sin of a
+ * float.  sin/cos are taken in double and rounded to float, which is within 1 ULP of (and almost
+ * always equal to) the float libm result the reference gets.
+ * raw6: [6][n] a0 a1 a2 b0 b1 b2;  df1: [5][n] b0/a0 b1/a0 b2/a0 -a1/a0 -a2/a0 (either may be NULL) */
+#include <math.h>
+void fzo_rbj_lowpass(const float* freq, const float* q, float sr, long n, float* raw6, float* df1)
+{
+   const float two_pi = 8. * atan(1.);
+   for (long s = 0; s < n; ++s) {
+      const float w0 = two_pi * freq[s] / sr;
+      const float cosw0 = (float)cos((double)w0);
+      const float sinw0 = (float)sin((double)w0);
+      const float alpha = sinw0 / (2. * q[s]);
+      const float b0 = (1. - cosw0) / 2.;
+      const float b1 = 1. - cosw0;
+      const float b2 = (1. - cosw0) / 2.;
+      const float a0 = 1. + alpha;
+      const float a1 = -2. * cosw0;
+      const float a2 = 1. - alpha;
+      if (raw6) {
+         raw6[0 * n + s] = a0; raw6[1 * n + s] = a1; raw6[2 * n + s] = a2;
+         raw6[3 * n + s] = b0; raw6[4 * n + s] = b1; raw6[5 * n + s] = b2;
+      }
+      if (df1) {
+         df1[0 * n + s] = b0 / a0; df1[1 * n + s] = b1 / a0; df1[2 * n + s] = b2 / a0;
+         df1[3 * n + s] = -a1 / a0; df1[4 * n + s] = -a2 / a0;
+      }
+   }
+}
+
+/* the reference's own spelling, std::cos / std::sin on float (cosf / sinf), for the 1-ULP claim */
+void fzo_rbj_lowpass_libmf(const float* freq, const float* q, float sr, long n, float* raw6)
+{
+   const float two_pi = 8. * atan(1.);
+   for (long s = 0; s < n; ++s) {
+      const float w0 = two_pi * freq[s] / sr;
+      const float cosw0 = cosf(w0);
+      const float alpha = sinf(w0) / (2. * q[s]);
+      raw6[0 * n + s] = 1. + alpha; raw6[1 * n + s] = -2. * cosw0; raw6[2 * n + s] = 1. - alpha;
+      raw6[3 * n + s] = (1. - cosw0) / 2.; raw6[4 * n + s] = 1. - cosw0; raw6[5 * n + s] = (1. - cosw0) / 2.;
+   }
+}
+
 /* ---- synthetic input, identical to oracle/flowz_oracle.py: synth_input -------------- */
 static inline uint32_t fmix32(uint32_t h)
 {

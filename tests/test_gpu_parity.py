@@ -524,3 +524,33 @@ def test_one_program_many_states_concurrently(torch_cuda, F):
     [t.join() for t in th]
     for k in range(2):
         assert ndiff(outs[k], want[k]) == 0
+
+
+def test_rbj_lowpass_coefficient_generator_feeds_stream_params(torch_cuda, F):
+    """reactive_filter_coeff.cpp:38-58 on the device, written straight into the rows
+    of the per-stream `params` buffer that a DF1 stage with fz_stream_param coefficients reads."""
+    torch = torch_cuda
+    ns, T = 5000, 400
+    rng = np.random.default_rng(11)
+    freq = rng.uniform(30.0, 18000.0, ns).astype(np.float32)
+    q = rng.uniform(0.4, 9.0, ns).astype(np.float32)
+    raw6 = torch.empty((6, ns), device="cuda")
+    params = torch.empty((5, ns), device="cuda")
+    F.rbj_lowpass(torch.from_numpy(freq).cuda(), torch.from_numpy(q).cuda(), 44100.0, raw6=raw6, df1=params)
+    torch.cuda.synchronize()
+    want_raw, want_df1 = C.rbj_lowpass(freq, q, 44100.0)
+    got_raw, got_df1 = raw6.cpu().numpy(), params.cpu().numpy()
+    # coefficient parity: double sin/cos rounded to float on both sides -> equal except for rare
+    # double-rounding ties; tolerance as stated in the header: 1 ULP of 1.0
+    assert (np.abs(got_raw - want_raw) <= 2.0 ** -23).all()
+    assert (got_raw.view(np.uint32) == want_raw.view(np.uint32)).mean() > 0.999
+    assert (np.abs(got_df1 - want_df1) <= 2.0 ** -22).all()
+    # the filter itself, with the device-generated coefficients: bit-exact
+    g = G.df1_param(0)
+    prog = F.compile(F.from_sexpr(g))
+    assert prog.n_param == 5
+    x = O.synth_input(SEED + 4, np.arange(ns), T)
+    y, _ = prog.run_block(torch.from_numpy(x).cuda(), params=params)
+    want = O.compile(g, ns, params=got_df1).run(x)
+    assert ndiff(y.cpu().numpy(), want) == 0
+    assert np.isfinite(want).all() and np.abs(want).max() < 50.0      # low-pass: bounded response

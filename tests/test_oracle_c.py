@@ -96,3 +96,22 @@ def test_double_literals_follow_cpp_usual_arithmetic_conversions():
     assert same(C.mixed_precision_biquad(x), O.compile(G.mixed_precision_biquad(), NS).run(x))
     allf = ("fb", ("add", ("mul", G.lit(0.9), G.DEL(1, 1)), ("mul", G.lit(0.1), G.IN(2))))
     assert not same(O.compile(allf, NS).run(x), O.compile(G.one_pole_readme(0.9), NS).run(x))
+
+
+def test_rbj_lowpass_oracle_matches_reference_spelling_within_1ulp():
+    """reactive_filter_coeff.cpp:38-58: the oracle takes sin/cos in double and rounds to float; the
+    reference calls std::sin/std::cos on float.  Coefficients agree within 1 ULP (mostly exactly)."""
+    rng = np.random.default_rng(3)
+    freq = rng.uniform(20.0, 20000.0, 4096).astype(np.float32)
+    q = rng.uniform(0.3, 12.0, 4096).astype(np.float32)
+    raw6, df1 = C.rbj_lowpass(freq, q, 44100.0)
+    ref = C.rbj_lowpass(freq, q, 44100.0, libmf=True)
+    ulp = np.abs(raw6.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+    # cancellation in 1.-cosw0 / 1.-alpha can amplify a 1-ULP sin/cos difference: bound it relative to 1.0
+    assert (np.abs(raw6 - ref) <= 2.0 ** -23).all()
+    assert (ulp == 0).mean() > 0.9
+    # the reference's own demo point: sr 44100, freq 440, Q 1/sqrt(2)  (:38-40)
+    r, d = C.rbj_lowpass([440.0], [1.0 / np.sqrt(2.0)], 44100.0)
+    a0, a1, a2, b0, b1, b2 = (float(v) for v in r[:, 0])
+    assert abs(a0 - 1.0443) < 1e-3 and abs(a1 + 1.99607) < 1e-4 and abs(b1 - 2 * b0) < 1e-9 and b0 == b2
+    assert np.allclose(d[:, 0], [b0 / a0, b1 / a0, b2 / a0, -a1 / a0, -a2 / a0], rtol=1e-7)

@@ -96,6 +96,7 @@ def _load():
         "fz_bank_process_host": (ctypes.c_int, [P, P, P, u32]),
         "fz_device_count": (ctypes.c_int, []),
         "fz_synth_fill": (ctypes.c_int, [P, u64, u32, u32, u32, u64, u64, u32, P]),
+        "fz_rbj_lowpass": (ctypes.c_int, [P, P, f32, u64, P, P, P]),
         "fz_copy_probe": (ctypes.c_int, [P, P, u64, P]),
     }
     for name, (res, args) in sig.items():

@@ -270,6 +270,33 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
 // ---- AOT utility kernels ---------------------------------------------------------------------------------------
 typedef float fzr_f4 __attribute__((ext_vector_type(4)));
 
+// reactive_equations/reactive_filter_coeff.cpp:38-58, one stream per thread
+__global__ void __launch_bounds__(256) fz_rbj_lowpass_kernel(const float* __restrict__ freq, const float* __restrict__ q, float sr,
+                                                             unsigned long long n, float* raw6, float* df1)
+{
+   const unsigned long long s = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+   if (s >= n) return;
+   const float two_pi = (float)(8. * 0.78539816339744830962);     // const float two_pi = 8. * std::atan(1.)
+   const float w0 = two_pi * freq[s] / sr;
+   const float cosw0 = (float)cos((double)w0);                      // std::cos(float) to within 1 ULP
+   const float sinw0 = (float)sin((double)w0);
+   const float alpha = (float)(sinw0 / (2. * q[s]));
+   const float b0 = (float)((1. - cosw0) / 2.);
+   const float b1 = (float)(1. - cosw0);
+   const float b2 = (float)((1. - cosw0) / 2.);
+   const float a0 = (float)(1. + alpha);
+   const float a1 = (float)(-2. * cosw0);
+   const float a2 = (float)(1. - alpha);
+   if (raw6) {
+      raw6[0 * n + s] = a0; raw6[1 * n + s] = a1; raw6[2 * n + s] = a2;
+      raw6[3 * n + s] = b0; raw6[4 * n + s] = b1; raw6[5 * n + s] = b2;
+   }
+   if (df1) {
+      df1[0 * n + s] = b0 / a0; df1[1 * n + s] = b1 / a0; df1[2 * n + s] = b2 / a0;
+      df1[3 * n + s] = -a1 / a0; df1[4 * n + s] = -a2 / a0;
+   }
+}
+
 __device__ __forceinline__ unsigned fmix32(unsigned h)
 {
    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
@@ -353,6 +380,18 @@ int fz_synth_fill(float* dst, uint64_t n_streams, uint32_t n_samples, uint32_t n
       dim3 grid((unsigned)((row + 1023) / 1024), std::min<uint32_t>(n_samples, 64u));
       hipLaunchKernelGGL(fz_synth_fill_kernel, grid, dim3(256), 0, (hipStream_t)hip_stream, dst, row, n_wires, seed,
                          (unsigned long long)stream0, (unsigned long long)t0, n_samples, tile_floats);
+      FZ_HIP(hipGetLastError());
+      return FZ_OK;)
+}
+
+int fz_rbj_lowpass(const float* freq, const float* q, float sample_rate, uint64_t n_streams, float* raw6, float* df1,
+                   void* hip_stream)
+{
+   FZ_GUARD(
+      if (!freq || !q || !n_streams || (!raw6 && !df1)) fail(FZ_E_INVALID, "fz_rbj_lowpass: bad arguments");
+      require_device();
+      hipLaunchKernelGGL(fz_rbj_lowpass_kernel, dim3((unsigned)((n_streams + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                         freq, q, sample_rate, (unsigned long long)n_streams, raw6, df1);
       FZ_HIP(hipGetLastError());
       return FZ_OK;)
 }

@@ -353,6 +353,22 @@ def synth_fill(dst, seed: int, stream0: int = 0, t0: int = 0):
     return dst
 
 
+def rbj_lowpass(freq, q, sample_rate: float, raw6=None, df1=None):
+    """Per-stream RBJ low-pass coefficients on the device (reactive_filter_coeff.cpp:38-58).
+    freq, q: CUDA float32 [n]; raw6: [6, n] (a0 a1 a2 b0 b1 b2) and/or df1: [5, n] rows
+    (b0/a0 b1/a0 b2/a0 -a1/a0 -a2/a0), e.g. a slice of a `params` buffer."""
+    import torch
+
+    n = freq.numel()
+    assert freq.is_cuda and q.is_cuda and q.numel() == n and freq.dtype == q.dtype == torch.float32
+    for t, rows in ((raw6, 6), (df1, 5)):
+        assert t is None or (t.is_cuda and t.is_contiguous() and tuple(t.shape) == (rows, n))
+    C.check(C.lib.fz_rbj_lowpass(freq.data_ptr(), q.data_ptr(), float(sample_rate), n,
+                                 raw6.data_ptr() if raw6 is not None else None,
+                                 df1.data_ptr() if df1 is not None else None,
+                                 torch.cuda.current_stream().cuda_stream))
+
+
 def copy_probe(src, dst):
     import torch
 
