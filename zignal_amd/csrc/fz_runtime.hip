@@ -175,9 +175,16 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // (measured crossover on the 6-biquad cascade: 2^18 streams, profiles/r01/sweep_stream_counts.txt)
       v.P = (n_streams >= (1u << 18) && n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) ? 2 : 1;
    }
+   // deep graphs: keep the register-resident delay lines + prefetch buffers inside the 512-entry
+   // VGPR/AGPR file (measured: a 24-stage cascade needs ~300 VGPRs at 2 streams per lane)
+   uint32_t reg_state = 0;
+   for (const Line& l : g.lines)
+      if (!l.in_lds) reg_state += l.depth;
+   if (!reqP && v.P == 2 && reg_state > 36) v.P = 1;
    // prefetch depth in time steps: 16 rows in flight per lane; 32 once the chip is oversubscribed
    // with packed lanes (fewer, fatter waves: 2 per SIMD)
    v.U = reqU ? reqU : ((v.P == 2 && n_streams >= (1u << 19) && g.n_in == 1 && g.n_out == 1) ? 32 : 16);
+   if (!reqU && reg_state * v.P > 60) v.U = 8;
    // stage packing: one stream per lane, the two isomorphic halves of the graph in one v_pk_*
    if (v.flags & FZ_VF_STAGE_PACK) {
       if (!g.split.ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_STAGE_PACK: the graph is not two isomorphic halves in series");
