@@ -123,7 +123,10 @@ int fz_program_ir(const fz_program* p, fz_ir_node* nodes, uint32_t cap);
 /* node id of each output wire; writes min(n_out, cap), returns n_out */
 int fz_program_outputs(const fz_program* p, uint32_t* node_ids, uint32_t cap);
 /* delay lines: source node and depth of line l; state rows of line l start at the sum of the
- * depths before it, row (start + j) holds the wire's value at t-1-j (j = 0 newest).          */
+ * depths before it, row (start + j) holds the wire's value at t-1-j (j = 0 newest).
+ * Lines deeper than 256 samples are rings in HBM instead: their `depth` rows are ring slots, one
+ * extra state row per such line (after all line rows) holds the ring phase p (as a float), and the
+ * value at t-1-j sits in slot (p - 1 - j) mod depth.  n_state counts those phase rows.          */
 int fz_program_lines(const fz_program* p, uint32_t* src_nodes, uint32_t* depths, uint32_t cap);
 /* read / overwrite a uniform coefficient (literal terminal) between blocks */
 int fz_program_get_const(const fz_program* p, uint32_t slot, float* value);

@@ -554,3 +554,47 @@ def test_rbj_lowpass_coefficient_generator_feeds_stream_params(torch_cuda, F):
     want = O.compile(g, ns, params=got_df1).run(x)
     assert ndiff(y.cpu().numpy(), want) == 0
     assert np.isfinite(want).all() and np.abs(want).max() < 50.0      # low-pass: bounded response
+
+
+# ---- delays beyond LDS: rings in HBM (the line's state rows), prefetched like extra wires -----------------
+def far_graph():
+    """feed-forward comb _1[_1000] into a feedback comb reading its own output 777 and 2 samples back"""
+    return G.seq(G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 1000))),
+                 G.fb(G.add(G.add(G.mul(G.lit(0.6), G.DEL(1, 777)), G.mul(G.lit(0.1), G.DEL(1, 2))), G.IN(2))))
+
+
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_far_delays_hbm_rings_chained_blocks(torch_cuda, F, P):
+    g = far_graph()
+    prog = F.compile(F.from_sexpr(g))
+    assert prog.max_delay == 1000 and prog.n_lds_slots == 0 and prog.n_state == 1000 + 777 + 2
+    ns = 140
+    sizes = [5, 1, 300, 31, 1000, 777, 64, 16, 2000, 123]           # crosses both ring lengths several times
+    x = O.synth_input(SEED + 6, np.arange(ns), sum(sizes))
+    want = O.compile(g, ns).run(x)
+    st, pos, outs = None, 0, []
+    for k, n in enumerate(sizes):
+        y, st = run_gpu(torch_cuda, F, prog, x[pos:pos + n], state=st, variant=F.make_variant(P if k % 2 == 0 else 1, 16 if k % 3 else 8))
+        outs.append(y)
+        pos += n
+    assert ndiff(np.concatenate(outs), want) == 0
+    assert np.abs(want[-500:]).max() > 1e-3                            # the combs are alive at the end
+
+
+def test_far_delay_minimum_and_tiled_layout(torch_cuda, F):
+    """smallest far-read distance (32 samples = two prefetch chunks) on a 300-deep line, tiled frames"""
+    torch = torch_cuda
+    g = G.fb(G.add(G.add(G.mul(G.lit(0.4), G.DEL(1, 300)), G.mul(G.lit(-0.3), G.DEL(1, 32))), G.IN(2)))
+    prog = F.compile(F.from_sexpr(g))
+    ns, T = 2048, 700
+    x = O.synth_input(SEED + 7, np.arange(ns), T)
+    want = O.compile(g, ns).run(x)
+    xt = F.to_tiled(torch.from_numpy(x).cuda(), 512)
+    yt, _ = prog.run_block(xt, variant=F.make_variant(2, 16))
+    assert ndiff(F.from_tiled(yt).cpu().numpy(), want) == 0
+
+
+def test_far_delay_with_mid_range_reader_is_rejected(F):
+    with pytest.raises(F.FlowzError) as ei:
+        F.compile(F.from_sexpr(G.add(G.DEL(1, 500), G.DEL(1, 20))))
+    assert ei.value.code == -6

@@ -76,6 +76,8 @@ GRAPHS = {
     "long_delay": lambda: G.seq(G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 40))),
                                 G.fb(G.add(G.mul(G.lit(0.7), G.DEL(1, 23)), G.IN(2)))),
     "div_neg": lambda: ("div", ("neg", G.IN(1)), G.add(G.lit(2.5), G.mul(G.DEL(1, 1), G.DEL(1, 1)))),
+    "far_delays": lambda: G.seq(G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 400))),
+                                G.fb(G.add(G.add(G.mul(G.lit(0.6), G.DEL(1, 333)), G.mul(G.lit(0.1), G.DEL(1, 2))), G.IN(2)))),
     "one_pole_double_literal": G.one_pole_readme,                      # flowz/README.md:52
     "mixed_precision_biquad": G.mixed_precision_biquad,
     "double_div": lambda: ("div", G.add(G.IN(1), G.lit64(1.5)), G.add(G.lit64(3.0), G.mul(G.DEL(1, 1), G.DEL(1, 1)))),
@@ -86,7 +88,7 @@ GRAPHS = {
 def test_lowering_vs_oracle(name):
     g = GRAPHS[name]()
     p = F.compile(F.from_sexpr(g))
-    ns, T = 3, 96
+    ns, T = 3, (900 if name == "far_delays" else 96)
     assert p.n_in == O.input_arity(g) and p.n_out == O.output_arity(g)
     x = O.synth_input(11, np.arange(ns), T, n_wires=max(p.n_in, 1))
     want = O.compile(g, ns).run(x)

@@ -74,6 +74,17 @@ struct Line {
    uint32_t row0;    // first state row
    bool in_lds;      // ring buffer in LDS instead of registers
    uint32_t lds_slot0 = 0, lds_size = 0;   // ring placement (size is a power of two >= depth)
+   // FAR lines (depth > kLdsMaxDepth): the line's state rows ARE a ring buffer in HBM, written
+   // every sample and read `n` samples later through the prefetch path; one extra state row holds
+   // the ring phase.  Reads with n <= kRegMaxDepth use `shadow` register copies of the newest values.
+   bool far = false;
+   uint32_t phase_row = 0;
+   uint32_t shadow = 0;
+};
+
+struct FarRead {
+   uint32_t line;   // index into Graph::lines
+   uint32_t n;      // delay
 };
 
 struct Graph {
@@ -87,12 +98,16 @@ struct Graph {
    uint32_t n_state = 0, max_delay = 0, n_ops = 0, n_lds_slots = 0;
    std::vector<int> line_of_node;    // node -> line index or -1
    StageSplit split;                 // stage packing, when the graph allows it
+   std::vector<FarRead> far_reads;   // distinct (far line, delay) pairs, in first-use order
+   std::vector<uint32_t> far_lines;  // indices of far lines
 };
 
 StageSplit find_stage_split(const Graph& g);
 
 // register-resident delay lines up to this depth; deeper ones become LDS rings
 constexpr uint32_t kRegMaxDepth = 8;
+constexpr uint32_t kLdsMaxDepth = 256;   // deeper lines live in HBM (ring in the state buffer)
+constexpr uint32_t kFarMinDelay = 32;    // a far read must be at least two prefetch chunks (2 x 16 steps) old
 
 Graph lower(const fz_expr* e);   // throws Error
 std::vector<uint32_t> max_input_delays(const fz_expr* e);

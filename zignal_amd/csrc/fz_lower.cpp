@@ -340,7 +340,8 @@ Graph lower(const fz_expr* e)
       l.src = kv.first;
       l.depth = kv.second;
       l.row0 = row;
-      l.in_lds = l.depth > kRegMaxDepth;
+      l.far = l.depth > kLdsMaxDepth;
+      l.in_lds = l.depth > kRegMaxDepth && !l.far;
       if (l.in_lds) {
          uint32_t sz = 1;
          while (sz < l.depth) sz <<= 1;
@@ -352,6 +353,25 @@ Graph lower(const fz_expr* e)
       g.max_delay = std::max(g.max_delay, l.depth);
       g.line_of_node[l.src] = (int)g.lines.size();
       g.lines.push_back(l);
+   }
+   // far lines: classify their readers, add one phase row per line
+   for (size_t li = 0; li < g.lines.size(); ++li) {
+      Line& l = g.lines[li];
+      if (!l.far) continue;
+      g.far_lines.push_back((uint32_t)li);
+      l.phase_row = row++;
+      for (const Node& n : g.nodes) {
+         if (n.kind != FZ_IR_DELAY || n.a != l.src) continue;
+         if (n.b <= kRegMaxDepth) l.shadow = std::max(l.shadow, n.b);
+         else if (n.b < kFarMinDelay)
+            fail(FZ_E_UNSUPPORTED, "a wire delayed by more than " + std::to_string(kLdsMaxDepth) + " samples cannot also be read with a delay of 9.." +
+                                      std::to_string(kFarMinDelay - 1) + " (node " + std::to_string(l.src) + ")");
+         else {
+            bool seen = false;
+            for (const FarRead& fr : g.far_reads) seen = seen || (fr.line == li && fr.n == n.b);
+            if (!seen) g.far_reads.push_back(FarRead{(uint32_t)li, n.b});
+         }
+      }
    }
    g.n_state = row;
    g.n_lds_slots = lds;

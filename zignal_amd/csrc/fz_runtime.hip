@@ -185,6 +185,12 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    // with packed lanes (fewer, fatter waves: 2 per SIMD)
    v.U = reqU ? reqU : ((v.P == 2 && n_streams >= (1u << 19) && g.n_in == 1 && g.n_out == 1) ? 32 : 16);
    if (!reqU && reg_state * v.P > 60) v.U = 8;
+   if (!g.far_lines.empty()) {
+      // far (HBM ring) reads are prefetched one chunk ahead: the chunk must be shorter than half the
+      // smallest far delay (kFarMinDelay = 32)
+      if (reqU > 16) fail(FZ_E_INVALID, "graphs with delays beyond LDS need unroll <= 16");
+      v.U = std::min(v.U, 16u);
+   }
    // stage packing: one stream per lane, the two isomorphic halves of the graph in one v_pk_*
    if (v.flags & FZ_VF_STAGE_PACK) {
       if (!g.split.ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_STAGE_PACK: the graph is not two isomorphic halves in series");

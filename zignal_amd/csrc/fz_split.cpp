@@ -90,7 +90,7 @@ struct Matcher {
 StageSplit find_stage_split(const Graph& g)
 {
    StageSplit none;
-   if (g.n_in != 1 || g.n_out != 1 || g.n_lds_slots != 0 || g.n_ops < 2) return none;
+   if (g.n_in != 1 || g.n_out != 1 || g.n_lds_slots != 0 || !g.far_lines.empty() || g.n_ops < 2) return none;
    for (const Node& n : g.nodes)
       if (n.f64) return none;                              // packed halves are float32 pairs
    const uint32_t N = (uint32_t)g.nodes.size();
