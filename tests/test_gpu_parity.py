@@ -598,3 +598,20 @@ def test_far_delay_with_mid_range_reader_is_rejected(F):
     with pytest.raises(F.FlowzError) as ei:
         F.compile(F.from_sexpr(G.add(G.DEL(1, 500), G.DEL(1, 20))))
     assert ei.value.code == -6
+
+
+def test_large_graph_64_stages_320_coefficients(torch_cuda, F):
+    """a 64-stage cascade with distinct coefficients: 576 ops per sample, 320 uniform coefficients in
+    the kernarg segment, 130 state floats; plain, stage-packed (8 segments of 8 stages) and 2/lane."""
+    rng = np.random.default_rng(0)
+    coefs = [G.stable_biquad(rng.uniform(0.5, 0.9), rng.uniform(0.2, 2.8),
+                             (rng.uniform(0.1, 0.3), rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2))) for _ in range(64)]
+    prog = F.compile(F.from_sexpr(G.df1_cascade(64, coefs)))
+    assert (prog.n_ops, prog.n_const, prog.n_state, prog.stage_packable) == (576, 320, 130, 1)
+    ns, T = 130, 150
+    x = O.synth_input(SEED + 8, np.arange(ns), T)
+    want = C.df1_cascade(coefs, x)
+    for v in (F.make_variant(1, 8, 256, NO_STAGE_PACK), F.make_variant(1, 8, 256, STAGE_PACK), F.make_variant(2, 4)):
+        got, _ = run_gpu(torch_cuda, F, prog, x, variant=v)
+        assert ndiff(got, want) == 0
+    assert np.isfinite(want).all()
