@@ -84,6 +84,8 @@ def main():
                          "default); 0 = plain time-major [t][stream]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config2", action="store_true", help="skip the secondary 65 536-stream measurement")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="do not try the alternative kernel variants during warm-up (the pool's boxes differ by a few %%)")
     ap.add_argument("--time-major-too", action="store_true",
                     help="also time the same workload on plain time-major frames (secondary figure)")
     args = ap.parse_args()
@@ -119,6 +121,27 @@ def main():
     state = torch.zeros((prog.n_state, ns), dtype=torch.float32, device=dev)
     F.synth_fill(x, SEED, stream0=begin)
     torch.cuda.synchronize()
+
+    # plan selection (warm-up, untimed): when no variant is forced, time the library default against two
+    # close alternatives for two launches each and keep the fastest on THIS box
+    tuned = None
+    if not args.no_autotune and not (args.lanes or args.unroll or args.block or args.flags) and ns >= (1 << 18):
+        cands = [F.make_variant(0, 0), F.make_variant(2, 16), F.make_variant(4, 8)]
+        best = None
+        for cv in cands:
+            prog.run_block(x, state=state, out=y, variant=cv)          # first touch / code load
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(2):
+                prog.run_block(x, state=state, out=y, variant=cv)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 2
+            if best is None or ms < best[0]:
+                best = (ms, cv)
+        variant = best[1]
+        tuned = prog.kernel_name(variant, ns, T)
+        state.zero_()
 
     # first block from zero state: kept for the parity check
     prog.run_block(x, state=state, out=y, variant=variant)
@@ -233,7 +256,8 @@ def main():
                        "streams_per_gpu": ns, "block_samples": T, "streams_total": ns * world,
                        "parallelism": f"stream-sharded x{world}, no data-path collective",
                        "kernel_variant": {"streams_per_lane": args.lanes, "unroll": args.unroll,
-                                          "block_threads": args.block, "flags": args.flags}},
+                                          "block_threads": args.block, "flags": args.flags,
+                                          "autotuned": tuned}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": prog.kernel_name(variant, ns, T), "algorithmic_bytes_per_launch": b_alg,
