@@ -45,7 +45,9 @@ for d in sorted(os.listdir(base)):
 for k in summ["kernels"].values():
     for c in k["counters"].values():
         c["mean"] = sum(c["per_launch"]) / len(c["per_launch"])
-blk = summ["kernels"][KN]["counters"]
+PK = KN if KN in summ["kernels"] else sorted(k for k in summ["kernels"] if k.startswith("fz_block_kernel_p"))[0]
+summ["pmc_kernel"] = PK   # variant the PMC passes ran (plan selection off: the library default)
+blk = summ["kernels"][PK]["counters"]
 cp = summ["kernels"]["fz::fz_copy_kernel"]["counters"]
 copy_bytes = bench["config"]["streams_per_gpu"] * bench["config"]["block_samples"] * 4
 b_alg = bench["roofline"]["algorithmic_bytes_per_launch"]
@@ -57,7 +59,7 @@ summ["hbm_traffic"] = {
               "FETCH_SIZE counts 1/2 of a coalesced streaming read -> x2; calibrated in the same runs on fz_copy_kernel "
               "(exactly %d bytes each way)" % copy_bytes,
     "calibration_copy_kernel": {"read_factor": round(rf, 4), "write_factor": round(wf, 4)},
-    KN: {"FETCH_SIZE_KiB": blk["FETCH_SIZE"]["mean"], "WRITE_SIZE_KiB": blk["WRITE_SIZE"]["mean"],
+    PK: {"FETCH_SIZE_KiB": blk["FETCH_SIZE"]["mean"], "WRITE_SIZE_KiB": blk["WRITE_SIZE"]["mean"],
                         "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": b_alg,
                         "traffic_over_algorithmic": round(traffic / b_alg, 5)}}
 if "SQ_INSTS_VALU" in blk:
