@@ -135,6 +135,7 @@ struct Kernel {
    void* function = nullptr;   // hipFunction_t
    std::vector<char> code;     // code object
    bool loaded = false;
+   ~Kernel();                  // unloads the module (fz_runtime.hip)
 };
 
 }  // namespace fz

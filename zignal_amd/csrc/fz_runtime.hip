@@ -42,6 +42,11 @@ static void require_device()
                            "(there is no CPU fallback in the product path)");
 }
 
+Kernel::~Kernel()
+{
+   if (loaded && module) (void)hipModuleUnload((hipModule_t)module);
+}
+
 // ---- kernel cache -----------------------------------------------------------------------------------
 static std::vector<const char*> build_options(const Variant& v)
 {
