@@ -44,7 +44,10 @@ static void require_device()
 
 Kernel::~Kernel()
 {
-   if (loaded && module) (void)hipModuleUnload((hipModule_t)module);
+   if (loaded && module) {
+      (void)hipDeviceSynchronize();          // launches are asynchronous: never unload code that may still run
+      (void)hipModuleUnload((hipModule_t)module);
+   }
 }
 
 // ---- kernel cache -----------------------------------------------------------------------------------
