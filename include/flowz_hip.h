@@ -148,10 +148,10 @@ typedef struct fz_variant {
 enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores                   */
        FZ_VF_NO_XCD_REMAP = 2u, /* plain blockIdx order instead of one contiguous stream range per XCD */
        FZ_VF_SLP = 4u,          /* let the compiler's SLP vectoriser pair scalar ops (off by default) */
-       FZ_VF_STAGE_PACK = 8u,   /* one stream per lane, but pack the two isomorphic halves of a serial
-                                   graph (e.g. stages 1-3 | 4-6 of a cascade) into v_pk_* with the
-                                   second half running one sample behind; chosen automatically for
-                                   small stream counts when fz_info.stage_packable                  */
+       FZ_VF_STAGE_PACK = 8u,   /* one stream per lane; the K isomorphic segments of a serial graph (e.g. the
+                                   stages of a cascade, after an optional scalar prefix) run skewed in time,
+                                   segment j at t-j, and segments i, i+K/2 share one v_pk_* per node; chosen
+                                   automatically below 2^18 streams when fz_info.stage_packable          */
        FZ_VF_NO_STAGE_PACK = 16u };
 /* bits 8..11 of flags: minimum waves per SIMD requested from the register allocator (0 = none) */
 #define FZ_VF_MIN_WAVES(n) (((uint32_t)(n) & 15u) << 8)

@@ -199,9 +199,9 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       if (reqU > 16) fail(FZ_E_INVALID, "graphs with delays beyond LDS need unroll <= 16");
       v.U = std::min(v.U, 16u);
    }
-   // stage packing: one stream per lane, the two isomorphic halves of the graph in one v_pk_*
+   // stage packing: one stream per lane, pairs of isomorphic graph segments in one v_pk_* (fz_split.cpp)
    if (v.flags & FZ_VF_STAGE_PACK) {
-      if (!g.split.ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_STAGE_PACK: the graph is not two isomorphic halves in series");
+      if (!g.split.ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_STAGE_PACK: the graph is not a series of isomorphic segments");
       if (v.P != 1) fail(FZ_E_INVALID, "FZ_VF_STAGE_PACK needs streams_per_lane == 1");
    } else if (!reqP && v.P == 1 && g.split.ok && !(v.flags & FZ_VF_NO_STAGE_PACK) &&
               n_samples >= 32u * (g.split.K - 1)) {
