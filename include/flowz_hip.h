@@ -122,6 +122,10 @@ typedef struct fz_ir_node {
 int fz_program_ir(const fz_program* p, fz_ir_node* nodes, uint32_t cap);
 /* node id of each output wire; writes min(n_out, cap), returns n_out */
 int fz_program_outputs(const fz_program* p, uint32_t* node_ids, uint32_t cap);
+/* arithmetic type of each output wire before it is narrowed to the float32 frame: 0 = float, 1 = double
+ * (the ResultType inference of flowz.hpp:585-644 / test/tests.cpp:200-231, with compile()'s float delay
+ * lines: a delayed read is float whatever was pushed, flowz.hpp:1245); writes min(n_out, cap), returns n_out */
+int fz_program_output_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap);
 /* delay lines: source node and depth of line l; state rows of line l start at the sum of the
  * depths before it, row (start + j) holds the wire's value at t-1-j (j = 0 newest).
  * Lines deeper than 256 samples are rings in HBM instead: their `depth` rows are ring slots, one

@@ -312,6 +312,20 @@ class FlowzOracle:
         return y
 
 
+def output_dtypes(expr):
+    """Arithmetic type of every output wire as the evaluator produces it: 'f32' or 'f64'.
+    Built-in operators promote by the usual arithmetic conversions (flowz.hpp:769-772; the cases of
+    test/tests.cpp:200-231 without delays); a delayed read is float because compile() builds float
+    delay lines (flowz.hpp:1245) -- the unused ResultType transform (:585-644) would keep the pushed type."""
+    f = FlowzOracle(expr, 1)
+    zeros = [np.zeros(1, F32)] * f.n_in
+    f._t += 1
+    for i, x in enumerate(zeros):
+        f._cur_in[i] = x
+    with np.errstate(all="ignore"):
+        return ["f64" if np.asarray(f._value(w)).dtype == np.float64 else "f32" for w in f._outs]
+
+
 def compile(expr, n_streams: int = 1, params=None) -> FlowzOracle:  # noqa: A001 (mirrors flowz::compile)
     return FlowzOracle(expr, n_streams, params)
 

@@ -202,3 +202,9 @@ def test_stage_split_detection_and_packed_kernel_builds(tmp_path, monkeypatch):
     F.compile(F.from_sexpr(G.osc_chain(6))).build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))   # scalar prefix + 6 segments
     with pytest.raises(F.FlowzError):
         F.compile(F.from_sexpr(G.df1())).build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))
+
+
+@pytest.mark.parametrize("case", KA["result_types"], ids=lambda c: "tests.cpp:" + c["lines"])
+def test_output_dtypes_match_tests_cpp_result_types(case):
+    p = F.compile(F.from_sexpr(tup(case["graph"])))
+    assert p.output_dtypes() == case["types"]

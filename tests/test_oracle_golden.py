@@ -104,3 +104,9 @@ def test_synth_input_range_and_determinism():
     assert x.dtype == np.float32 and x.min() >= -1.0 and x.max() < 1.0
     assert np.array_equal(x, O.synth_input(20160512, np.arange(5), 1000))
     assert np.array_equal(x[10:20], O.synth_input(20160512, np.arange(5), 10, t0=10))
+
+
+@pytest.mark.parametrize("case", KA["result_types"], ids=lambda c: "tests.cpp:" + c["lines"])
+def test_result_types_float_double(case):
+    """test_result_type_transform (tests.cpp:184-232), float/double cases: the oracle's evaluated types"""
+    assert O.output_dtypes(tup(case["graph"])) == case["types"]

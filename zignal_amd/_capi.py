@@ -76,6 +76,7 @@ def _load():
         "fz_program_info": (ctypes.c_int, [P, ctypes.POINTER(Info)]),
         "fz_program_ir": (ctypes.c_int, [P, ctypes.POINTER(IrNode), u32]),
         "fz_program_outputs": (ctypes.c_int, [P, ctypes.POINTER(u32), u32]),
+        "fz_program_output_dtypes": (ctypes.c_int, [P, ctypes.POINTER(u32), u32]),
         "fz_program_lines": (ctypes.c_int, [P, ctypes.POINTER(u32), ctypes.POINTER(u32), u32]),
         "fz_program_get_const": (ctypes.c_int, [P, u32, ctypes.POINTER(f32)]),
         "fz_program_set_const": (ctypes.c_int, [P, u32, f32]),

@@ -74,6 +74,13 @@ int fz_program_outputs(const fz_program* p, uint32_t* ids, uint32_t cap)
    return (int)p->g.outputs.size();
 }
 
+int fz_program_output_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap)
+{
+   if (!p) { set_error("null program"); return FZ_E_INVALID; }
+   for (size_t k = 0; k < p->g.outputs.size() && k < cap; ++k) dtypes[k] = p->g.nodes[p->g.outputs[k]].f64 ? 1u : 0u;
+   return (int)p->g.outputs.size();
+}
+
 int fz_program_lines(const fz_program* p, uint32_t* src, uint32_t* depth, uint32_t cap)
 {
    if (!p) { set_error("null program"); return FZ_E_INVALID; }

@@ -223,6 +223,12 @@ class Program:
         C.check(C.lib.fz_program_outputs(self._h, buf, self.n_out))
         return [buf[i] for i in range(self.n_out)]
 
+    def output_dtypes(self):
+        """'f32' / 'f64' per output wire: its C++ arithmetic type before narrowing to the float32 frame."""
+        buf = (ctypes.c_uint32 * max(self.n_out, 1))()
+        C.check(C.lib.fz_program_output_dtypes(self._h, buf, self.n_out))
+        return ["f64" if buf[i] else "f32" for i in range(self.n_out)]
+
     def lines(self):
         n = self.n_lines
         s, d = (ctypes.c_uint32 * max(n, 1))(), (ctypes.c_uint32 * max(n, 1))()
