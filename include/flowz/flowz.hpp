@@ -248,20 +248,22 @@ struct program_deleter {
 };
 using program_ptr = std::shared_ptr<fz_program>;
 
-template <class Tuple, size_t... K>
-Tuple to_tuple(const float* v, std::index_sequence<K...>)
+template <class Tuple, class T, size_t... K>
+Tuple to_tuple(const T* v, std::index_sequence<K...>)
 {
    return Tuple(v[K]...);
 }
 
-template <int N, class = std::make_index_sequence<N>>
-struct float_tuple;
-template <int N, size_t... K>
-struct float_tuple<N, std::index_sequence<K...>> {
+template <class T, int N, class = std::make_index_sequence<N>>
+struct value_tuple;
+template <class T, int N, size_t... K>
+struct value_tuple<T, N, std::index_sequence<K...>> {
    template <size_t>
-   using f = float;
+   using f = T;
    using type = std::tuple<f<K>...>;
 };
+template <int N>
+using float_tuple = value_tuple<float, N>;
 
 }  // namespace detail
 
@@ -327,6 +329,12 @@ public:
       refresh_refs();
       detail::check(fz_bank_process_host(bank_, in_host, out_host, n_samples));
    }
+   // float64 result frames: double sub-expression results leave un-narrowed, float wires widen exactly
+   void process_host(const float* in_host, double* out_host, uint32_t n_samples)
+   {
+      refresh_refs();
+      detail::check(fz_bank_process_host_f64(bank_, in_host, out_host, n_samples));
+   }
 };
 
 // compile() result: the reference's stateful_lambda (flowz.hpp:1181-1230).
@@ -343,14 +351,21 @@ class stateful_lambda {
    }
 
    using result_t = typename detail::float_tuple<Out>::type;
+   using result_f64_t = typename detail::value_tuple<double, Out>::type;
+
+   template <class T, class... Args>
+   typename detail::value_tuple<T, Out>::type call_as(const Args&... args)
+   {
+      const float in[In > 0 ? In : 1] = {static_cast<float>(args)...};
+      T out[Out];
+      own().process_host(In > 0 ? in : nullptr, out, 1);
+      return detail::to_tuple<typename detail::value_tuple<T, Out>::type>(out, std::make_index_sequence<Out>{});
+   }
 
    template <class... Args>
    result_t call(std::integral_constant<int, 0>, const Args&... args)
    {
-      const float in[In > 0 ? In : 1] = {static_cast<float>(args)...};
-      float out[Out];
-      own().process_host(In > 0 ? in : nullptr, out, 1);
-      return detail::to_tuple<result_t>(out, std::make_index_sequence<Out>{});
+      return call_as<float>(args...);
    }
 
    template <int Missing, class... Args>
@@ -384,6 +399,15 @@ public:
    auto operator()(const Args&... args)
    {
       return call(std::integral_constant<int, In - static_cast<int>(sizeof...(Args))>{}, args...);
+   }
+
+   // one sample with the results as doubles: what the reference's closure returns for graphs with
+   // double literals (tuple<double>, test/tests.cpp:201-231); float wires widen exactly.  The wire
+   // types themselves are run-time here: fz_program_output_dtypes()
+   template <class... Args, class = typename std::enable_if<(sizeof...(Args) == In)>::type>
+   result_f64_t call_f64(const Args&... args)
+   {
+      return call_as<double>(args...);
    }
 
    // the block API: n_streams independent closures with zeroed state in HBM

@@ -156,7 +156,10 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
                                    stages of a cascade, after an optional scalar prefix) run skewed in time,
                                    segment j at t-j, and segments i, i+K/2 share one v_pk_* per node; chosen
                                    automatically below 2^18 streams when fz_info.stage_packable          */
-       FZ_VF_NO_STAGE_PACK = 16u };
+       FZ_VF_NO_STAGE_PACK = 16u,
+       FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
+                                   float*): the results of graphs with double literals leave un-narrowed, float
+                                   wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */
 /* bits 8..11 of flags: minimum waves per SIMD requested from the register allocator (0 = none) */
 #define FZ_VF_MIN_WAVES(n) (((uint32_t)(n) & 15u) << 8)
 
@@ -221,6 +224,9 @@ int  fz_bank_process(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n
 int  fz_bank_process_tiled(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples,
                            uint32_t tile_streams, const fz_variant* v, void* hip_stream);
 int  fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint32_t n_samples);
+/* the same with float64 result frames (FZ_VF_OUT_F64): what a closure with double literals returns
+ * in the reference (tuple<double>, flowz.hpp:1225-1229 with the ResultType of test/tests.cpp:201) */
+int  fz_bank_process_host_f64(fz_bank* b, const float* in_host, double* out_host, uint32_t n_samples);
 
 /* ------------------------------------------------------------------------------------------
  * Device utilities used by the measurement harness (bench.py) and tests.

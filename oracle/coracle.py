@@ -66,9 +66,9 @@ def _coefs(cs):
     return arr
 
 
-def _run(fname, pre_args, x, n_in, n_out, stream_major):
+def _run(fname, pre_args, x, n_in, n_out, stream_major, out_dtype=F32):
     x, T, ns = _prep(x, n_in, stream_major)
-    y = np.empty((ns, T, n_out) if stream_major else (T, ns, n_out), F32)
+    y = np.empty((ns, T, n_out) if stream_major else (T, ns, n_out), out_dtype)
     xss, xts = _strides(T, ns, n_in, stream_major)
     yss, yts = _strides(T, ns, n_out, stream_major)
     getattr(lib(), fname)(*pre_args, _p(x), _pd(xss), _pd(xts), _p(y), _pd(yss), _pd(yts),
@@ -115,12 +115,16 @@ def osc_chain(params, x, n_stage=6, stream_major=False):
     return _run("fzo_osc_chain", (_p(params), _pd(params.shape[1]), ctypes.c_int(n_stage)), x, 1, 1, stream_major)
 
 
-def one_pole_readme(a, x, stream_major=False):
+def one_pole_readme(a, x, stream_major=False, out_f64=False):
+    if out_f64:
+        return _run("fzo_one_pole_readme_f64out", (ctypes.c_float(float(F32(a))),), x, 1, 1, stream_major, np.float64)
     return _run("fzo_one_pole_readme", (ctypes.c_float(float(F32(a))),), x, 1, 1, stream_major)
 
 
-def mixed_precision_biquad(x, b=(0.05, -0.075, 0.275), a=(0.2, -0.8), stream_major=False):
+def mixed_precision_biquad(x, b=(0.05, -0.075, 0.275), a=(0.2, -0.8), stream_major=False, out_f64=False):
     pre = tuple(ctypes.c_double(float(v)) for v in b) + tuple(ctypes.c_float(float(F32(v))) for v in a)
+    if out_f64:
+        return _run("fzo_mixed_precision_biquad_f64out", pre, x, 1, 1, stream_major, np.float64)
     return _run("fzo_mixed_precision_biquad", pre, x, 1, 1, stream_major)
 
 

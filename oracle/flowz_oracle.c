@@ -227,6 +227,21 @@ void fzo_one_pole_readme(float a, const float* x, ptrdiff_t xss, ptrdiff_t xts,
    }
 }
 
+/* the same closure, results handed out as the C++ type of the output wire (double: tuple<double> of
+ * tests.cpp:222,229): what the FZ_VF_OUT_F64 frames hold                                           */
+void fzo_one_pole_readme_f64out(float a, const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                                double* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      float y1 = 0.f;
+      for (long t = 0; t < T; ++t) {
+         double o = a * y1 + 0.1 * x[s * xss + t * xts];
+         y1 = (float)o;
+         y[s * yss + t * yts] = o;
+      }
+   }
+}
+
 /* ---- DF1 whose feed-forward coefficients are double literals: f in double, feedback products in
  * float, y = (f + (double)(a1*y1)) + (double)(a2*y2) in double, truncated to float for the delay
  * line and the frame (tests/graphs.py: mixed_precision_biquad)                                   */
@@ -243,6 +258,23 @@ void fzo_mixed_precision_biquad(double b0, double b1, double b2, float a1, float
          x2 = x1; x1 = x0;
          y2 = y1; y1 = (float)o;
          y[s * yss + t * yts] = (float)o;
+      }
+   }
+}
+
+void fzo_mixed_precision_biquad_f64out(double b0, double b1, double b2, float a1, float a2,
+                                       const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                                       double* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      float x1 = 0.f, x2 = 0.f, y1 = 0.f, y2 = 0.f;
+      for (long t = 0; t < T; ++t) {
+         float x0 = x[s * xss + t * xts];
+         double f = (b0 * x0 + b1 * x1) + b2 * x2;
+         double o = (f + a1 * y1) + a2 * y2;
+         x2 = x1; x1 = x0;
+         y2 = y1; y1 = (float)o;
+         y[s * yss + t * yts] = o;
       }
    }
 }

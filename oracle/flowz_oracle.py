@@ -160,8 +160,9 @@ class FlowzOracle:
 
     step(*inputs) == one call of stateful_lambda::operator() per stream (flowz.hpp:1225)."""
 
-    def __init__(self, expr, n_streams: int = 1, params=None):
+    def __init__(self, expr, n_streams: int = 1, params=None, out_f64: bool = False):
         self.expr = expr
+        self.out_dtype = np.float64 if out_f64 else F32      # float64: outputs leave un-narrowed
         self.n_streams = int(n_streams)
         self.n_in = input_arity(expr)
         self.n_out = output_arity(expr)
@@ -289,7 +290,7 @@ class FlowzOracle:
         for i, x in enumerate(inputs):
             self._cur_in[i] = np.ascontiguousarray(
                 np.broadcast_to(np.asarray(x, dtype=F32), (self.n_streams,)))
-        outs = [np.array(self._value(w), dtype=F32, copy=True) for w in self._outs]
+        outs = [np.array(self._value(w), dtype=self.out_dtype, copy=True) for w in self._outs]
         # consumers first, pushes last (:994, :1067)
         new = [np.array(self._value(w), dtype=F32, copy=True) for w in self._delayed]
         for w, v in zip(self._delayed, new):
@@ -303,7 +304,7 @@ class FlowzOracle:
         if x.ndim == 2 and self.n_in == 1:
             x = x[:, :, None]
         T = x.shape[0]
-        y = np.empty((T, self.n_streams, self.n_out), F32)
+        y = np.empty((T, self.n_streams, self.n_out), self.out_dtype)
         with np.errstate(all="ignore"):
             for t in range(T):
                 o = self.step(*[x[t, :, i] for i in range(self.n_in)])
@@ -326,8 +327,8 @@ def output_dtypes(expr):
         return ["f64" if np.asarray(f._value(w)).dtype == np.float64 else "f32" for w in f._outs]
 
 
-def compile(expr, n_streams: int = 1, params=None) -> FlowzOracle:  # noqa: A001 (mirrors flowz::compile)
-    return FlowzOracle(expr, n_streams, params)
+def compile(expr, n_streams: int = 1, params=None, out_f64: bool = False) -> FlowzOracle:  # noqa: A001 (mirrors flowz::compile)
+    return FlowzOracle(expr, n_streams, params, out_f64)
 
 
 # ----------------------------------------------------------------------------------------

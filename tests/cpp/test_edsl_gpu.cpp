@@ -107,6 +107,23 @@ int main()
       float a2 = 1.f;
       auto one_pole_f = compile(~(std::ref(a2) * _1[_1] + 0.1f * _2));
       CHECK(one_pole_f.info().n_const64 == 0 && one_pole.info().n_const64 == 1);
+      // call_f64: the double result itself, as the reference's tuple<double> (tests.cpp:222,229)
+      float a3 = 0.75f;
+      auto one_pole_d = compile(~(std::ref(a3) * _1[_1] + 0.1 * _2));
+      float yd1 = 0.f;
+      bool wide = false;
+      for (int n = 0; n < 10; ++n) {
+         const float x = n == 0 ? 1.f : 0.25f;
+         const double want = a3 * yd1 + 0.1 * x;
+         const std::tuple<double> got = one_pole_d.call_f64(x);
+         CHECK(std::get<0>(got) == want);
+         wide = wide || want != static_cast<double>(static_cast<float>(want));
+         yd1 = static_cast<float>(want);
+      }
+      CHECK(wide);
+      auto two = compile((_1 , 0.5 * _1));                  // (float wire, double wire)
+      const std::tuple<double, double> r = two.call_f64(0.3f);
+      CHECK(std::get<0>(r) == static_cast<double>(0.3f) && std::get<1>(r) == 0.5 * 0.3f);
    }
    {  // block API: 96 independent integrators, 33 samples in one launch, then 7 more (state carried)
       auto f = compile(~(_1[_1] + _2));

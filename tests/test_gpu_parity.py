@@ -196,6 +196,58 @@ def test_double_literal_graphs_vs_compiled_c(torch_cuda, F):
         assert ndiff(got, C.mixed_precision_biquad(x)) == 0
 
 
+def ndiff64(a, b):
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return int((a.view(np.uint64) != b.view(np.uint64)).sum())
+
+
+@pytest.mark.parametrize("P", [0, 1, 2, 4])
+def test_float64_output_frames_keep_double_results(torch_cuda, F, P):
+    """FZ_VF_OUT_F64: the double result of a graph with double literals leaves un-narrowed (the
+    tuple<double> of tests.cpp:222-231); float wires widen exactly.  vs compiled C and the oracle,
+    time-major and tiled, chained blocks."""
+    torch = torch_cuda
+    ns, T = 2048, 150
+    x = O.synth_input(SEED + 31, np.arange(ns), T)
+    xd = torch.from_numpy(x).cuda()
+    v = F.make_variant(P, 8) if P else None
+    p1 = F.compile(F.from_sexpr(G.one_pole_readme(0.9)))
+    p2 = F.compile(F.from_sexpr(G.mixed_precision_biquad()))
+    for prog, want in ((p1, C.one_pole_readme(0.9, x, out_f64=True)), (p2, C.mixed_precision_biquad(x, out_f64=True))):
+        y, _ = prog.run_block(xd, variant=v, out_f64=True)
+        assert y.dtype == torch.float64 and ndiff64(y.cpu().numpy(), want) == 0
+        assert (want != want.astype(np.float32)).any()                       # the low bits are really there
+        ya, st = prog.run_block(xd[:70], variant=v, out_f64=True)            # chained blocks
+        yb, _ = prog.run_block(xd[70:], state=st, variant=v, out_f64=True)
+        assert ndiff64(torch.cat([ya, yb]).cpu().numpy(), want) == 0
+        yt, _ = prog.run_block(F.to_tiled(xd, 256), variant=v, out_f64=True)  # tiled layout
+        assert ndiff64(F.from_tiled(yt).cpu().numpy(), want) == 0
+    # mixed output types: (float wire, double wire) -> both widened into one float64 frame
+    g = G.seq(G.chan(G.IN(1), G.mul(G.lit64(0.3), G.IN(1))), G.par(G.add(G.IN(1), G.DEL(1, 1)), G.IN(1)))
+    prog = F.compile(F.from_sexpr(g))
+    assert prog.output_dtypes() == ["f32", "f64"]
+    y, _ = prog.run_block(xd, variant=v, out_f64=True)
+    want = O.compile(g, ns, out_f64=True).run(x)
+    assert ndiff64(y.cpu().numpy(), want) == 0
+    y32, _ = prog.run_block(xd, variant=v)
+    assert ndiff(y32.cpu().numpy(), want.astype(np.float32)) == 0          # narrowing once == float32 frames
+
+
+def test_float64_output_frames_of_float_graphs_and_stage_packing(torch_cuda, F):
+    """A float-only graph widens exactly, also through the stage-packed kernel."""
+    torch = torch_cuda
+    ns, T = 512, 257
+    x = O.synth_input(SEED + 32, np.arange(ns), T)
+    xd = torch.from_numpy(x).cuda()
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    want = C.df1_cascade([G.STABLE] * 6, x).astype(np.float64)
+    for v in (None, F.make_variant(1, 8, 256, F.C.FZ_VF_STAGE_PACK), F.make_variant(2, 4), F.make_variant(1, 8, 256, F.C.FZ_VF_NO_STAGE_PACK)):
+        y, _ = prog.run_block(xd, variant=v, out_f64=True)
+        assert ndiff64(y.cpu().numpy(), want) == 0
+
+
 def test_denormals_and_specials_are_kept(torch_cuda, F):
     """No flush-to-zero, NaN/Inf propagate like the CPU."""
     g = G.df1()

@@ -250,7 +250,8 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    const uint64_t wmax = std::max<uint64_t>(std::max(g.n_in, g.n_out), 1);
    if (tile_streams == 0 || tile_streams >= n_streams) tile_streams = 0;    // one tile == plain time-major
    const uint64_t row_streams = tile_streams ? tile_streams : n_streams;
-   if (row_streams * wmax >= (1ull << 30)) fail(FZ_E_UNSUPPORTED, "row longer than 4 GiB: shard or tile the streams");
+   const uint64_t out_w = (uint64_t)std::max<uint32_t>(g.n_out, 1) * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 2 : 1);
+   if (row_streams * std::max(wmax, out_w) >= (1ull << 30)) fail(FZ_E_UNSUPPORTED, "row longer than 4 GiB: shard or tile the streams");
    if (n_streams >= (1ull << 32)) fail(FZ_E_UNSUPPORTED, "more than 2^32 streams per launch: shard the streams");
    if (tile_streams && n_streams % tile_streams) fail(FZ_E_INVALID, "n_streams must be a multiple of tile_streams");
    require_device();
@@ -512,12 +513,12 @@ int fz_bank_process_tiled(fz_bank* b, const float* in_dev, float* out_dev, uint3
                         hip_stream, tile_streams);)
 }
 
-int fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint32_t n_samples)
+static int bank_process_host(fz_bank* b, const float* in_host, void* out_host, uint32_t n_samples, bool f64)
 {
    FZ_GUARD(
       if (!b || !out_host || !n_samples) fail(FZ_E_INVALID, "fz_bank_process_host: bad arguments");
       const Graph& g = b->prog->g;
-      const size_t ib = (size_t)n_samples * b->n_streams * g.n_in * 4, ob = (size_t)n_samples * b->n_streams * g.n_out * 4;
+      const size_t ib = (size_t)n_samples * b->n_streams * g.n_in * 4, ob = (size_t)n_samples * b->n_streams * g.n_out * (f64 ? 8 : 4);
       if (ib > b->stage_in_cap) {
          (void)hipFree(b->stage_in);
          b->stage_in = nullptr;
@@ -534,11 +535,22 @@ int fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint
          if (!in_host) fail(FZ_E_INVALID, "in_host is null but the graph has input wires");
          FZ_HIP(hipMemcpy(b->stage_in, in_host, ib, hipMemcpyHostToDevice));
       }
+      const fz_variant v64{0, 0, 0, FZ_VF_OUT_F64};
       int rc = fz::launch(b->prog, g.n_in ? b->stage_in : nullptr, b->stage_out, g.n_state ? b->state : nullptr, b->params,
-                          b->n_streams, n_samples, nullptr, nullptr, 0);
+                          b->n_streams, n_samples, f64 ? &v64 : nullptr, nullptr, 0);
       if (rc != FZ_OK) return rc;
       FZ_HIP(hipMemcpy(out_host, b->stage_out, ob, hipMemcpyDeviceToHost));
       return FZ_OK;)
+}
+
+int fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint32_t n_samples)
+{
+   return bank_process_host(b, in_host, out_host, n_samples, false);
+}
+
+int fz_bank_process_host_f64(fz_bank* b, const float* in_host, double* out_host, uint32_t n_samples)
+{
+   return bank_process_host(b, in_host, out_host, n_samples, true);
 }
 
 }  // extern "C"

@@ -283,10 +283,11 @@ class Program:
             C.check(C.lib.fz_run_block(self._h, in_ptr, out_ptr, state_ptr, params_ptr, int(n_streams),
                                        int(n_samples), vp, stream))
 
-    def run_block(self, x, state=None, params=None, out=None, variant: Optional[Variant] = None):
+    def run_block(self, x, state=None, params=None, out=None, variant: Optional[Variant] = None, out_f64: bool = False):
         """x: CUDA float32 frames, either time-major [T, n_streams, n_in] or stream-tiled
         [n_tiles, T, tile_streams, n_in] (the HBM-friendly layout, see fz_run_block_tiled).
         state: [n_state, n_streams] in/out (allocated zeroed when None), params: [n_param, n_streams].
+        out_f64: float64 output frames (results of double sub-expressions leave un-narrowed).
         Launches on torch's current stream; returns (out, state), out laid out like x."""
         import torch
 
@@ -303,8 +304,13 @@ class Program:
             T, ns, _ = x.shape
             tile = 0
             oshape = (T, ns, self.n_out)
+        odt = torch.float64 if out_f64 else torch.float32
+        if out_f64:
+            v0 = variant if variant is not None else Variant(0, 0, 0, 0)
+            variant = Variant(v0.streams_per_lane, v0.unroll, v0.block_threads, v0.flags | C.FZ_VF_OUT_F64)
         if out is None:
-            out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+            out = torch.empty(oshape, dtype=odt, device=x.device)
+        assert out.dtype == odt
         if state is None:
             state = torch.zeros((max(self.n_state, 1), ns), dtype=torch.float32, device=x.device)
         assert state.is_contiguous() and out.is_contiguous() and tuple(out.shape) == oshape
