@@ -28,6 +28,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <complex>
 #include <tuple>
 #include <type_traits>
 #include <utility>
@@ -118,6 +119,8 @@ expr<0, 1> as_expr(T v)
       return expr<0, 1>(handle(fz_literal_f64(static_cast<double>(v))));
    return expr<0, 1>(handle(fz_literal(static_cast<float>(v))));
 }
+// a std::complex<float> terminal (test/tests.cpp:206-207): the wire above it is complex
+inline expr<0, 1> as_expr(const std::complex<float>& z) { return expr<0, 1>(handle(fz_literal_c32(z.real(), z.imag()))); }
 inline expr<0, 1> as_expr(std::reference_wrapper<float> r)
 {
    const uint32_t id = next_uniform_id();
@@ -136,6 +139,7 @@ const expr<I, O>& as_expr(const expr<I, O>& e)
 
 template <class T>
 struct is_operand : std::integral_constant<bool, std::is_arithmetic<typename std::decay<T>::type>::value ||
+                                                    std::is_same<typename std::decay<T>::type, std::complex<float>>::value ||
                                                     std::is_same<typename std::decay<T>::type, std::reference_wrapper<float>>::value ||
                                                     std::is_same<typename std::decay<T>::type, std::reference_wrapper<const float>>::value> {};
 
@@ -356,6 +360,8 @@ class stateful_lambda {
    template <class T, class... Args>
    typename detail::value_tuple<T, Out>::type call_as(const Args&... args)
    {
+      if (info().n_out != static_cast<uint32_t>(Out))
+         throw error(FZ_E_INVALID, "this graph has std::complex output wires: call it with call_flat(x...)");
       const float in[In > 0 ? In : 1] = {static_cast<float>(args)...};
       T out[Out];
       own().process_host(In > 0 ? in : nullptr, out, 1);
@@ -408,6 +414,17 @@ public:
    result_f64_t call_f64(const Args&... args)
    {
       return call_as<double>(args...);
+   }
+
+   // one sample, results as the raw output frame: one float per real wire, (re, im) per std::complex
+   // wire (the wire types are run-time here: fz_program_output_dtypes)
+   template <class... Args, class = typename std::enable_if<(sizeof...(Args) == In)>::type>
+   std::vector<float> call_flat(const Args&... args)
+   {
+      const float in[In > 0 ? In : 1] = {static_cast<float>(args)...};
+      std::vector<float> out(info().n_out);
+      own().process_host(In > 0 ? in : nullptr, out.data(), 1);
+      return out;
    }
 
    // the block API: n_streams independent closures with zeroed state in HBM

@@ -52,6 +52,15 @@ fz_expr* fz_literal_f64(double value);               /* a C++ `double` literal t
                                                         it evaluate in double (usual arithmetic conversions,
                                                         proto::_default :769-772; test/tests.cpp:200-231),
                                                         delay lines and output frames stay float32 (:1245) */
+fz_expr* fz_literal_c32(float re, float im);         /* a std::complex<float> terminal (test/tests.cpp:206-207):
+                                                        the wire above it is complex -- two float32 slots
+                                                        (re, im) of the output frame; operators follow
+                                                        std::complex<float> (scalar mul/div and add touch the
+                                                        parts as <complex> does, complex*complex is the
+                                                        (ac-bd, ad+bc) of __mulsc3 for finite values).  A
+                                                        complex wire cannot enter a delay line (they are
+                                                        float, :1245) nor meet a double operand (no such
+                                                        operator in C++): FZ_E_GRAPH                     */
 fz_expr* fz_stream_param(uint32_t k);                /* per-stream, block-constant coefficient k:
                                                         the std::ref terminal of flowz/README.md:42-61,
                                                         one value per stream                          */
@@ -95,6 +104,7 @@ typedef struct fz_info {
    uint32_t n_lds_slots; /* ring-buffer slots kept in LDS (lines deeper than the register cap) */
    uint32_t stage_packable; /* 1 when the graph is a series of isomorphic segments (FZ_VF_STAGE_PACK) */
    uint32_t n_const64;   /* distinct float64 literal terminals                                */
+   uint32_t n_out_wires; /* output wires (output_arity); < n_out when some wires are complex         */
 } fz_info;
 
 int  fz_compile(const fz_expr* e, fz_program** out);
@@ -120,9 +130,10 @@ typedef struct fz_ir_node {
 
 /* nodes are in evaluation (topological) order; writes min(n, cap), returns n */
 int fz_program_ir(const fz_program* p, fz_ir_node* nodes, uint32_t cap);
-/* node id of each output wire; writes min(n_out, cap), returns n_out */
+/* node id of each output frame slot (a complex wire takes two: re, im); writes min(n_out, cap), returns n_out */
 int fz_program_outputs(const fz_program* p, uint32_t* node_ids, uint32_t cap);
-/* arithmetic type of each output wire before it is narrowed to the float32 frame: 0 = float, 1 = double
+/* arithmetic type of each output frame slot before it is narrowed to the float32 frame: 0 = float, 1 = double,
+ * 2 / 3 = real / imaginary part of a std::complex<float> wire
  * (the ResultType inference of flowz.hpp:585-644 / test/tests.cpp:200-231, with compile()'s float delay
  * lines: a delayed read is float whatever was pushed, flowz.hpp:1245); writes min(n_out, cap), returns n_out */
 int fz_program_output_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap);

@@ -1,0 +1,36 @@
+// TEST INFRASTRUCTURE: the complex_mix graph (tests/graphs.py) written with std::complex<float> and
+// the natural C++ operators -- what proto::_default<eval_it> (flowz.hpp:769-772) applies to the
+// evaluated children when a terminal is a std::complex<float> (test/tests.cpp:206-207).
+// It pins the restatements of <complex> in flowz_oracle.c (float _Complex) and flowz_oracle.py
+// (_Cplx) against the <complex> of this toolchain.  g++ -O3 -ffp-contract=off.
+#include <complex>
+#include <cstddef>
+
+extern "C" void fzo_complex_mix_std(float are, float aim, float bre, float bim, const float* c /* [5] */,
+                                    const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                                    float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   using cplx = std::complex<float>;
+   const cplx A{are, aim}, B{bre, bim};
+   for (long s = 0; s < n_streams; ++s) {
+      float acc = 0.f;
+      for (long t = 0; t < T; ++t) {
+         const float x0 = x[s * xss + t * xts];
+         const cplx z1 = A * x0;
+         const cplx z2 = (x0 * x0) * B;
+         const cplx z3 = z1 * z2;
+         const cplx z4 = z3 + c[0];
+         const cplx z5 = c[1] - z4;
+         const cplx z6 = z5 / c[2];
+         const cplx z7 = (-z6) - z1;
+         const cplx z8 = z7 + z2;
+         const cplx z9 = c[3] + z8;
+         const cplx z10 = z9 - c[4];
+         acc = acc + x0;
+         float* o = y + s * yss + t * yts;
+         o[0] = z10.real();
+         o[1] = z10.imag();
+         o[2] = acc;
+      }
+   }
+}

@@ -25,7 +25,21 @@ class Coef(ctypes.Structure):
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE, "libflowz_oracle.so"])
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libflowz_oracle.so", "libflowz_oracle_std.so"])
+
+
+_LIB_STD = None
+
+
+def lib_std():
+    """std::complex<float> spelling of the complex graphs (oracle/complex_std.cpp)."""
+    global _LIB_STD
+    if _LIB_STD is None:
+        path = os.path.join(_HERE, "libflowz_oracle_std.so")
+        if not os.path.exists(path):
+            build()
+        _LIB_STD = ctypes.CDLL(path)
+    return _LIB_STD
 
 
 def lib():
@@ -66,12 +80,12 @@ def _coefs(cs):
     return arr
 
 
-def _run(fname, pre_args, x, n_in, n_out, stream_major, out_dtype=F32):
+def _run(fname, pre_args, x, n_in, n_out, stream_major, out_dtype=F32, library=None):
     x, T, ns = _prep(x, n_in, stream_major)
     y = np.empty((ns, T, n_out) if stream_major else (T, ns, n_out), out_dtype)
     xss, xts = _strides(T, ns, n_in, stream_major)
     yss, yts = _strides(T, ns, n_out, stream_major)
-    getattr(lib(), fname)(*pre_args, _p(x), _pd(xss), _pd(xts), _p(y), _pd(yss), _pd(yts),
+    getattr(library or lib(), fname)(*pre_args, _p(x), _pd(xss), _pd(xts), _p(y), _pd(yss), _pd(yts),
                           ctypes.c_long(ns), ctypes.c_long(T))
     return y
 
@@ -126,6 +140,16 @@ def mixed_precision_biquad(x, b=(0.05, -0.075, 0.275), a=(0.2, -0.8), stream_maj
     if out_f64:
         return _run("fzo_mixed_precision_biquad_f64out", pre, x, 1, 1, stream_major, np.float64)
     return _run("fzo_mixed_precision_biquad", pre, x, 1, 1, stream_major)
+
+
+def complex_mix(x, A=(0.6, 0.8), B=(0.3, -0.4), c=(0.5, 0.25, 1.5, -0.125, 0.75), stream_major=False, std=False):
+    """-> frames of 3 slots (re, im, integrator): tests/graphs.py complex_mix.
+    std=True: the std::complex<float> spelling (oracle/complex_std.cpp) instead of float _Complex."""
+    cc = np.ascontiguousarray(c, F32)
+    pre = tuple(ctypes.c_float(float(F32(v))) for v in (*A, *B)) + (_p(cc),)
+    if std:
+        return _run("fzo_complex_mix_std", pre, x, 1, 3, stream_major, library=lib_std())
+    return _run("fzo_complex_mix", pre, x, 1, 3, stream_major)
 
 
 def rbj_lowpass(freq, q, sr, libmf=False):

@@ -279,6 +279,40 @@ void fzo_mixed_precision_biquad_f64out(double b0, double b1, double b2, float a1
    }
 }
 
+/* ---- std::complex<float> wires (ResultType cases test/tests.cpp:206-207), with C99 `float _Complex`
+ * -- the very representation std::complex<float> wraps (_M_value) and whose operators it forwards to:
+ * complex (op) real touches the parts without cross terms, complex * complex is __mulsc3.
+ * tests/graphs.py: complex_mix -- every supported operator once, next to a real integrator wire:
+ *   z1 = A*x   z2 = (x*x)*B   z3 = z1*z2   z4 = z3 + c0   z5 = c1 - z4   z6 = z5 / c2
+ *   z7 = (-z6) - z1   z8 = z7 + z2   z9 = c3 + z8   z10 = z9 - c4 ;   frame = (re z10, im z10, integ) */
+void fzo_complex_mix(float are, float aim, float bre, float bim, const float* c /* [5] */,
+                     const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                     float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   const float _Complex A = __builtin_complex(are, aim), B = __builtin_complex(bre, bim);
+   for (long s = 0; s < n_streams; ++s) {
+      float acc = 0.f;
+      for (long t = 0; t < T; ++t) {
+         const float x0 = x[s * xss + t * xts];
+         float _Complex z1 = A;  z1 *= x0;                   /* operator*(complex, T): r = z; r *= s   */
+         float _Complex z2 = B;  z2 *= (x0 * x0);            /* operator*(T, complex): r = z; r *= s   */
+         float _Complex z3 = z1; z3 *= z2;                   /* complex *= complex: __mulsc3            */
+         float _Complex z4 = z3; z4 += c[0];
+         float _Complex z5 = -z4; z5 += c[1];                /* operator-(T, complex): r = -z; r += s   */
+         float _Complex z6 = z5; z6 /= c[2];
+         float _Complex z7 = -z6; z7 -= z1;
+         float _Complex z8 = z7; z8 += z2;
+         float _Complex z9 = z8; z9 += c[3];                 /* operator+(T, complex): r = z; r += s    */
+         float _Complex z10 = z9; z10 -= c[4];
+         acc = acc + x0;                                     /* ~(_1[_1] + _2)                          */
+         float* o = y + s * yss + t * yts;
+         o[0] = __real__ z10;
+         o[1] = __imag__ z10;
+         o[2] = acc;
+      }
+   }
+}
+
 /* ---- RBJ low-pass coefficients, reactive_equations/reactive_filter_coeff.cpp:38-58, with the
  * reference's types: every PARAMETER is float, `1.` `2.` are double literals; std::cos/std::sin of a
  * float.  sin/cos are taken in double and rounded to float, which is within 1 ULP of (and almost

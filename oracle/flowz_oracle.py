@@ -49,6 +49,10 @@ Graph notation ("s-expressions", plain nested tuples; a shared data format, no c
                          flowz.hpp:769-772; test/tests.cpp:200-231); the value is truncated to
                          float when it enters a delay line (rotate_push_back :130-137, state is
                          float :1245) and when it leaves the graph (float32 output frames)
+    ('litc', re, im)     std::complex<float> terminal (test/tests.cpp:206-207): the wire above it is
+                         complex; operators as <complex> defines them for complex<float> (class _Cplx
+                         below); it takes two slots (re, im) of the output frame; it cannot enter a
+                         delay line (float state, :1245) nor meet a double operand (no such operator)
     ('param', k)         per-stream coefficient k (block-constant std::ref analogue,
                          flowz/README.md:42-61)
     ('add'|'sub'|'mul'|'div', a, b), ('neg', a)             flowz.hpp:769-772
@@ -78,7 +82,7 @@ def input_arity(e) -> int:
     k = e[0]
     if k in ("in", "del"):
         return int(e[1])                      # :163-170  arity of _i is i
-    if k in ("lit", "lit64", "param"):
+    if k in ("lit", "lit64", "litc", "param"):
         return 0                              # :171-174
     if k == "fb":                             # :175-181
         return max(0, input_arity(e[1]) - output_arity(e[1]))
@@ -122,7 +126,7 @@ def max_input_delays(e) -> tuple:
         return (0,) * (e[1] - 1) + (int(e[2]),)
     if k == "in":
         return (0,) * e[1]
-    if k in ("lit", "lit64", "param"):
+    if k in ("lit", "lit64", "litc", "param"):
         return ()
     if k == "fb":                             # :459-465
         return max_input_delays(e[1])[output_arity(e[1]):]
@@ -135,6 +139,74 @@ def max_input_delays(e) -> tuple:
     if k in _ARITH or k == "chan":            # :493-496 fold with max-zip
         return zipmax(max_input_delays(e[2]), max_input_delays(e[1]))
     raise GraphError(f"unknown node {k!r}")
+
+
+# ----------------------------------------------------------------------------------------
+# std::complex<float> values: the operators of <complex> on (re, im) float32 pairs
+# ----------------------------------------------------------------------------------------
+
+class _Cplx:
+    """std::complex<float>, one per stream.  libstdc++/libc++ <complex>, complex<float>:
+         z *= s, z /= s        scale both parts          z += s, z -= s     real part only
+         s - z                 complex r = -z; r += s    -z                 both parts
+         z * w                 _Complex float multiply = __mulsc3: ac = a*c, bd = b*d, ad = a*d,
+                               bc = b*c, (ac - bd, ad + bc), every operation rounded to float (its
+                               inf/nan recovery branch is not restated: finite values only)
+       s / z, z / w (__divsc3) are not restated."""
+
+    __array_ufunc__ = None            # numpy arrays defer to the reflected operators below
+    __slots__ = ("re", "im")
+
+    def __init__(self, re, im):
+        self.re = np.asarray(re, F32)
+        self.im = np.asarray(im, F32)
+
+    @staticmethod
+    def _scalar(o):
+        o = np.asarray(o)
+        if o.dtype != F32:
+            raise GraphError("std::complex<float> and double operands do not mix (no such operator in C++)")
+        return o
+
+    def __add__(self, o):
+        if isinstance(o, _Cplx):
+            return _Cplx(self.re + o.re, self.im + o.im)
+        return _Cplx(self.re + self._scalar(o), self.im)
+
+    def __radd__(self, o):
+        return _Cplx(self.re + self._scalar(o), self.im)
+
+    def __sub__(self, o):
+        if isinstance(o, _Cplx):
+            return _Cplx(self.re - o.re, self.im - o.im)
+        return _Cplx(self.re - self._scalar(o), self.im)
+
+    def __rsub__(self, o):
+        return _Cplx((-self.re) + self._scalar(o), -self.im)
+
+    def __mul__(self, o):
+        if isinstance(o, _Cplx):
+            ac, bd = self.re * o.re, self.im * o.im
+            ad, bc = self.re * o.im, self.im * o.re
+            return _Cplx(ac - bd, ad + bc)
+        o = self._scalar(o)
+        return _Cplx(self.re * o, self.im * o)
+
+    def __rmul__(self, o):
+        o = self._scalar(o)
+        return _Cplx(self.re * o, self.im * o)
+
+    def __truediv__(self, o):
+        if isinstance(o, _Cplx):
+            raise GraphError("division by a std::complex wire (__divsc3) is not restated")
+        o = self._scalar(o)
+        return _Cplx(self.re / o, self.im / o)
+
+    def __rtruediv__(self, o):
+        raise GraphError("division by a std::complex wire (__divsc3) is not restated")
+
+    def __neg__(self):
+        return _Cplx(-self.re, -self.im)
 
 
 # ----------------------------------------------------------------------------------------
@@ -184,6 +256,17 @@ class FlowzOracle:
         self._delayed = [w for w in self._wires if w.depth > 0]
         for w in self._delayed:                      # zero-initialised float state (:1245)
             w.fifo = [np.zeros(self.n_streams, F32) for _ in range(w.depth)]
+        # output frame slots: a complex wire takes two (re, im).  Types are static: probe them once.
+        self._t += 1
+        for i in range(self.n_in):
+            self._cur_in[i] = np.zeros(self.n_streams, F32)
+        with np.errstate(all="ignore"):
+            probe = [self._value(w) for w in self._outs]
+            for w in self._delayed:
+                if isinstance(self._value(w), _Cplx):
+                    raise GraphError("a std::complex wire cannot enter a delay line: compile() stores float state")
+        self.out_types = ["cf32" if isinstance(v, _Cplx) else ("f64" if np.asarray(v).dtype == np.float64 else "f32") for v in probe]
+        self.n_slots = sum(2 if k == "cf32" else 1 for k in self.out_types)
 
     # -- construction ------------------------------------------------------------------
     def _new(self, fn=None):
@@ -231,6 +314,9 @@ class FlowzOracle:
         if k == "lit64":
             c64 = np.float64(e[1])
             return [self._new(lambda c64=c64: np.full(self.n_streams, c64, np.float64))]
+        if k == "litc":
+            cr, ci = F32(e[1]), F32(e[2])
+            return [self._new(lambda cr=cr, ci=ci: _Cplx(np.full(self.n_streams, cr, F32), np.full(self.n_streams, ci, F32)))]
         if k == "param":
             idx = int(e[1])
             return [self._new(lambda idx=idx: self._params[idx])]
@@ -290,7 +376,15 @@ class FlowzOracle:
         for i, x in enumerate(inputs):
             self._cur_in[i] = np.ascontiguousarray(
                 np.broadcast_to(np.asarray(x, dtype=F32), (self.n_streams,)))
-        outs = [np.array(self._value(w), dtype=self.out_dtype, copy=True) for w in self._outs]
+        outs = []
+        for w in self._outs:                       # complex wires come out as numpy complex (exact pair)
+            v = self._value(w)
+            if isinstance(v, _Cplx):
+                c = np.empty(self.n_streams, np.complex128 if self.out_dtype == np.float64 else np.complex64)
+                c.real, c.imag = v.re, v.im
+                outs.append(c)
+            else:
+                outs.append(np.array(v, dtype=self.out_dtype, copy=True))
         # consumers first, pushes last (:994, :1067)
         new = [np.array(self._value(w), dtype=F32, copy=True) for w in self._delayed]
         for w, v in zip(self._delayed, new):
@@ -299,32 +393,35 @@ class FlowzOracle:
         return tuple(outs)
 
     def run(self, x):
-        """x: float32 [T, n_streams, n_in] (time-major frames) -> [T, n_streams, n_out]."""
+        """x: float32 [T, n_streams, n_in] (time-major frames) -> [T, n_streams, n_slots]
+        (n_slots == n_out unless some output wires are complex: those take two slots, re then im)."""
         x = np.asarray(x, dtype=F32)
         if x.ndim == 2 and self.n_in == 1:
             x = x[:, :, None]
         T = x.shape[0]
-        y = np.empty((T, self.n_streams, self.n_out), self.out_dtype)
+        y = np.empty((T, self.n_streams, self.n_slots), self.out_dtype)
         with np.errstate(all="ignore"):
             for t in range(T):
                 o = self.step(*[x[t, :, i] for i in range(self.n_in)])
+                k = 0
                 for j in range(self.n_out):
-                    y[t, :, j] = o[j]
+                    if self.out_types[j] == "cf32":
+                        y[t, :, k] = o[j].real
+                        y[t, :, k + 1] = o[j].imag
+                        k += 2
+                    else:
+                        y[t, :, k] = o[j]
+                        k += 1
         return y
 
 
 def output_dtypes(expr):
-    """Arithmetic type of every output wire as the evaluator produces it: 'f32' or 'f64'.
+    """Arithmetic type of every output wire as the evaluator produces it: 'f32', 'f64' or 'cf32'
+    (std::complex<float>, tests.cpp:206-207).
     Built-in operators promote by the usual arithmetic conversions (flowz.hpp:769-772; the cases of
     test/tests.cpp:200-231 without delays); a delayed read is float because compile() builds float
     delay lines (flowz.hpp:1245) -- the unused ResultType transform (:585-644) would keep the pushed type."""
-    f = FlowzOracle(expr, 1)
-    zeros = [np.zeros(1, F32)] * f.n_in
-    f._t += 1
-    for i, x in enumerate(zeros):
-        f._cur_in[i] = x
-    with np.errstate(all="ignore"):
-        return ["f64" if np.asarray(f._value(w)).dtype == np.float64 else "f32" for w in f._outs]
+    return list(FlowzOracle(expr, 1).out_types)
 
 
 def compile(expr, n_streams: int = 1, params=None, out_f64: bool = False) -> FlowzOracle:  # noqa: A001 (mirrors flowz::compile)

@@ -125,6 +125,24 @@ int main()
       const std::tuple<double, double> r = two.call_f64(0.3f);
       CHECK(std::get<0>(r) == static_cast<double>(0.3f) && std::get<1>(r) == 0.5 * 0.3f);
    }
+   {  // std::complex<float> terminals (test/tests.cpp:206-207): the wire is complex, the frame holds (re, im)
+      using cplx = std::complex<float>;
+      auto rot = compile(_1 |= cplx{0.6f, 0.8f} * _1);
+      CHECK(rot.info().n_out == 2 && rot.info().n_out_wires == 1);
+      const std::vector<float> r = rot.call_flat(0.7f);
+      const cplx want = cplx{0.6f, 0.8f} * 0.7f;
+      CHECK(r.size() == 2 && r[0] == want.real() && r[1] == want.imag());
+      auto chain = compile(2 * _1 |= _1 * cplx{0.3f, -0.4f} |= (_1 * cplx{0.6f, 0.8f} + 0.25f));
+      volatile float xin = -0.3f, two = 2.f;           // run-time values: no compile-time (MPC, exactly rounded) folding
+      const std::vector<float> q = chain.call_flat(static_cast<float>(xin));
+      const float x2 = two * xin;
+      volatile float b_re = 0.3f, b_im = -0.4f, c_re = 0.6f, c_im = 0.8f;
+      const cplx w2 = (x2 * cplx{b_re, b_im}) * cplx{c_re, c_im} + 0.25f;
+      CHECK(q.size() == 2 && q[0] == w2.real() && q[1] == w2.imag());
+      bool threw = false;
+      try { rot(0.7f); } catch (const flowz::error&) { threw = true; }
+      CHECK(threw);
+   }
    {  // block API: 96 independent integrators, 33 samples in one launch, then 7 more (state carried)
       auto f = compile(~(_1[_1] + _2));
       const int ns = 96;

@@ -199,3 +199,24 @@ def df1_param(base):
 def osc_chain(n=6):
     """resonator(param 0) |= n x DF1(params 1+5j ..): config 4, C_ps = 1 + 5n."""
     return seq(resonator_param(0), *[df1_param(1 + 5 * j) for j in range(n)])
+
+
+def litc(re, im):
+    return ("litc", float(F32(re)), float(F32(im)))
+
+
+def complex_mix(A=(0.6, 0.8), B=(0.3, -0.4), c=(0.5, 0.25, 1.5, -0.125, 0.75)):
+    """std::complex<float> wires (ResultType, test/tests.cpp:206-207): every supported operator once,
+    next to a real integrator wire.  Output frame: (re, im, integrator).  oracle/flowz_oracle.c: fzo_complex_mix"""
+    x = IN(1)
+    z1 = mul(litc(*A), x)
+    z2 = mul(mul(x, x), litc(*B))
+    z3 = mul(z1, z2)
+    z4 = add(z3, lit(c[0]))
+    z5 = sub(lit(c[1]), z4)
+    z6 = ("div", z5, lit(c[2]))
+    z7 = sub(("neg", z6), z1)
+    z8 = add(z7, z2)
+    z9 = add(lit(c[3]), z8)
+    z10 = sub(z9, lit(c[4]))
+    return chan(z10, fb(add(DEL(1, 1), IN(2))))

@@ -248,6 +248,24 @@ def test_float64_output_frames_of_float_graphs_and_stage_packing(torch_cuda, F):
         assert ndiff64(y.cpu().numpy(), want) == 0
 
 
+@pytest.mark.parametrize("P", [0, 1, 2, 4])
+def test_complex_wires_vs_std_complex(torch_cuda, F, P):
+    """std::complex<float> wires (tests.cpp:206-207): every supported <complex> operator, next to a real
+    feedback wire; frames hold (re, im, integrator).  vs the std::complex<float> spelling compiled by g++."""
+    torch = torch_cuda
+    ns, T = 4096, 120
+    x = O.synth_input(SEED + 41, np.arange(ns), T)
+    want = C.complex_mix(x, std=True)
+    prog = F.compile(F.from_sexpr(G.complex_mix()))
+    v = F.make_variant(P, 8) if P else None
+    got, _ = run_gpu(torch, F, prog, x, variant=v)
+    assert got.shape == (T, ns, 3) and ndiff(got, want) == 0
+    y64, _ = prog.run_block(torch.from_numpy(x).cuda(), variant=v, out_f64=True)
+    assert ndiff64(y64.cpu().numpy(), want.astype(np.float64)) == 0
+    yt, _ = prog.run_block(F.to_tiled(torch.from_numpy(x).cuda(), 1024), variant=v)
+    assert ndiff(F.from_tiled(yt).cpu().numpy(), want) == 0
+
+
 def test_denormals_and_specials_are_kept(torch_cuda, F):
     """No flush-to-zero, NaN/Inf propagate like the CPU."""
     g = G.df1()

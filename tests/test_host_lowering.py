@@ -208,3 +208,23 @@ def test_stage_split_detection_and_packed_kernel_builds(tmp_path, monkeypatch):
 def test_output_dtypes_match_tests_cpp_result_types(case):
     p = F.compile(F.from_sexpr(tup(case["graph"])))
     assert p.output_dtypes() == case["types"]
+
+
+def test_complex_wires_lower_to_float_pairs():
+    """std::complex<float> terminals (tests.cpp:206-207) expand into (re, im) float nodes; the frame
+    has one slot per part; what C++ would not compile is rejected."""
+    p = F.compile(F.from_sexpr(G.complex_mix()))
+    assert p.output_dtypes() == ["cf32", "f32"] and p.n_out == 3 and p.info.n_out_wires == 3 - 1
+    assert all(dt == "f32" for dt in p.ir_dtypes())
+    # evaluate the lowered IR on the CPU (test interpreter) against the oracle
+    x = O.synth_input(3, np.arange(5), 33)
+    assert np.array_equal(run_ir(p, x)[0].view(np.uint32), O.compile(G.complex_mix(), 5).run(x).view(np.uint32))
+    # Python complex numbers are complex terminals
+    q = F.compile(F._1 * (0.5 + 2j))
+    assert q.output_dtypes() == ["cf32"] and q.n_out == 2
+    for bad in (("mul", ("litc", 1.0, 0.0), ("lit64", 2.0)),
+                ("seq", ("mul", ("litc", 1.0, 0.0), ("in", 1)), ("del", 1, 1)),
+                ("fb", ("mul", ("litc", 1.0, 0.0), ("add", ("del", 1, 1), ("in", 2)))),
+                ("div", ("in", 1), ("litc", 1.0, 1.0))):
+        with pytest.raises(F.FlowzError):
+            F.compile(F.from_sexpr(bad))

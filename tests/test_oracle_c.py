@@ -98,6 +98,29 @@ def test_double_literals_follow_cpp_usual_arithmetic_conversions():
     assert not same(O.compile(allf, NS).run(x), O.compile(G.one_pole_readme(0.9), NS).run(x))
 
 
+def test_complex_wires_three_spellings_agree():
+    """std::complex<float> wires (tests.cpp:206-207): the generic Python oracle (_Cplx pairs), the C
+    restatement (float _Complex) and the std::complex<float> spelling compiled by g++ are bit-identical."""
+    x = O.synth_input(77, np.arange(257), 96)
+    g = G.complex_mix()
+    assert O.output_dtypes(g) == ["cf32", "f32"]
+    want = C.complex_mix(x, std=True)
+    assert same(C.complex_mix(x), want)
+    assert same(O.compile(g, 257).run(x), want)
+    assert np.isfinite(want).all() and (want[..., 1] != 0).any()
+    # per-sample protocol: the complex wire comes back as one complex value
+    f = O.compile(("mul", ("litc", 0.0, 1.0), ("in", 1)))
+    (z,) = f.step(2.0)
+    assert z.dtype == np.complex64 and z[0] == 2j
+    # what C++ rejects is rejected
+    with pytest.raises(O.GraphError):
+        O.compile(("mul", ("litc", 1.0, 0.0), ("lit64", 2.0)))                    # complex<float> * double
+    with pytest.raises(O.GraphError):
+        O.compile(("seq", ("mul", ("litc", 1.0, 0.0), ("in", 1)), ("del", 1, 1)))  # float delay line
+    with pytest.raises(O.GraphError):
+        O.compile(("div", ("in", 1), ("litc", 1.0, 1.0)))
+
+
 def test_rbj_lowpass_oracle_matches_reference_spelling_within_1ulp():
     """reactive_filter_coeff.cpp:38-58: the oracle takes sin/cos in double and rounds to float; the
     reference calls std::sin/std::cos on float.  Coefficients agree within 1 ULP (mostly exactly)."""

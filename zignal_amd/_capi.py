@@ -31,7 +31,7 @@ IR_KINDS = {1: "input", 2: "const", 3: "param", 4: "delay", 5: "add", 6: "sub", 
 class Info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in
                 ("n_in", "n_out", "n_nodes", "n_ops", "n_lines", "n_state", "n_const", "n_param", "max_delay", "n_lds_slots",
-                 "stage_packable", "n_const64")]
+                 "stage_packable", "n_const64", "n_out_wires")]
 
 
 class IrNode(ctypes.Structure):
@@ -58,6 +58,7 @@ def _load():
         "fz_delayed": (P, [u32, u32]),
         "fz_literal": (P, [f32]),
         "fz_literal_f64": (P, [ctypes.c_double]),
+        "fz_literal_c32": (P, [ctypes.c_float, ctypes.c_float]),
         "fz_stream_param": (P, [u32]),
         "fz_uniform": (P, [u32, f32]),
         "fz_program_set_uniform": (ctypes.c_int, [P, u32, f32]),

@@ -48,6 +48,7 @@ int fz_program_info(const fz_program* p, fz_info* info)
       info->n_lds_slots = g.n_lds_slots;
       info->stage_packable = g.split.ok ? 1u : 0u;
       info->n_const64 = (uint32_t)g.consts64.size();
+      info->n_out_wires = g.n_out_wires;
       return FZ_OK;)
 }
 
@@ -77,7 +78,7 @@ int fz_program_outputs(const fz_program* p, uint32_t* ids, uint32_t cap)
 int fz_program_output_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap)
 {
    if (!p) { set_error("null program"); return FZ_E_INVALID; }
-   for (size_t k = 0; k < p->g.outputs.size() && k < cap; ++k) dtypes[k] = p->g.nodes[p->g.outputs[k]].f64 ? 1u : 0u;
+   for (size_t k = 0; k < p->g.outputs.size() && k < cap; ++k) dtypes[k] = p->g.out_part[k] ? 1u + p->g.out_part[k] : (p->g.nodes[p->g.outputs[k]].f64 ? 1u : 0u);
    return (int)p->g.outputs.size();
 }
 

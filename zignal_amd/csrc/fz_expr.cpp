@@ -148,6 +148,16 @@ fz_expr* fz_literal_f64(double value)
    return e;
 }
 
+fz_expr* fz_literal_c32(float re, float im)
+{
+   auto* e = mk(EK::Literal);
+   e->value = re;
+   e->value_im = im;
+   e->cplx = true;
+   e->in_arity = 0;
+   return e;
+}
+
 fz_expr* fz_uniform(uint32_t k, float initial)
 {
    FZ_GUARD_PTR(

@@ -34,6 +34,8 @@ struct fz_expr {
    float value = 0.f;     // literal
    double value64 = 0.0;  // float64 literal
    bool f64 = false;      // literal is a C++ double
+   bool cplx = false;     // literal is a std::complex<float> (value, value_im)
+   float value_im = 0.f;
    fz_op op = FZ_OP_ADD;  // arith
    fz_expr* a = nullptr;
    fz_expr* b = nullptr;
@@ -90,7 +92,9 @@ struct FarRead {
 struct Graph {
    uint32_t n_in = 0, n_out = 0, n_param = 0;
    std::vector<Node> nodes;          // topological order
-   std::vector<uint32_t> outputs;    // node ids
+   std::vector<uint32_t> outputs;    // node ids, one per output frame slot
+   std::vector<uint8_t> out_part;    // per slot: 0 real wire, 1 / 2 = re / im of a complex wire
+   uint32_t n_out_wires = 0;         // output_arity (complex wires take two slots)
    std::vector<Line> lines;          // ordered by src
    std::vector<float> consts;        // uniform coefficient slots
    std::vector<double> consts64;     // float64 literal terminals

@@ -40,6 +40,14 @@ struct Raw {
 
 struct Elab {
    std::vector<Raw> raw;
+   // std::complex<float> wires (test/tests.cpp:206-207) are lowered to PAIRS of float nodes while the
+   // wire graph is built: a complex wire is known by its real part (always a fresh node), imag_of maps
+   // it to the imaginary part.  The operators expand the way <complex> defines them for complex<float>:
+   //   z*s, s*z = (re*s, im*s)    z/s = (re/s, im/s)    z+s, s+z = (re+s, im)    z-s = (re-s, im)
+   //   s-z = ((-re)+s, -im)   [complex r = -z; r += s]    z+-w componentwise    -z = (-re, -im)
+   //   z*w = (ac-bd, ad+bc): the arithmetic of __mulsc3 (_Complex float) for finite values; its
+   //         inf/nan recovery branch is not reproduced.   s/z, z/w (__divsc3): not supported.
+   std::map<int, int> imag_of;
 
    int add(uint32_t kind, int a = -1, int b = -1, float value = 0.f, uint32_t n = 0)
    {
@@ -69,8 +77,15 @@ struct Elab {
             return {ins[e->i - 1]};
          case EK::Delayed:                                              // place_delay :950-958
             if (e->i > ins.size()) fail(FZ_E_GRAPH, "placeholder _" + std::to_string(e->i) + " has no wire to bind to");
+            if (imag_of.count(ins[e->i - 1]))
+               fail(FZ_E_GRAPH, "a std::complex wire cannot be read through a delay line: compile() stores float state (flowz.hpp:1245)");
             return {add(FZ_IR_DELAY, ins[e->i - 1], -1, 0.f, e->n)};
          case EK::Literal: {
+            if (e->cplx) {
+               int re = add(FZ_IR_CONST, -1, -1, e->value), im = add(FZ_IR_CONST, -1, -1, e->value_im);
+               imag_of[re] = im;
+               return {re};
+            }
             int id = add(FZ_IR_CONST, -1, -1, e->value);
             raw[(size_t)id].f64 = e->f64;
             raw[(size_t)id].value64 = e->value64;
@@ -82,9 +97,15 @@ struct Elab {
             int a = one(e->a, ins), b = one(e->b, ins);
             uint32_t k = e->op == FZ_OP_ADD ? FZ_IR_ADD : e->op == FZ_OP_SUB ? FZ_IR_SUB
                        : e->op == FZ_OP_MUL ? FZ_IR_MUL : FZ_IR_DIV;
-            return {add(k, a, b)};
+            if (imag_of.count(a) || imag_of.count(b)) return {complex_arith(k, a, b)};
+            return {arith(k, a, b)};
          }
-         case EK::Neg: return {add(FZ_IR_NEG, one(e->a, ins))};
+         case EK::Neg: {
+            int a = one(e->a, ins);
+            int re = arith(FZ_IR_NEG, a);
+            if (imag_of.count(a)) imag_of[re] = arith(FZ_IR_NEG, imag_of[a]);
+            return {re};
+         }
          case EK::Channel: {                                            // :765-768 same inputs to both
             auto l = run(e->a, ins), r = run(e->b, ins);
             l.insert(l.end(), r.begin(), r.end());
@@ -115,11 +136,61 @@ struct Elab {
             in2.insert(in2.end(), ins.begin(), ins.end());
             auto ao = run(e->a, in2);
             if (ao.size() != k) fail(FZ_E_GRAPH, "feedback body arity mismatch");
+            for (int w : ao)
+               if (imag_of.count(w))
+                  fail(FZ_E_GRAPH, "a std::complex wire cannot be fed back: compile() stores float state (flowz.hpp:1245)");
             for (size_t j = 0; j < k; ++j) raw[(size_t)fwd[j]].a = ao[j];
             return ao;
          }
       }
       fail(FZ_E_GRAPH, "unknown expression node");
+   }
+
+   // arithmetic node; its C++ type (double if an operand is) is known right away: forward references
+   // and delayed reads are float
+   int arith(uint32_t kind, int a, int b = -1)
+   {
+      int id = add(kind, a, b);
+      raw[(size_t)id].f64 = raw[(size_t)a].f64 || (b >= 0 && raw[(size_t)b].f64);
+      return id;
+   }
+
+   int complex_arith(uint32_t k, int a, int b)
+   {
+      const bool ca = imag_of.count(a) != 0, cb = imag_of.count(b) != 0;
+      if ((!ca && raw[(size_t)a].f64) || (!cb && raw[(size_t)b].f64))
+         fail(FZ_E_GRAPH, "std::complex<float> and double operands do not mix (C++ has no such operator)");
+      int re = -1, im = -1;
+      if (ca && cb) {
+         const int ar = a, ai = imag_of[a], br = b, bi = imag_of[b];
+         switch (k) {
+            case FZ_IR_ADD: case FZ_IR_SUB: re = arith(k, ar, br); im = arith(k, ai, bi); break;
+            case FZ_IR_MUL: {
+               const int ac = arith(FZ_IR_MUL, ar, br), bd = arith(FZ_IR_MUL, ai, bi);
+               const int ad = arith(FZ_IR_MUL, ar, bi), bc = arith(FZ_IR_MUL, ai, br);
+               re = arith(FZ_IR_SUB, ac, bd);
+               im = arith(FZ_IR_ADD, ad, bc);
+               break;
+            }
+            default: fail(FZ_E_UNSUPPORTED, "division by a std::complex wire (__divsc3) is not supported");
+         }
+      } else if (ca) {                                      // complex (op) scalar
+         const int ar = a, ai = imag_of[a];
+         switch (k) {
+            case FZ_IR_ADD: case FZ_IR_SUB: re = arith(k, ar, b); im = ai; break;
+            default: re = arith(k, ar, b); im = arith(k, ai, b); break;       // MUL, DIV
+         }
+      } else {                                              // scalar (op) complex
+         const int br = b, bi = imag_of[b];
+         switch (k) {
+            case FZ_IR_ADD: re = arith(FZ_IR_ADD, br, a); im = bi; break;
+            case FZ_IR_SUB: re = arith(FZ_IR_ADD, arith(FZ_IR_NEG, br), a); im = arith(FZ_IR_NEG, bi); break;
+            case FZ_IR_MUL: re = arith(FZ_IR_MUL, br, a); im = arith(FZ_IR_MUL, bi, a); break;
+            default: fail(FZ_E_UNSUPPORTED, "division by a std::complex wire (__divsc3) is not supported");
+         }
+      }
+      imag_of[re] = im;
+      return re;
    }
 
    int resolve(int id) const
@@ -157,9 +228,21 @@ Graph lower(const fz_expr* e)
    const uint32_t n_in = (uint32_t)e->in_arity;
    std::vector<int> ins;
    for (uint32_t i = 0; i < n_in; ++i) ins.push_back(el.add(FZ_IR_INPUT, -1, -1, 0.f, i));   // front panel
-   std::vector<int> outs = el.run(e, ins);
-   if ((int)outs.size() != e->out_arity) fail(FZ_E_GRAPH, "output arity mismatch between arity table and routing");
-   if (outs.empty()) fail(FZ_E_GRAPH, "graph has no output wire");
+   std::vector<int> out_wires = el.run(e, ins);
+   if ((int)out_wires.size() != e->out_arity) fail(FZ_E_GRAPH, "output arity mismatch between arity table and routing");
+   if (out_wires.empty()) fail(FZ_E_GRAPH, "graph has no output wire");
+   // output frame slots: a complex wire takes two (re, im)
+   std::vector<int> outs;
+   std::vector<uint8_t> out_part;
+   for (int w : out_wires) {
+      auto it = el.imag_of.find(w);
+      outs.push_back(w);
+      out_part.push_back(it == el.imag_of.end() ? 0 : 1);
+      if (it != el.imag_of.end()) {
+         outs.push_back(it->second);
+         out_part.push_back(2);
+      }
+   }
 
    auto& raw = el.raw;
    const size_t N = raw.size();
@@ -327,6 +410,8 @@ Graph lower(const fz_expr* e)
    }
    g.n_in = n_in;
    g.n_out = (uint32_t)outs.size();
+   g.n_out_wires = (uint32_t)out_wires.size();
+   g.out_part = out_part;
    for (int o : outs) g.outputs.push_back(nid(o));
 
    // delay lines: one per delayed wire, depth = deepest reader

@@ -113,6 +113,12 @@ def lit64(v: float) -> Expr:
     return Expr(C.lib.fz_literal_f64(float(v)))
 
 
+def litc(re: float, im: float = 0.0) -> Expr:
+    """A std::complex<float> terminal (test/tests.cpp:206-207): the wire above it is complex and takes
+    two float32 slots (re, im) of the output frame.  Python complex numbers become these."""
+    return Expr(C.lib.fz_literal_c32(float(re), float(im)))
+
+
 def uniform(k: int, initial: float = 0.0) -> Expr:
     """Uniform run-time coefficient k (the std::ref(x) terminal): Program.set_uniform(k, v)."""
     return Expr(C.lib.fz_uniform(int(k), float(initial)))
@@ -127,6 +133,8 @@ def as_expr(x) -> Expr:
         return x
     if isinstance(x, tuple):
         return chan(*x)
+    if isinstance(x, complex):
+        return litc(x.real, x.imag)
     if isinstance(x, (int, float)) or hasattr(x, "__float__"):
         return lit(float(x))
     raise TypeError(f"cannot use {type(x).__name__} in a Flowz expression")
@@ -162,6 +170,7 @@ def from_sexpr(e) -> Expr:
     if k == "del": return Placeholder(e[1])[int(e[2])]
     if k == "lit": return lit(e[1])
     if k == "lit64": return lit64(e[1])
+    if k == "litc": return litc(e[1], e[2])
     if k == "param": return param(e[1])
     if k == "uniform": return uniform(e[1], e[2])
     if k == "neg": return -from_sexpr(e[1])
@@ -224,10 +233,11 @@ class Program:
         return [buf[i] for i in range(self.n_out)]
 
     def output_dtypes(self):
-        """'f32' / 'f64' per output wire: its C++ arithmetic type before narrowing to the float32 frame."""
+        """'f32' / 'f64' / 'cf32' per output WIRE: its C++ type before narrowing to the float32 frame
+        (a 'cf32' wire, std::complex<float>, takes two frame slots: re, im)."""
         buf = (ctypes.c_uint32 * max(self.n_out, 1))()
         C.check(C.lib.fz_program_output_dtypes(self._h, buf, self.n_out))
-        return ["f64" if buf[i] else "f32" for i in range(self.n_out)]
+        return [("f32", "f64", "cf32")[buf[i]] for i in range(self.n_out) if buf[i] != 3]
 
     def lines(self):
         n = self.n_lines
