@@ -127,7 +127,7 @@ int fz_program_build(fz_program* p, const fz_variant* v)
    FZ_GUARD(
       if (!p) fail(FZ_E_INVALID, "null program");
       // "auto" fields resolve as for a large stream count
-      (void)get_kernel(p, resolve_variant(p->g, v, 1ull << 20), false);
+      (void)get_kernel(p, resolve_variant(p->g, v, 1ull << 20), nullptr);
       return FZ_OK;)
 }
 

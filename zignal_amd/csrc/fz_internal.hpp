@@ -135,11 +135,15 @@ std::string full_source(const Graph& g, const Variant& v);
 
 // ---- runtime ---------------------------------------------------------------------------------------------
 struct Kernel {
-   void* module = nullptr;     // hipModule_t
-   void* function = nullptr;   // hipFunction_t
-   std::vector<char> code;     // code object
-   bool loaded = false;
-   ~Kernel();                  // unloads the module (fz_runtime.hip)
+   struct Loaded {
+      int device;
+      void* module;     // hipModule_t
+      void* function;   // hipFunction_t
+   };
+   std::vector<char> code;        // code object (device independent: gfx950)
+   std::vector<Loaded> loaded;    // one module per device the kernel ran on
+   void* function_on_current_device(const std::string& symbol);   // loads on first use (caller holds the program mutex)
+   ~Kernel();                     // unloads the modules (fz_runtime.hip)
 };
 
 }  // namespace fz
@@ -152,7 +156,9 @@ struct fz_program {
 
 namespace fz {
 Variant resolve_variant(const Graph& g, const fz_variant* v, uint64_t n_streams, uint32_t n_samples = 1u << 20);
-std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, bool need_load);
+// builds (or fetches from the caches) the kernel of variant v; fn_out != null: also load it on the
+// current device and return its hipFunction_t
+std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out);
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params,
            uint64_t n_streams, uint32_t n_samples, const fz_variant* v, void* stream, uint32_t tile_streams = 0);
 int device_count();

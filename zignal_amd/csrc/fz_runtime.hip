@@ -44,10 +44,29 @@ static void require_device()
 
 Kernel::~Kernel()
 {
-   if (loaded && module) {
+   if (loaded.empty()) return;
+   int cur = 0;
+   (void)hipGetDevice(&cur);
+   for (const Loaded& l : loaded) {
+      (void)hipSetDevice(l.device);
       (void)hipDeviceSynchronize();          // launches are asynchronous: never unload code that may still run
-      (void)hipModuleUnload((hipModule_t)module);
+      (void)hipModuleUnload((hipModule_t)l.module);
    }
+   (void)hipSetDevice(cur);
+}
+
+void* Kernel::function_on_current_device(const std::string& symbol)
+{
+   int dev = 0;
+   FZ_HIP(hipGetDevice(&dev));
+   for (const Loaded& l : loaded)
+      if (l.device == dev) return l.function;
+   hipModule_t mod;
+   FZ_HIP(hipModuleLoadData(&mod, code.data()));
+   hipFunction_t fn;
+   FZ_HIP(hipModuleGetFunction(&fn, mod, symbol.c_str()));
+   loaded.push_back(Loaded{dev, mod, fn});
+   return fn;
 }
 
 // ---- kernel cache -----------------------------------------------------------------------------------
@@ -112,7 +131,7 @@ static std::vector<char> jit_compile(const Graph& g, const Variant& v)
    return code;
 }
 
-std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, bool need_load)
+std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out)
 {
    std::lock_guard<std::mutex> lock(p->mu);
    auto& slot = p->kernels[v];
@@ -149,15 +168,9 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, bool need_lo
       }
       slot = k;
    }
-   if (need_load && !slot->loaded) {
+   if (fn_out) {
       require_device();
-      hipModule_t mod;
-      FZ_HIP(hipModuleLoadData(&mod, slot->code.data()));
-      hipFunction_t fn;
-      FZ_HIP(hipModuleGetFunction(&fn, mod, kernel_name(p->g, v).c_str()));
-      slot->module = mod;
-      slot->function = fn;
-      slot->loaded = true;
+      *fn_out = slot->function_on_current_device(kernel_name(p->g, v));
    }
    return slot;
 }
@@ -264,7 +277,8 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       if (tile_streams % (v.P * v.block))
          fail(FZ_E_INVALID, "tile_streams must be a multiple of streams_per_lane * block_threads");
    }
-   auto k = get_kernel(p, v, true);
+   void* fn = nullptr;
+   auto k = get_kernel(p, v, &fn);
 
    // kernarg image of `struct fz_args` (8-byte aligned: pad the coefficient tail)
    const size_t off64 = (sizeof(ArgsHeader) + sizeof(float) * std::max<size_t>(g.consts.size(), 1) + 7) & ~size_t(7);
@@ -280,7 +294,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    size_t size = buf.size();
    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
    const unsigned grid = (unsigned)((h.n_groups + v.block - 1) / v.block);
-   FZ_HIP(hipModuleLaunchKernel((hipFunction_t)k->function, grid, 1, 1, v.block, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
+   FZ_HIP(hipModuleLaunchKernel((hipFunction_t)fn, grid, 1, 1, v.block, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
    if (std::getenv("FLOWZ_HIP_DEBUG")) {
       FZ_HIP(hipStreamSynchronize((hipStream_t)stream));
       std::fprintf(stderr, "[flowz_hip] launched grid=%u block=%u P=%u U=%u flags=%u n_streams=%llu n_samples=%u kernarg=%zu B\n",
@@ -379,6 +393,7 @@ using namespace fz;
 struct fz_bank {
    fz_program* prog = nullptr;
    uint64_t n_streams = 0;
+   int device = 0;              // the bank's buffers live on this device
    float* state = nullptr;
    float* params = nullptr;
    float* stage_in = nullptr;
@@ -430,14 +445,24 @@ int fz_copy_probe(const float* src, float* dst, uint64_t n_floats, void* hip_str
 }
 
 // ---- fz_bank -------------------------------------------------------------------------------------------------
+static void check_bank_device(const fz_bank* b)
+{
+   int dev = 0;
+   FZ_HIP(hipGetDevice(&dev));
+   if (dev != b->device)
+      fail(FZ_E_INVALID, "the bank's buffers live on device " + std::to_string(b->device) + ", the current device is " + std::to_string(dev));
+}
+
 int fz_bank_create(fz_program* p, uint64_t n_streams, fz_bank** out)
 {
    FZ_GUARD(
       if (!p || !out || !n_streams) fail(FZ_E_INVALID, "fz_bank_create: bad arguments");
       require_device();
-      auto* b = new fz_bank();
+      std::unique_ptr<fz_bank, void (*)(fz_bank*)> guard(new fz_bank(), fz_bank_destroy);
+      fz_bank* b = guard.get();
       b->prog = p;
       b->n_streams = n_streams;
+      FZ_HIP(hipGetDevice(&b->device));
       const size_t sb = std::max<size_t>((size_t)p->g.n_state * n_streams * 4, 16);
       FZ_HIP(hipMalloc((void**)&b->state, sb));
       FZ_HIP(hipMemset(b->state, 0, sb));                 // zero-initialised float state, flowz.hpp:1245
@@ -446,7 +471,7 @@ int fz_bank_create(fz_program* p, uint64_t n_streams, fz_bank** out)
          FZ_HIP(hipMalloc((void**)&b->params, pb));
          FZ_HIP(hipMemset(b->params, 0, pb));
       }
-      *out = b;
+      *out = guard.release();
       return FZ_OK;)
 }
 
@@ -454,14 +479,16 @@ int fz_bank_clone(const fz_bank* src, fz_bank** out)
 {
    FZ_GUARD(
       if (!src || !out) fail(FZ_E_INVALID, "fz_bank_clone: bad arguments");
+      check_bank_device(src);
       fz_bank* b = nullptr;
       int rc = fz_bank_create(src->prog, src->n_streams, &b);
       if (rc != FZ_OK) return rc;
+      std::unique_ptr<fz_bank, void (*)(fz_bank*)> guard(b, fz_bank_destroy);
       const size_t sb = (size_t)src->prog->g.n_state * src->n_streams * 4;
       if (sb) FZ_HIP(hipMemcpy(b->state, src->state, sb, hipMemcpyDeviceToDevice));
       if (src->params)
          FZ_HIP(hipMemcpy(b->params, src->params, (size_t)src->prog->g.n_param * src->n_streams * 4, hipMemcpyDeviceToDevice));
-      *out = b;
+      *out = guard.release();
       return FZ_OK;)
 }
 
@@ -479,6 +506,7 @@ int fz_bank_reset(fz_bank* b)
 {
    FZ_GUARD(
       if (!b) fail(FZ_E_INVALID, "null bank");
+      check_bank_device(b);
       const size_t sb = (size_t)b->prog->g.n_state * b->n_streams * 4;
       if (sb) FZ_HIP(hipMemset(b->state, 0, sb));
       return FZ_OK;)
@@ -489,6 +517,7 @@ int fz_bank_set_params_host(fz_bank* b, const float* params)
    FZ_GUARD(
       if (!b || !params) fail(FZ_E_INVALID, "fz_bank_set_params_host: bad arguments");
       if (!b->params) fail(FZ_E_INVALID, "graph has no per-stream coefficients");
+      check_bank_device(b);
       FZ_HIP(hipMemcpy(b->params, params, (size_t)b->prog->g.n_param * b->n_streams * 4, hipMemcpyHostToDevice));
       return FZ_OK;)
 }
@@ -499,6 +528,7 @@ int fz_bank_process(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_
 {
    FZ_GUARD(
       if (!b) fail(FZ_E_INVALID, "null bank");
+      check_bank_device(b);
       const Graph& g = b->prog->g;
       return fz::launch(b->prog, in_dev, out_dev, g.n_state ? b->state : nullptr, b->params, b->n_streams, n_samples, v, hip_stream, 0);)
 }
@@ -508,6 +538,7 @@ int fz_bank_process_tiled(fz_bank* b, const float* in_dev, float* out_dev, uint3
 {
    FZ_GUARD(
       if (!b) fail(FZ_E_INVALID, "null bank");
+      check_bank_device(b);
       const Graph& g = b->prog->g;
       return fz::launch(b->prog, in_dev, out_dev, g.n_state ? b->state : nullptr, b->params, b->n_streams, n_samples, v,
                         hip_stream, tile_streams);)
@@ -517,17 +548,20 @@ static int bank_process_host(fz_bank* b, const float* in_host, void* out_host, u
 {
    FZ_GUARD(
       if (!b || !out_host || !n_samples) fail(FZ_E_INVALID, "fz_bank_process_host: bad arguments");
+      check_bank_device(b);
       const Graph& g = b->prog->g;
       const size_t ib = (size_t)n_samples * b->n_streams * g.n_in * 4, ob = (size_t)n_samples * b->n_streams * g.n_out * (f64 ? 8 : 4);
       if (ib > b->stage_in_cap) {
          (void)hipFree(b->stage_in);
          b->stage_in = nullptr;
+         b->stage_in_cap = 0;
          FZ_HIP(hipMalloc((void**)&b->stage_in, ib));
          b->stage_in_cap = ib;
       }
       if (ob > b->stage_out_cap) {
          (void)hipFree(b->stage_out);
          b->stage_out = nullptr;
+         b->stage_out_cap = 0;
          FZ_HIP(hipMalloc((void**)&b->stage_out, ob));
          b->stage_out_cap = ob;
       }
