@@ -80,3 +80,28 @@ def make(seed, max_in=3, depth=3):
     n_in = int(rng.integers(1, max_in + 1))
     g, n_out = graph(rng, n_in, depth)
     return g, n_in, n_out
+
+
+def _retype(rng, e, p64):
+    """flip float literals into C++ double literals with probability p64"""
+    if not isinstance(e, tuple):
+        return e
+    if e[0] == "lit":
+        return ("lit64", float(e[1])) if rng.random() < p64 else e
+    return tuple(_retype(rng, c, p64) if isinstance(c, tuple) else c for c in e)
+
+
+def make_typed(seed, max_in=3, depth=3):
+    """as make(), with mixed wire types: some coefficients are double literals (float64 sub-expressions,
+    narrowed when they enter a delay line), or -- float-only graphs -- a feed-forward
+    std::complex<float> stage behind the first output wire.  Returns (sexpr, n_in, n_out_wires, kind)."""
+    rng = np.random.default_rng(seed + 77000)
+    g, n_in, n_out = make(seed, max_in, depth)
+    if rng.random() < 0.45:                           # the stage reads wire 1, the other outputs pass around it
+        z = ("litc", float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)))
+        w = ("litc", float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)))
+        post = add(mul(mul(z, IN(1)), w), mul(_coef(rng), IN(1)))
+        if rng.random() < 0.5:
+            post = sub(lit(rng.uniform(-1, 1)), ("neg", post))
+        return seq(g, post), n_in, n_out, "complex"
+    return _retype(rng, g, 0.35), n_in, n_out, "double"

@@ -49,6 +49,74 @@ def test_lowering_matches_oracle_on_random_graphs(chunk):
     assert n >= 15
 
 
+def same64(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    nan = np.isnan(a) & np.isnan(b)
+    return np.array_equal(np.where(nan, 0, a).view(np.uint64), np.where(nan, 0, b).view(np.uint64))
+
+
+def usable_typed(seed):
+    g, n_in, n_out, kind = R.make_typed(seed)
+    try:
+        if O.input_arity(g) != n_in or O.output_arity(g) != n_out:
+            return None
+        O.compile(g, 1)
+    except O.GraphError:
+        return None
+    return g, n_in, n_out, kind
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_lowering_matches_oracle_on_random_typed_graphs(chunk):
+    """double literals and std::complex stages sprinkled over the random graphs"""
+    kinds = set()
+    n = 0
+    for seed in range(3000 + chunk * 25, 3000 + chunk * 25 + 25):
+        u = usable_typed(seed)
+        if u is None:
+            continue
+        g, n_in, n_out, kind = u
+        p = F.compile(F.from_sexpr(g))
+        f = O.compile(g, 2)
+        assert (p.n_in, p.info.n_out_wires, p.n_out) == (n_in, n_out, f.n_slots)
+        assert p.output_dtypes() == f.out_types
+        x = O.synth_input(seed, np.arange(2), 40, n_wires=n_in)
+        got, _ = run_ir(p, x)
+        assert same_or_both_nan(got, f.run(x)), f"seed {seed}: {g}"
+        kinds.add(kind if kind == "complex" else ("double" if p.n_const64 else "float"))
+        n += 1
+    assert n >= 12 and {"complex", "double"} <= kinds
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", range(3))
+def test_kernels_match_oracle_on_random_typed_graphs(chunk):
+    import torch
+    ns, T = 136, 45
+    n = 0
+    for seed in range(4000 + chunk * 20, 4000 + chunk * 20 + 20):
+        u = usable_typed(seed)
+        if u is None:
+            continue
+        g, n_in, n_out, kind = u
+        p = F.compile(F.from_sexpr(g))
+        x = O.synth_input(seed, np.arange(ns), T, n_wires=n_in)
+        want = O.compile(g, ns).run(x)
+        want64 = O.compile(g, ns, out_f64=True).run(x)
+        xd = torch.from_numpy(x).cuda()
+        for P in (1, 2, 4):
+            y, _ = p.run_block(xd, variant=F.make_variant(P, 8))
+            assert same_or_both_nan(y.cpu().numpy(), want), f"seed {seed} P={P}: {g}"
+        y64, _ = p.run_block(xd, out_f64=True)
+        assert same64(y64.cpu().numpy(), want64), f"seed {seed} f64 frames: {g}"
+        ya, st = p.run_block(xd[:19].contiguous())
+        yb, st = p.run_block(xd[19:].contiguous(), state=st)
+        assert same_or_both_nan(torch.cat([ya, yb]).cpu().numpy(), want), f"seed {seed} chained"
+        n += 1
+    assert n >= 10
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunk", range(6))
 def test_kernels_match_oracle_on_random_graphs(chunk):
