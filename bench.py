@@ -122,24 +122,12 @@ def main():
     F.synth_fill(x, SEED, stream0=begin)
     torch.cuda.synchronize()
 
-    # plan selection (warm-up, untimed): when no variant is forced, time the library default against two
-    # close alternatives for two launches each and keep the fastest on THIS box
+    # plan selection (warm-up, untimed): when no variant is forced, let the library measure its candidate
+    # variants for this shape on THIS board (fz_program_tune, the FFTW_MEASURE of this library; which one
+    # wins differs from board to board) -- later launches without a variant use the winner
     tuned = None
-    if not args.no_autotune and not (args.lanes or args.unroll or args.block or args.flags) and ns >= (1 << 18):
-        cands = [F.make_variant(0, 0), F.make_variant(2, 16), F.make_variant(4, 8)]
-        best = None
-        for cv in cands:
-            prog.run_block(x, state=state, out=y, variant=cv)          # first touch / code load
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(2):
-                prog.run_block(x, state=state, out=y, variant=cv)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 2
-            if best is None or ms < best[0]:
-                best = (ms, cv)
-        variant = best[1]
+    if not args.no_autotune and not (args.lanes or args.unroll or args.block or args.flags):
+        variant, _ = prog.tune(x, state=state, out=y)
         tuned = prog.kernel_name(variant, ns, T)
         state.zero_()
 
@@ -203,13 +191,16 @@ def main():
         y2 = torch.empty(shp, dtype=torch.float32, device=dev)
         st2 = torch.zeros((prog.n_state, ns2), dtype=torch.float32, device=dev)
         F.synth_fill(x2, SEED)
+        v2 = None
+        if tuned is not None:
+            v2, _ = prog.tune(x2, state=st2, out=y2)
         for _ in range(20):
-            prog.run_block(x2, state=st2, out=y2)
+            prog.run_block(x2, state=st2, out=y2, variant=v2)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(200):
-            prog.run_block(x2, state=st2, out=y2)
+            prog.run_block(x2, state=st2, out=y2, variant=v2)
         e1.record()
         torch.cuda.synchronize()
         ms2 = e0.elapsed_time(e1) / 200
@@ -217,7 +208,7 @@ def main():
         cfg2 = {"workload": f"6-stage DF1 cascade, {ns2} streams x {T}-sample block (BASELINE configs[1])",
                 "steps": 200, "warmup": 20, "avg_launch_ms": round(ms2, 4), "Msamples_per_s": round(ns2 * T / ms2 / 1e3, 1),
                 "achieved_GBs": round(b2 / ms2 / 1e6, 1), "frac": round(b2 / ms2 / 1e6 / HBM_PEAK_GBS, 4),
-                "kernel": prog.kernel_name(None, ns2, T)}
+                "kernel": prog.kernel_name(v2, ns2, T)}
         del x2, y2, st2
 
     # copy-kernel yardstick (same bytes in + out), rank 0 only

@@ -328,6 +328,15 @@ public:
       detail::check(fz_bank_process_tiled(bank_, in_dev, out_dev, n_samples, tile_streams, v, hip_stream));
    }
    uint32_t recommended_tile_streams() const { return fz_recommended_tile_streams(prog_.get()); }
+   // measure the kernel variants for this shape on these buffers once and keep the fastest for later
+   // process()/process_tiled() calls (fz_program_tune); the bank's state advances: reset() afterwards
+   fz_variant tune(const float* in_dev, float* out_dev, uint32_t n_samples, uint32_t tile_streams = 0, void* hip_stream = nullptr)
+   {
+      refresh_refs();
+      fz_variant v{0, 0, 0, 0};
+      detail::check(fz_bank_tune(bank_, in_dev, out_dev, n_samples, tile_streams, hip_stream, &v, nullptr));
+      return v;
+   }
    void process_host(const float* in_host, float* out_host, uint32_t n_samples)
    {
       refresh_refs();

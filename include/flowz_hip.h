@@ -173,6 +173,11 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
                                    wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */
 /* bits 8..11 of flags: minimum waves per SIMD requested from the register allocator (0 = none) */
 #define FZ_VF_MIN_WAVES(n) (((uint32_t)(n) & 15u) << 8)
+/* bits 20..22 of flags: at most n workgroups per CU (the kernel pads its LDS); 0 = as many as fit.
+ * Fewer, fatter waves keep fewer frame tiles in flight: which occupancy streams fastest from HBM depends
+ * on the board -- let fz_program_tune measure it                                                   */
+#define FZ_VF_MAX_WG(n) (((uint32_t)(n) & 7u) << 20)
+/* bits 12..14 / 16..18: cache policy of frame loads / stores (experiment knob, see the kernel source) */
 
 int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */
 /* symbol of the variant's kernel as profilers show it, e.g. "fz_block_kernel_p2u32b256f0"; the
@@ -215,6 +220,16 @@ int fz_run_block_tiled(fz_program* p, const float* in, float* out, float* state,
 /* tile_streams that makes the row segments ~32 KiB for this graph's frame widths (power of two) */
 uint32_t fz_recommended_tile_streams(const fz_program* p);
 
+/* Plan selection (what FFTW_MEASURE is to FFTW): time the candidate kernel variants of this program
+ * for this shape on the caller's own device buffers and remember the fastest; later fz_run_block /
+ * fz_run_block_tiled / fz_bank_process* calls with the same (n_streams, tile_streams) on this device and
+ * variant == NULL use it.  All variants compute bit-identical results.  The buffers are used as by
+ * fz_run_block_tiled (tile_streams 0: time-major) for a few dozen blocks: `out` is overwritten and
+ * `state` advances -- reset it afterwards.  chosen / chosen_ms (may be NULL): the winner and its time
+ * per block.  Synchronises hip_stream.                                                            */
+int fz_program_tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+                    uint32_t n_samples, uint32_t tile_streams, void* hip_stream, fz_variant* chosen, float* chosen_ms);
+
 /* ------------------------------------------------------------------------------------------
  * fz_bank -- device-resident closure state for n_streams streams: the `state_` member of
  * stateful_lambda (flowz.hpp:1190-1191).  clone == copying the closure (snapshot, :1206).
@@ -234,6 +249,9 @@ int  fz_bank_process(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n
 /* fz_bank_process with stream-tiled frames (see fz_run_block_tiled) */
 int  fz_bank_process_tiled(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples,
                            uint32_t tile_streams, const fz_variant* v, void* hip_stream);
+/* fz_program_tune on the bank's own state and per-stream coefficients (the state advances: fz_bank_reset) */
+int  fz_bank_tune(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples, uint32_t tile_streams,
+                  void* hip_stream, fz_variant* chosen, float* chosen_ms);
 int  fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint32_t n_samples);
 /* the same with float64 result frames (FZ_VF_OUT_F64): what a closure with double literals returns
  * in the reference (tuple<double>, flowz.hpp:1225-1229 with the ResultType of test/tests.cpp:201) */

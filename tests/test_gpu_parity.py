@@ -685,3 +685,30 @@ def test_large_graph_64_stages_320_coefficients(torch_cuda, F):
         got, _ = run_gpu(torch_cuda, F, prog, x, variant=v)
         assert ndiff(got, want) == 0
     assert np.isfinite(want).all()
+
+
+def test_tune_picks_a_plan_and_results_do_not_change(torch_cuda, F):
+    """fz_program_tune: the measured plan is used by later launches without a variant; every candidate
+    computes the same bits."""
+    torch = torch_cuda
+    ns, T = 1 << 18, 64
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    x = torch.empty((ns // 8192, T, 8192, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED)
+    ref, _ = prog.run_block(x, variant=F.make_variant(1, 8))
+    chosen, ms = prog.tune(x)
+    assert ms > 0 and chosen.streams_per_lane in (0, 1, 2, 4)
+    got, _ = prog.run_block(x)                                   # planned variant
+    assert torch.equal(got, ref)
+    got2, _ = prog.run_block(x, variant=chosen)
+    assert torch.equal(got2, ref)
+    sample = _sample_ids(ns, 24, 5)
+    xs = F.from_tiled(x)[:, sample].cpu().numpy()
+    assert ndiff(F.from_tiled(got)[:, sample].cpu().numpy(), C.df1_cascade([G.STABLE] * 6, xs)) == 0
+    # a few streams: the stage-packed candidates
+    x2 = torch.empty((T, 4096, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x2, SEED + 1)
+    r2, _ = prog.run_block(x2, variant=F.make_variant(1, 8, 256, F.C.FZ_VF_NO_STAGE_PACK))
+    prog.tune(x2)
+    g2, _ = prog.run_block(x2)
+    assert torch.equal(g2, r2)

@@ -25,6 +25,11 @@ class NoDeviceError(FlowzError):
 FZ_OK, FZ_E_INVALID, FZ_E_GRAPH, FZ_E_NO_DEVICE, FZ_E_HIP, FZ_E_COMPILE, FZ_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 FZ_OP_ADD, FZ_OP_SUB, FZ_OP_MUL, FZ_OP_DIV, FZ_OP_NEG = 1, 2, 3, 4, 5
 FZ_VF_NO_NT, FZ_VF_NO_XCD_REMAP, FZ_VF_SLP, FZ_VF_STAGE_PACK, FZ_VF_NO_STAGE_PACK, FZ_VF_OUT_F64 = 1, 2, 4, 8, 16, 64
+
+
+def FZ_VF_MAX_WG(n):
+    """at most n workgroups per CU (flags bits 20..22)"""
+    return (int(n) & 7) << 20
 IR_KINDS = {1: "input", 2: "const", 3: "param", 4: "delay", 5: "add", 6: "sub", 7: "mul", 8: "div", 9: "neg"}
 
 
@@ -86,6 +91,7 @@ def _load():
         "fz_program_source": (ctypes.c_long, [P, ctypes.POINTER(Variant), ctypes.c_char_p, ctypes.c_size_t]),
         "fz_run_block": (ctypes.c_int, [P, P, P, P, P, u64, u32, ctypes.POINTER(Variant), P]),
         "fz_run_block_tiled": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, ctypes.POINTER(Variant), P]),
+        "fz_program_tune": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, P, ctypes.POINTER(Variant), ctypes.POINTER(f32)]),
         "fz_recommended_tile_streams": (u32, [P]),
         "fz_bank_create": (ctypes.c_int, [P, u64, ctypes.POINTER(P)]),
         "fz_bank_clone": (ctypes.c_int, [P, ctypes.POINTER(P)]),
@@ -95,6 +101,7 @@ def _load():
         "fz_bank_state_device": (P, [P]),
         "fz_bank_process": (ctypes.c_int, [P, P, P, u32, ctypes.POINTER(Variant), P]),
         "fz_bank_process_tiled": (ctypes.c_int, [P, P, P, u32, u32, ctypes.POINTER(Variant), P]),
+        "fz_bank_tune": (ctypes.c_int, [P, P, P, u32, u32, P, ctypes.POINTER(Variant), ctypes.POINTER(f32)]),
         "fz_bank_process_host": (ctypes.c_int, [P, P, P, u32]),
         "fz_bank_process_host_f64": (ctypes.c_int, [P, P, P, u32]),
         "fz_device_count": (ctypes.c_int, []),

@@ -193,4 +193,12 @@ int fz_run_block_tiled(fz_program* p, const float* in, float* out, float* state,
       return launch(p, in, out, state, params, n_streams, n_samples, v, hip_stream, tile_streams);)
 }
 
+int fz_program_tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+                    uint32_t n_samples, uint32_t tile_streams, void* hip_stream, fz_variant* chosen, float* chosen_ms)
+{
+   FZ_GUARD(
+      if (!p) fail(FZ_E_INVALID, "null program");
+      return tune(p, in, out, state, params, n_streams, n_samples, tile_streams, hip_stream, chosen, chosen_ms);)
+}
+
 }  // extern "C"

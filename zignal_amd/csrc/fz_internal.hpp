@@ -7,6 +7,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "flowz_hip.h"
@@ -152,6 +153,9 @@ struct fz_program {
    fz::Graph g;
    std::mutex mu;
    std::map<fz::Variant, std::shared_ptr<fz::Kernel>> kernels;
+   // measured plans (fz_program_tune): (n_streams, tile_streams, device) -> the variant to use when the
+   // caller passes none
+   std::map<std::tuple<uint64_t, uint32_t, int>, fz_variant> plans;
 };
 
 namespace fz {
@@ -161,5 +165,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* v, uint64_t n_streams,
 std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out);
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params,
            uint64_t n_streams, uint32_t n_samples, const fz_variant* v, void* stream, uint32_t tile_streams = 0);
+int tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+         uint32_t n_samples, uint32_t tile_streams, void* stream, fz_variant* chosen, float* chosen_ms);
 int device_count();
 }  // namespace fz

@@ -254,6 +254,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
 {
    const Graph& g = p->g;
    if (n_streams == 0 || n_samples == 0) return FZ_OK;      // an empty block: nothing to evaluate, state unchanged
+   if (n_samples == 0xFFFFFFFFu) fail(FZ_E_INVALID, "n_samples must be below 2^32 - 1");
    if (!out) fail(FZ_E_INVALID, "out is null");
    if (g.n_in && !in) fail(FZ_E_INVALID, "in is null but the graph has input wires");
    if (g.n_state && !state) fail(FZ_E_INVALID, "state is null but the graph has delay lines");
@@ -268,6 +269,17 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    if (n_streams >= (1ull << 32)) fail(FZ_E_UNSUPPORTED, "more than 2^32 streams per launch: shard the streams");
    if (tile_streams && n_streams % tile_streams) fail(FZ_E_INVALID, "n_streams must be a multiple of tile_streams");
    require_device();
+   fz_variant planned;
+   if (!uv) {                                               // a measured plan for this shape on this device?
+      int dev = 0;
+      FZ_HIP(hipGetDevice(&dev));
+      std::lock_guard<std::mutex> lock(p->mu);
+      auto it = p->plans.find(std::make_tuple(n_streams, tile_streams, dev));
+      if (it != p->plans.end()) {
+         planned = it->second;
+         uv = &planned;
+      }
+   }
    Variant v = resolve_variant(g, uv, n_streams, n_samples);
    if (tile_streams) {
       // a workgroup must not straddle tiles: shrink the lane packing / block until it divides
@@ -300,6 +312,92 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       std::fprintf(stderr, "[flowz_hip] launched grid=%u block=%u P=%u U=%u flags=%u n_streams=%llu n_samples=%u kernarg=%zu B\n",
                    grid, v.block, v.P, v.U, v.flags, (unsigned long long)n_streams, n_samples, size);
    }
+   return FZ_OK;
+}
+
+// ---- plan selection ------------------------------------------------------------------------------------------
+// The variants differ by a few percent, and which one wins depends on the board (measured: the same
+// variant is +5 % on one MI355X of the pool and -3 % on the next), so -- like FFTW_MEASURE -- time the
+// candidates on the caller's own buffers once and remember the winner for this shape.
+int tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+         uint32_t n_samples, uint32_t tile_streams, void* stream, fz_variant* chosen, float* chosen_ms)
+{
+   const Graph& g = p->g;
+   if (!n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_tune: empty block");
+   require_device();
+   if (tile_streams == 0 || tile_streams >= n_streams) tile_streams = 0;
+   const Variant d = resolve_variant(g, nullptr, n_streams, n_samples);
+   std::vector<fz_variant> cands{fz_variant{0, 0, 0, 0}};
+   if (d.flags & FZ_VF_STAGE_PACK) {
+      cands.push_back(fz_variant{1, 24, 0, FZ_VF_STAGE_PACK});
+   } else if (d.P == 2) {            // many streams, narrow frames: lane packing x prefetch depth x workgroups per CU
+      cands.push_back(fz_variant{2, 16, 0, 0});
+      cands.push_back(fz_variant{4, 8, 0, 0});
+      cands.push_back(fz_variant{2, 16, 256, FZ_VF_MAX_WG(2)});
+      cands.push_back(fz_variant{2, 32, 256, FZ_VF_MAX_WG(2)});
+      cands.push_back(fz_variant{4, 8, 256, FZ_VF_MAX_WG(1)});
+      cands.push_back(fz_variant{4, 12, 256, FZ_VF_MAX_WG(1)});
+      cands.push_back(fz_variant{4, 16, 256, FZ_VF_MAX_WG(1)});
+   } else if (n_streams >= (1u << 17)) {
+      cands.push_back(fz_variant{1, 16, 256, FZ_VF_MAX_WG(1)});
+      cands.push_back(fz_variant{1, 8, 256, FZ_VF_MAX_WG(1)});
+      cands.push_back(fz_variant{1, 16, 256, FZ_VF_MAX_WG(2)});
+      if (n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) cands.push_back(fz_variant{2, 16, 0, 0});
+   }
+   hipEvent_t e0, e1;
+   FZ_HIP(hipEventCreate(&e0));
+   FZ_HIP(hipEventCreate(&e1));
+   float best_ms = 0.f;
+   int best = -1;
+   std::string first_error;
+   // the default is measured twice: the first pass only brings the clocks and the memory system up to
+   // speed (whoever runs first would otherwise look slower than it is)
+   for (size_t cc = 0; cc <= cands.size(); ++cc) {
+      const bool warmup = cc == 0;
+      const size_t c = warmup ? 0 : cc - 1;
+      try {
+         launch(p, in, out, state, params, n_streams, n_samples, &cands[c], stream, tile_streams);   // build, load, first touch
+         // one launch to size the measurement (>= ~25 ms of kernel time: sub-millisecond kernels need
+         // dozens of launches before their timing settles), then the measurement proper
+         float ms = 0.f;
+         int reps = 1;
+         for (int pass = 0; pass < 2; ++pass) {
+            FZ_HIP(hipEventRecord(e0, (hipStream_t)stream));
+            for (int r = 0; r < reps; ++r) launch(p, in, out, state, params, n_streams, n_samples, &cands[c], stream, tile_streams);
+            FZ_HIP(hipEventRecord(e1, (hipStream_t)stream));
+            FZ_HIP(hipEventSynchronize(e1));
+            FZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+            ms /= (float)reps;
+            if (pass == 0) reps = std::max(3, std::min(100, (int)(25.f / std::max(ms, 1e-3f))));
+         }
+         if (std::getenv("FLOWZ_HIP_DEBUG"))
+            std::fprintf(stderr, "[flowz_hip] tune P=%u U=%u block=%u flags=%u: %.4f ms\n", cands[c].streams_per_lane,
+                         cands[c].unroll, cands[c].block_threads, cands[c].flags, ms);
+         if (!warmup && (best < 0 || ms < best_ms)) {
+            best = (int)c;
+            best_ms = ms;
+         }
+      } catch (const Error& er) {                          // a candidate this graph / shape does not allow
+         if (er.code == FZ_E_HIP || er.code == FZ_E_NO_DEVICE) {
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            throw;
+         }
+         if (first_error.empty()) first_error = er.msg;
+      }
+   }
+   (void)hipEventDestroy(e0);
+   (void)hipEventDestroy(e1);
+   if (best < 0) fail(FZ_E_INVALID, "fz_program_tune: no variant could run: " + first_error);
+   int dev = 0;
+   FZ_HIP(hipGetDevice(&dev));
+   {
+      std::lock_guard<std::mutex> lock(p->mu);
+      if (best == 0) p->plans.erase(std::make_tuple(n_streams, tile_streams, dev));
+      else p->plans[std::make_tuple(n_streams, tile_streams, dev)] = cands[(size_t)best];
+   }
+   if (chosen) *chosen = cands[(size_t)best];
+   if (chosen_ms) *chosen_ms = best_ms;
    return FZ_OK;
 }
 
@@ -542,6 +640,17 @@ int fz_bank_process_tiled(fz_bank* b, const float* in_dev, float* out_dev, uint3
       const Graph& g = b->prog->g;
       return fz::launch(b->prog, in_dev, out_dev, g.n_state ? b->state : nullptr, b->params, b->n_streams, n_samples, v,
                         hip_stream, tile_streams);)
+}
+
+int fz_bank_tune(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples, uint32_t tile_streams, void* hip_stream,
+                 fz_variant* chosen, float* chosen_ms)
+{
+   FZ_GUARD(
+      if (!b) fail(FZ_E_INVALID, "null bank");
+      check_bank_device(b);
+      const Graph& g = b->prog->g;
+      return fz::tune(b->prog, in_dev, out_dev, g.n_state ? b->state : nullptr, b->params, b->n_streams, n_samples, tile_streams,
+                      hip_stream, chosen, chosen_ms);)
 }
 
 static int bank_process_host(fz_bank* b, const float* in_host, void* out_host, uint32_t n_samples, bool f64)

@@ -334,6 +334,37 @@ class Program:
         return out, state
 
 
+def _tune(self, x, state=None, params=None, out=None):
+    """Measure the candidate kernel variants for this shape on these buffers (fz_program_tune) and
+    remember the fastest: later run_block calls of the same shape without a variant use it.
+    x as for run_block; `state` advances (a scratch one is used when None), `out` is overwritten.
+    Returns (Variant, milliseconds per block)."""
+    import torch
+
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    if x.dim() == 4:
+        n_tiles, T, tile, _ = x.shape
+        ns = n_tiles * tile
+        oshape = (n_tiles, T, tile, self.n_out)
+    else:
+        T, ns, _ = x.shape
+        tile = 0
+        oshape = (T, ns, self.n_out)
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    if state is None:
+        state = torch.zeros((max(self.n_state, 1), ns), dtype=torch.float32, device=x.device)
+    pp = params.data_ptr() if self.n_param else None
+    chosen, ms = Variant(0, 0, 0, 0), ctypes.c_float(0)
+    C.check(C.lib.fz_program_tune(self._h, x.data_ptr() if self.n_in else None, out.data_ptr(),
+                                  state.data_ptr() if self.n_state else None, pp, ns, T, tile,
+                                  torch.cuda.current_stream().cuda_stream, ctypes.byref(chosen), ctypes.byref(ms)))
+    return chosen, float(ms.value)
+
+
+Program.tune = _tune
+
+
 def to_tiled(x, tile_streams: int):
     """time-major [T, n_streams, w] -> stream-tiled [n_tiles, T, tile_streams, w] (torch or numpy)."""
     T, ns, w = x.shape
