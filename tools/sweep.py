@@ -50,6 +50,10 @@ def main():
     b_alg = ns * (4 * T * (prog.n_in + prog.n_out) + 8 * prog.n_state + 4 * prog.n_param)
     vs = []
     for s in a.variants:
+        if s == "tune":                          # the plan fz_program_tune selects on this box
+            cv, _ = prog.tune(x, state=state, params=params, out=y)
+            vs.append((f"tune->{cv.streams_per_lane},{cv.unroll},{cv.block_threads},{cv.flags}", cv))
+            continue
         t = [int(v) for v in s.split(",")]
         t += [0] * (4 - len(t))
         vs.append((s, F.make_variant(*t)))

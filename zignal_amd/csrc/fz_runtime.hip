@@ -204,7 +204,9 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    if (!reqP && v.P == 2 && reg_state > 36) v.P = 1;
    // prefetch depth in time steps: 16 rows in flight per lane; 32 once the chip is oversubscribed
    // with packed lanes (fewer, fatter waves: 2 per SIMD)
-   v.U = reqU ? reqU : ((v.P == 2 && n_streams >= (1u << 19) && g.n_in == 1 && g.n_out == 1) ? 32 : 16);
+   // (per-stream coefficients sit in VGPRs too: with 31 of them the deep prefetch costs 10 %)
+   const uint32_t reg_values = (reg_state + g.n_param) * v.P;
+   v.U = reqU ? reqU : ((v.P == 2 && n_streams >= (1u << 19) && g.n_in == 1 && g.n_out == 1 && reg_values <= 40) ? 32 : 16);
    if (!reqU && reg_state * v.P > 60) v.U = 8;
    if (!g.far_lines.empty()) {
       // far (HBM ring) reads are prefetched one chunk ahead: the chunk must be shorter than half the
