@@ -712,3 +712,32 @@ def test_tune_picks_a_plan_and_results_do_not_change(torch_cuda, F):
     prog.tune(x2)
     g2, _ = prog.run_block(x2)
     assert torch.equal(g2, r2)
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_host_frames_pipelined_path(torch_cuda, F, pinned):
+    """fz_bank_process_host on a long block: time chunks pipelined over three HIP streams (H2D, kernels,
+    D2H), pinned or pageable host memory; equal to the device-resident path, state carried on."""
+    torch = torch_cuda
+    ns, T = 16384, 2304                                   # 144 MiB each way: 5 chunks of 512 steps (ragged last one)
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    xd = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(xd, SEED + 51)
+    want, st = prog.run_block(xd)
+    x = torch.empty((T, ns, 1), dtype=torch.float32, pin_memory=pinned)
+    x.copy_(xd)
+    bank = prog.bank(ns)
+    y = bank.process_host(x if pinned else x.numpy())
+    y = y if pinned else torch.from_numpy(y)
+    assert torch.equal(y, want.cpu())
+    # second block continues from the carried state (short: the single round-trip path)
+    x2 = torch.empty((40, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x2, SEED + 52)
+    want2, _ = prog.run_block(x2, state=st)
+    y2 = bank.process_host(x2.cpu().numpy())
+    assert np.array_equal(y2, want2.cpu().numpy())
+    # float64 frames through the pipeline
+    bank.reset()
+    y64 = bank.process_host(x if pinned else x.numpy(), out_f64=True)
+    y64 = y64 if pinned else torch.from_numpy(y64)
+    assert torch.equal(y64, want.cpu().double())

@@ -499,6 +499,9 @@ struct fz_bank {
    float* stage_in = nullptr;
    float* stage_out = nullptr;
    size_t stage_in_cap = 0, stage_out_cap = 0;
+   // streams / events of the pipelined host path (created on first use)
+   hipStream_t s_h2d = nullptr, s_run = nullptr, s_d2h = nullptr;
+   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
 };
 
 extern "C" {
@@ -599,6 +602,11 @@ void fz_bank_destroy(fz_bank* b)
    (void)hipFree(b->params);
    (void)hipFree(b->stage_in);
    (void)hipFree(b->stage_out);
+   for (hipStream_t st : {b->s_h2d, b->s_run, b->s_d2h})
+      if (st) (void)hipStreamDestroy(st);
+   for (int i = 0; i < 2; ++i)
+      for (hipEvent_t e : {b->ev_in[i], b->ev_run[i], b->ev_out[i]})
+         if (e) (void)hipEventDestroy(e);
    delete b;
 }
 
@@ -655,36 +663,91 @@ int fz_bank_tune(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_sam
                       hip_stream, chosen, chosen_ms);)
 }
 
+static void ensure_stage(fz_bank* b, size_t ib, size_t ob)
+{
+   if (ib > b->stage_in_cap) {
+      (void)hipFree(b->stage_in);
+      b->stage_in = nullptr;
+      b->stage_in_cap = 0;
+      FZ_HIP(hipMalloc((void**)&b->stage_in, ib));
+      b->stage_in_cap = ib;
+   }
+   if (ob > b->stage_out_cap) {
+      (void)hipFree(b->stage_out);
+      b->stage_out = nullptr;
+      b->stage_out_cap = 0;
+      FZ_HIP(hipMalloc((void**)&b->stage_out, ob));
+      b->stage_out_cap = ob;
+   }
+}
+
+// Host frames in, host frames out.  Short blocks (the per-sample call protocol) take one synchronous
+// H2D / kernel / D2H round trip.  Long blocks are cut along TIME into chunks that flow through a
+// three-stage pipeline on three HIP streams -- H2D of chunk k+1, the kernel of chunk k and D2H of chunk
+// k-1 overlap (time-major frames: a time chunk is contiguous; the recurrence only orders the kernels,
+// which run back to back on one stream).  With pinned host memory (hipHostMalloc / hipHostRegister /
+// torch pin_memory) both PCIe directions run concurrently; pageable memory still works, HIP then
+// stages the copies itself.
 static int bank_process_host(fz_bank* b, const float* in_host, void* out_host, uint32_t n_samples, bool f64)
 {
    FZ_GUARD(
       if (!b || !out_host || !n_samples) fail(FZ_E_INVALID, "fz_bank_process_host: bad arguments");
       check_bank_device(b);
       const Graph& g = b->prog->g;
-      const size_t ib = (size_t)n_samples * b->n_streams * g.n_in * 4, ob = (size_t)n_samples * b->n_streams * g.n_out * (f64 ? 8 : 4);
-      if (ib > b->stage_in_cap) {
-         (void)hipFree(b->stage_in);
-         b->stage_in = nullptr;
-         b->stage_in_cap = 0;
-         FZ_HIP(hipMalloc((void**)&b->stage_in, ib));
-         b->stage_in_cap = ib;
-      }
-      if (ob > b->stage_out_cap) {
-         (void)hipFree(b->stage_out);
-         b->stage_out = nullptr;
-         b->stage_out_cap = 0;
-         FZ_HIP(hipMalloc((void**)&b->stage_out, ob));
-         b->stage_out_cap = ob;
-      }
-      if (ib) {
-         if (!in_host) fail(FZ_E_INVALID, "in_host is null but the graph has input wires");
-         FZ_HIP(hipMemcpy(b->stage_in, in_host, ib, hipMemcpyHostToDevice));
-      }
+      const size_t irow = (size_t)b->n_streams * g.n_in * 4, orow = (size_t)b->n_streams * g.n_out * (f64 ? 8 : 4);
+      if (irow && !in_host) fail(FZ_E_INVALID, "in_host is null but the graph has input wires");
       const fz_variant v64{0, 0, 0, FZ_VF_OUT_F64};
-      int rc = fz::launch(b->prog, g.n_in ? b->stage_in : nullptr, b->stage_out, g.n_state ? b->state : nullptr, b->params,
-                          b->n_streams, n_samples, f64 ? &v64 : nullptr, nullptr, 0);
-      if (rc != FZ_OK) return rc;
-      FZ_HIP(hipMemcpy(out_host, b->stage_out, ob, hipMemcpyDeviceToHost));
+      const fz_variant* uv = f64 ? &v64 : nullptr;
+      constexpr size_t kChunkBytes = 32u << 20;            // per direction and pipeline slot
+      const size_t row = std::max(irow, orow);
+      uint32_t chunk_t = (uint32_t)std::max<size_t>(1, kChunkBytes / std::max<size_t>(row, 1));
+      if ((size_t)n_samples * row <= 2 * kChunkBytes || chunk_t >= n_samples) {                    // one round trip
+         ensure_stage(b, irow * n_samples, orow * n_samples);
+         if (irow) FZ_HIP(hipMemcpy(b->stage_in, in_host, irow * n_samples, hipMemcpyHostToDevice));
+         int rc = fz::launch(b->prog, g.n_in ? b->stage_in : nullptr, b->stage_out, g.n_state ? b->state : nullptr, b->params,
+                             b->n_streams, n_samples, uv, nullptr, 0);
+         if (rc != FZ_OK) return rc;
+         FZ_HIP(hipMemcpy(out_host, b->stage_out, orow * n_samples, hipMemcpyDeviceToHost));
+         return FZ_OK;
+      }
+      if (chunk_t >= 64) chunk_t &= ~31u;                   // whole prefetch chunks
+      ensure_stage(b, 2 * irow * chunk_t, 2 * orow * chunk_t);
+      if (!b->s_h2d) {
+         FZ_HIP(hipStreamCreateWithFlags(&b->s_h2d, hipStreamNonBlocking));
+         FZ_HIP(hipStreamCreateWithFlags(&b->s_run, hipStreamNonBlocking));
+         FZ_HIP(hipStreamCreateWithFlags(&b->s_d2h, hipStreamNonBlocking));
+         for (int i = 0; i < 2; ++i) {
+            FZ_HIP(hipEventCreateWithFlags(&b->ev_in[i], hipEventDisableTiming));
+            FZ_HIP(hipEventCreateWithFlags(&b->ev_run[i], hipEventDisableTiming));
+            FZ_HIP(hipEventCreateWithFlags(&b->ev_out[i], hipEventDisableTiming));
+         }
+      }
+      FZ_HIP(hipDeviceSynchronize());                       // the bank's state may still be in use on other streams
+      const char* hin = reinterpret_cast<const char*>(in_host);
+      char* hout = reinterpret_cast<char*>(out_host);
+      uint32_t k = 0;
+      for (uint32_t t0 = 0; t0 < n_samples; t0 += chunk_t, ++k) {
+         const uint32_t nt = std::min(chunk_t, n_samples - t0);
+         const int slot = (int)(k & 1u);
+         float* din = reinterpret_cast<float*>(reinterpret_cast<char*>(b->stage_in) + (size_t)slot * irow * chunk_t);
+         float* dout = reinterpret_cast<float*>(reinterpret_cast<char*>(b->stage_out) + (size_t)slot * orow * chunk_t);
+         if (irow) {
+            if (k >= 2) FZ_HIP(hipStreamWaitEvent(b->s_h2d, b->ev_run[slot], 0));        // kernel k-2 has consumed this slot
+            FZ_HIP(hipMemcpyAsync(din, hin + (size_t)t0 * irow, irow * nt, hipMemcpyHostToDevice, b->s_h2d));
+            FZ_HIP(hipEventRecord(b->ev_in[slot], b->s_h2d));
+            FZ_HIP(hipStreamWaitEvent(b->s_run, b->ev_in[slot], 0));
+         }
+         if (k >= 2) FZ_HIP(hipStreamWaitEvent(b->s_run, b->ev_out[slot], 0));            // D2H k-2 has drained this slot
+         int rc = fz::launch(b->prog, g.n_in ? din : nullptr, dout, g.n_state ? b->state : nullptr, b->params, b->n_streams, nt, uv,
+                             b->s_run, 0);
+         if (rc != FZ_OK) return rc;
+         FZ_HIP(hipEventRecord(b->ev_run[slot], b->s_run));
+         FZ_HIP(hipStreamWaitEvent(b->s_d2h, b->ev_run[slot], 0));
+         FZ_HIP(hipMemcpyAsync(hout + (size_t)t0 * orow, dout, orow * nt, hipMemcpyDeviceToHost, b->s_d2h));
+         FZ_HIP(hipEventRecord(b->ev_out[slot], b->s_d2h));
+      }
+      FZ_HIP(hipStreamSynchronize(b->s_d2h));
+      FZ_HIP(hipStreamSynchronize(b->s_run));
       return FZ_OK;)
 }
 

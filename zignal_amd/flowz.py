@@ -365,6 +365,60 @@ def _tune(self, x, state=None, params=None, out=None):
 Program.tune = _tune
 
 
+class Bank:
+    """Device-resident closure state of n_streams streams of one program (fz_bank: the `state_` member of
+    the reference's stateful_lambda, flowz.hpp:1190-1191, times n_streams)."""
+
+    def __init__(self, prog: Program, n_streams: int):
+        self.prog, self.n_streams = prog, int(n_streams)
+        h = ctypes.c_void_p()
+        C.check(C.lib.fz_bank_create(prog._h, self.n_streams, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and C is not None:
+            C.lib.fz_bank_destroy(h)
+
+    def reset(self):
+        C.check(C.lib.fz_bank_reset(self._h))
+
+    def set_params(self, params):
+        """params: numpy float32 [n_param, n_streams]"""
+        import numpy as np
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        assert p.shape == (self.prog.n_param, self.n_streams)
+        C.check(C.lib.fz_bank_set_params_host(self._h, p.ctypes.data))
+
+    def process_host(self, x, out=None, out_f64: bool = False):
+        """Host frames in, host frames out (time-major [T, n_streams, n_in] float32 -> [T, n_streams, n_out]).
+        x / out: numpy arrays or CPU torch tensors; pinned tensors let both PCIe directions overlap with
+        the kernels (long blocks are pipelined in time chunks)."""
+        import numpy as np
+
+        is_torch = hasattr(x, "data_ptr")
+        T = int(x.shape[0])
+        if is_torch:
+            import torch
+            assert x.dtype == torch.float32 and x.is_contiguous() and not x.is_cuda
+            if out is None:
+                out = torch.empty((T, self.n_streams, self.prog.n_out), dtype=torch.float64 if out_f64 else torch.float32,
+                                  pin_memory=x.is_pinned())
+            xp, op = x.data_ptr(), out.data_ptr()
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            if out is None:
+                out = np.empty((T, self.n_streams, self.prog.n_out), np.float64 if out_f64 else np.float32)
+            xp, op = x.ctypes.data, out.ctypes.data
+        assert tuple(x.shape[1:]) in ((self.n_streams, self.prog.n_in), (self.n_streams,)) or self.prog.n_in == 0
+        fn = C.lib.fz_bank_process_host_f64 if out_f64 else C.lib.fz_bank_process_host
+        C.check(fn(self._h, xp if self.prog.n_in else None, op, T))
+        return out
+
+
+Program.bank = lambda self, n_streams: Bank(self, n_streams)
+
+
 def to_tiled(x, tile_streams: int):
     """time-major [T, n_streams, w] -> stream-tiled [n_tiles, T, tile_streams, w] (torch or numpy)."""
     T, ns, w = x.shape
