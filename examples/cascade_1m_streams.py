@@ -18,6 +18,8 @@ n_streams, n_samples = 1 << 20, 1024
 tile = prog.recommended_tile_streams()
 x = torch.empty((n_streams // tile, n_samples, tile, 1), device="cuda")
 F.synth_fill(x, seed=1)
+plan, ms = prog.tune(x)                                        # optional: measure the kernel variants on this board once
+print(f"plan: {plan.streams_per_lane} streams/lane, unroll {plan.unroll}, flags {plan.flags:#x}: {ms:.3f} ms per block")
 y, state = prog.run_block(x)                                   # one launch; state carries to the next block
 y2, state = prog.run_block(x, state=state)
 torch.cuda.synchronize()
