@@ -741,3 +741,13 @@ def test_host_frames_pipelined_path(torch_cuda, F, pinned):
     y64 = bank.process_host(x if pinned else x.numpy(), out_f64=True)
     y64 = y64 if pinned else torch.from_numpy(y64)
     assert torch.equal(y64, want.cpu().double())
+
+
+def test_copy_probe_copies(torch_cuda, F):
+    torch = torch_cuda
+    for n in (4, 1020, 4096 + 8, 1 << 22):
+        a = torch.randn(n, device="cuda")
+        b = torch.zeros(n + 4, device="cuda")
+        F.copy_probe(a, b[:n])
+        torch.cuda.synchronize()
+        assert torch.equal(a, b[:n]) and float(b[n:].abs().sum()) == 0.0

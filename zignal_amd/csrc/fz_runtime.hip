@@ -473,12 +473,20 @@ __global__ void __launch_bounds__(256) fz_synth_fill_kernel(float* dst, unsigned
    }
 }
 
+// one-shot float4 copy, four independent nt loads in flight per lane before the stores: the fastest
+// plain copy of profiles/r01/hbm_copy_patterns_microbench.txt (5.8-6.0 TB/s; a 2048-block grid-stride
+// loop and hipMemcpyDtoD stay at 4.8-4.9)
 __global__ void __launch_bounds__(256) fz_copy_kernel(const fzr_f4* __restrict__ src, fzr_f4* __restrict__ dst,
                                                       unsigned long long n4)
 {
-   unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
-   const unsigned long long stride = (unsigned long long)gridDim.x * 256u;
-   for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+   const unsigned long long base = (unsigned long long)blockIdx.x * 1024u + threadIdx.x;
+   fzr_f4 v[4];
+#pragma unroll
+   for (int k = 0; k < 4; ++k)
+      if (base + 256u * k < n4) v[k] = __builtin_nontemporal_load(src + base + 256u * k);
+#pragma unroll
+   for (int k = 0; k < 4; ++k)
+      if (base + 256u * k < n4) __builtin_nontemporal_store(v[k], dst + base + 256u * k);
 }
 
 }  // namespace fz
@@ -541,7 +549,9 @@ int fz_copy_probe(const float* src, float* dst, uint64_t n_floats, void* hip_str
    FZ_GUARD(
       if (!src || !dst || (n_floats & 3)) fail(FZ_E_INVALID, "fz_copy_probe: need non-null pointers and n_floats % 4 == 0");
       require_device();
-      hipLaunchKernelGGL(fz_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)hip_stream,
+      const unsigned long long n4 = n_floats / 4;
+      if (n4 > 1024ull * 0x7FFFFFFFull) fail(FZ_E_INVALID, "fz_copy_probe: buffer too large");
+      hipLaunchKernelGGL(fz_copy_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)hip_stream,
                          (const fzr_f4*)src, (fzr_f4*)dst, (unsigned long long)(n_floats / 4));
       FZ_HIP(hipGetLastError());
       return FZ_OK;)
