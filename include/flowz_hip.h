@@ -168,6 +168,8 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
                                    segment j at t-j, and segments i, i+K/2 share one v_pk_* per node; chosen
                                    automatically below 2^18 streams when fz_info.stage_packable          */
        FZ_VF_NO_STAGE_PACK = 16u,
+       FZ_VF_PREFETCH3 = 32u,   /* three input chunk buffers: loads run two chunks (2 x unroll steps) ahead
+                                   (not with delay lines beyond 256 samples)                              */
        FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
                                    float*): the results of graphs with double literals leave un-narrowed, float
                                    wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */

@@ -751,3 +751,17 @@ def test_copy_probe_copies(torch_cuda, F):
         F.copy_probe(a, b[:n])
         torch.cuda.synchronize()
         assert torch.equal(a, b[:n]) and float(b[n:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("T", [1, 15, 16, 17, 33, 48, 49, 80, 100])
+def test_triple_buffered_prefetch_variant(torch_cuda, F, T):
+    """FZ_VF_PREFETCH3 (loads two chunks ahead): every chunk-count remainder, plain and stage-packed."""
+    ns = 640
+    x = O.synth_input(SEED + 61, np.arange(ns), T)
+    want = C.df1_cascade([G.STABLE] * 6, x)
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    P3 = F.C.FZ_VF_PREFETCH3
+    for v in (F.make_variant(2, 16, 256, P3), F.make_variant(1, 16, 256, P3 | F.C.FZ_VF_STAGE_PACK), F.make_variant(4, 4, 256, P3),
+              F.make_variant(1, 8, 256, P3 | F.C.FZ_VF_NO_STAGE_PACK)):
+        got, _ = run_gpu(torch_cuda, F, prog, x, variant=v)
+        assert ndiff(got, want) == 0

@@ -212,6 +212,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // far (HBM ring) reads are prefetched one chunk ahead: the chunk must be shorter than half the
       // smallest far delay (kFarMinDelay = 32)
       if (reqU > 16) fail(FZ_E_INVALID, "graphs with delays beyond LDS need unroll <= 16");
+      if (v.flags & FZ_VF_PREFETCH3) fail(FZ_E_INVALID, "FZ_VF_PREFETCH3 is not available with delays beyond LDS");
       v.U = std::min(v.U, 16u);
    }
    // stage packing: one stream per lane, pairs of isomorphic graph segments in one v_pk_* (fz_split.cpp)
