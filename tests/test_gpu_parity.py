@@ -765,3 +765,36 @@ def test_triple_buffered_prefetch_variant(torch_cuda, F, T):
               F.make_variant(1, 8, 256, P3 | F.C.FZ_VF_NO_STAGE_PACK)):
         got, _ = run_gpu(torch_cuda, F, prog, x, variant=v)
         assert ndiff(got, want) == 0
+
+
+def test_block_launches_can_be_captured_in_a_hip_graph(torch_cuda, F):
+    """fz_run_block only enqueues (no allocation, no synchronisation once the kernel is loaded): a chain of
+    block launches captured in a hipGraph replays with identical results."""
+    torch = torch_cuda
+    ns, T, nblk = 4096, 48, 6
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    x = torch.empty((nblk, T, ns, 1), device="cuda")
+    F.synth_fill(x.view(nblk * T, ns, 1), SEED + 71)
+    y = torch.empty_like(x)
+    st = torch.zeros((prog.n_state, ns), device="cuda")
+
+    def blocks():
+        for k in range(nblk):
+            prog.run_block(x[k], state=st, out=y[k])
+    blocks()
+    torch.cuda.synchronize()
+    ref, st_ref = y.clone(), st.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    st.zero_()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            blocks()
+    st.zero_()
+    y.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref) and torch.equal(st, st_ref)
+    want = C.df1_cascade([G.STABLE] * 6, x.view(nblk * T, ns, 1)[:, :64].cpu().numpy())
+    assert ndiff(y.view(nblk * T, ns, 1)[:, :64].cpu().numpy(), want) == 0
