@@ -280,6 +280,14 @@ int fz_rbj_lowpass(const float* freq_dev, const float* q_dev, float sample_rate,
                    float* raw6_dev, float* df1_dev, void* hip_stream);
 /* plain float4 copy kernel: the measured-copy-bandwidth yardstick of the roofline report      */
 int fz_copy_probe(const float* src_dev, float* dst_dev, uint64_t n_floats, void* hip_stream);
+/* Layout adapter for callers that hold one contiguous buffer per stream, as every closure of the
+ * reference does (the sample loop of test/benchmark.cpp:137-147):
+ *   stream-major  [n_streams][n_samples][n_wires]   <->   frames [n_samples][n_streams][n_wires]
+ * (frames stream-tiled as fz_run_block_tiled takes them when tile_streams != 0: a multiple of 64 that
+ * divides n_streams).  to_stream_major == 0: src is stream-major, dst are frames; != 0: the reverse.
+ * One pass through LDS patches, reads and writes in 4 KiB runs; n_wires <= 64.                       */
+int fz_transpose_frames(const float* src_dev, float* dst_dev, uint64_t n_streams, uint32_t n_samples, uint32_t n_wires,
+                        uint32_t tile_streams, int to_stream_major, void* hip_stream);
 
 #ifdef __cplusplus
 }

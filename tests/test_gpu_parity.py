@@ -798,3 +798,31 @@ def test_block_launches_can_be_captured_in_a_hip_graph(torch_cuda, F):
     assert torch.equal(y, ref) and torch.equal(st, st_ref)
     want = C.df1_cascade([G.STABLE] * 6, x.view(nblk * T, ns, 1)[:, :64].cpu().numpy())
     assert ndiff(y.view(nblk * T, ns, 1)[:, :64].cpu().numpy(), want) == 0
+
+
+@pytest.mark.parametrize("w", [1, 2, 3, 4, 7])
+def test_stream_major_adapter(torch_cuda, F, w):
+    """fz_transpose_frames: [stream][t][wire] <-> frames, time-major and tiled, ragged sizes."""
+    torch = torch_cuda
+    for ns, T, tile in ((64, 64, 0), (200, 130, 0), (1000, 33, 0), (4096, 70, 1024), (2048, 1100, 256), (5, 3, 0)):
+        x = torch.randn((ns, T, w), device="cuda")
+        fr = F.frames_from_stream_major(x, tile)
+        want = x.permute(1, 0, 2).contiguous()                     # [T, ns, w]
+        got = F.from_tiled(fr) if tile else fr
+        assert torch.equal(got, want), (ns, T, tile)
+        back = F.frames_to_stream_major(fr)
+        assert torch.equal(back, x), (ns, T, tile)
+
+
+def test_stream_major_buffers_end_to_end(torch_cuda, F):
+    """One contiguous buffer per stream in (the reference's calling convention), the same out: adapter,
+    block kernel, adapter -- against the compiled oracle in its stream-major layout."""
+    torch = torch_cuda
+    ns, T = 8192, 300
+    xs = np.ascontiguousarray(np.transpose(O.synth_input(SEED + 81, np.arange(ns), T), (1, 0, 2)))     # [ns, T, 1]
+    want = C.df1_cascade([G.STABLE] * 6, xs, stream_major=True)
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    fr = F.frames_from_stream_major(torch.from_numpy(xs).cuda(), 1024)
+    y, _ = prog.run_block(fr)
+    got = F.frames_to_stream_major(y).cpu().numpy()
+    assert ndiff(got, want) == 0

@@ -109,6 +109,7 @@ def _load():
         "fz_synth_fill": (ctypes.c_int, [P, u64, u32, u32, u32, u64, u64, u32, P]),
         "fz_rbj_lowpass": (ctypes.c_int, [P, P, f32, u64, P, P, P]),
         "fz_copy_probe": (ctypes.c_int, [P, P, u64, P]),
+        "fz_transpose_frames": (ctypes.c_int, [P, P, u64, u32, u32, u32, ctypes.c_int, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)       # AttributeError here == the library does not export the ABI

@@ -492,6 +492,112 @@ __global__ void __launch_bounds__(256) fz_copy_kernel(const fzr_f4* __restrict__
       if (base + 256u * k < n4) __builtin_nontemporal_store(v[k], dst + base + 256u * k);
 }
 
+// Stream-major <-> frame layout adapter.  Callers of the reference hold one contiguous sample buffer
+// per closure ([stream][t][wire], the loop of test/benchmark.cpp:137-147); the block kernel wants
+// frames with the stream index fastest ([t][stream][wire], optionally tiled).  One workgroup moves a
+// 64-stream x CT-column patch (CT = whole frames, <= 64 floats) through LDS so that both the reads and
+// the writes are contiguous runs: rows of the stream-major side, (stream, wire) runs of the frame side.
+template <bool TO_STREAM_MAJOR>
+__global__ void __launch_bounds__(256) fz_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           unsigned long long n_streams, unsigned n_samples, unsigned W,
+                                                           unsigned tile_streams, unsigned nt /* frames per patch */,
+                                                           unsigned gx, unsigned gy)
+{
+   __shared__ float patch[64][65];
+   // workgroups that run at the same time cover a 16 x 16 block of patches, so that each side sees
+   // 4 KiB runs (16 patches x 256 B) instead of isolated 256 B pieces
+   constexpr unsigned SX = 16, SY = 16;
+   const unsigned sbx = (gx + SX - 1) / SX;
+   const unsigned long long b = blockIdx.x;
+   const unsigned long long sup = b / (SX * SY);
+   const unsigned within = (unsigned)(b % (SX * SY));
+   const unsigned px = (unsigned)(sup % sbx) * SX + within % SX, py = (unsigned)(sup / sbx) * SY + within / SX;
+   if (px >= gx || py >= gy) return;
+   const unsigned long long s0 = (unsigned long long)px * 64u;
+   const unsigned t0 = py * nt;
+   const unsigned tid = threadIdx.x;
+   const unsigned long long TW = (unsigned long long)n_samples * W;
+   const unsigned ns_here = (unsigned)(n_streams - s0 < 64u ? n_streams - s0 : 64u);
+   const unsigned nt_here = n_samples - t0 < nt ? n_samples - t0 : nt;
+   // frame side: element (t, s, w) at fbase + (t0 + t) * row_streams * W + s * W + w
+   const unsigned long long tile = tile_streams ? s0 / tile_streams : 0u;
+   const unsigned long long row_streams = tile_streams ? tile_streams : n_streams;
+   const unsigned long long s_in_tile = tile_streams ? s0 % tile_streams : s0;
+   const unsigned long long fbase = tile * (unsigned long long)n_samples * row_streams * W + s_in_tile * W;
+   const unsigned run = 64u * W;                                     // floats of one frame row of the patch
+   // stream-major side: element (s, c) at (s0 + s) * TW + t0 * W + c, c < nt * W
+   // full patches of 16-byte-aligned layouts move as float4 (all 4 loads of a thread in flight at once);
+   // edge patches and odd wire counts take the scalar path
+   const bool vec = nt * W == 64u && ns_here == 64u && nt_here == nt && (TW & 3u) == 0 && ((row_streams * W) & 3u) == 0;
+   if (vec) {
+      const unsigned q = tid & 15u, r0 = tid >> 4;                  // float4 column, first row
+      if (!TO_STREAM_MAJOR) {
+         fzr_f4 v[4];
+#pragma unroll
+         for (int k = 0; k < 4; ++k)
+            v[k] = __builtin_nontemporal_load(reinterpret_cast<const fzr_f4*>(src + (s0 + r0 + 16u * k) * TW + (unsigned long long)t0 * W) + q);
+#pragma unroll
+         for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) patch[r0 + 16u * k][q * 4u + j] = v[k][j];
+         __syncthreads();
+         // frame rows: nt rows of `run` floats; float4 index over the whole patch output
+         for (unsigned e = tid; e < nt * run / 4u; e += 256u) {
+            const unsigned t = e / (run / 4u), r = (e - t * (run / 4u)) * 4u;
+            fzr_f4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+               const unsigned rr = r + j, sl = rr / W, w = rr - sl * W;
+               o[j] = patch[sl][t * W + w];
+            }
+            __builtin_nontemporal_store(o, reinterpret_cast<fzr_f4*>(dst + fbase + (unsigned long long)(t0 + t) * row_streams * W + r));
+         }
+      } else {
+         for (unsigned e = tid; e < nt * run / 4u; e += 256u) {
+            const unsigned t = e / (run / 4u), r = (e - t * (run / 4u)) * 4u;
+            const fzr_f4 o = __builtin_nontemporal_load(reinterpret_cast<const fzr_f4*>(src + fbase + (unsigned long long)(t0 + t) * row_streams * W + r));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+               const unsigned rr = r + j, sl = rr / W, w = rr - sl * W;
+               patch[sl][t * W + w] = o[j];
+            }
+         }
+         __syncthreads();
+#pragma unroll
+         for (int k = 0; k < 4; ++k) {
+            fzr_f4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = patch[r0 + 16u * k][q * 4u + j];
+            __builtin_nontemporal_store(o, reinterpret_cast<fzr_f4*>(dst + (s0 + r0 + 16u * k) * TW + (unsigned long long)t0 * W) + q);
+         }
+      }
+      return;
+   }
+   if (!TO_STREAM_MAJOR) {
+      for (unsigned e = tid; e < 64u * 64u; e += 256u) {
+         const unsigned sl = e >> 6, c = e & 63u;
+         if (sl < ns_here && c < nt_here * W) patch[sl][c] = __builtin_nontemporal_load(src + (s0 + sl) * TW + (unsigned long long)t0 * W + c);
+      }
+      __syncthreads();
+      for (unsigned e = tid; e < nt * run; e += 256u) {
+         const unsigned t = e / run, r = e - t * run, sl = r / W, w = r - sl * W;
+         if (t < nt_here && sl < ns_here)
+            __builtin_nontemporal_store(patch[sl][t * W + w], dst + fbase + (unsigned long long)(t0 + t) * row_streams * W + r);
+      }
+   } else {
+      for (unsigned e = tid; e < nt * run; e += 256u) {
+         const unsigned t = e / run, r = e - t * run, sl = r / W, w = r - sl * W;
+         if (t < nt_here && sl < ns_here)
+            patch[sl][t * W + w] = __builtin_nontemporal_load(src + fbase + (unsigned long long)(t0 + t) * row_streams * W + r);
+      }
+      __syncthreads();
+      for (unsigned e = tid; e < 64u * 64u; e += 256u) {
+         const unsigned sl = e >> 6, c = e & 63u;
+         if (sl < ns_here && c < nt_here * W) __builtin_nontemporal_store(patch[sl][c], dst + (s0 + sl) * TW + (unsigned long long)t0 * W + c);
+      }
+   }
+}
+
 }  // namespace fz
 
 using namespace fz;
@@ -556,6 +662,31 @@ int fz_copy_probe(const float* src, float* dst, uint64_t n_floats, void* hip_str
       if (n4 > 1024ull * 0x7FFFFFFFull) fail(FZ_E_INVALID, "fz_copy_probe: buffer too large");
       hipLaunchKernelGGL(fz_copy_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)hip_stream,
                          (const fzr_f4*)src, (fzr_f4*)dst, (unsigned long long)(n_floats / 4));
+      FZ_HIP(hipGetLastError());
+      return FZ_OK;)
+}
+
+int fz_transpose_frames(const float* src, float* dst, uint64_t n_streams, uint32_t n_samples, uint32_t n_wires,
+                        uint32_t tile_streams, int to_stream_major, void* hip_stream)
+{
+   FZ_GUARD(
+      if (!src || !dst || !n_streams || !n_samples || !n_wires) fail(FZ_E_INVALID, "fz_transpose_frames: bad arguments");
+      if (n_wires > 64) fail(FZ_E_UNSUPPORTED, "fz_transpose_frames: more than 64 wires per frame");
+      if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) fail(FZ_E_INVALID, "device pointers must be 16-byte aligned");
+      if (tile_streams >= n_streams) tile_streams = 0;
+      if (tile_streams && (tile_streams % 64 || n_streams % tile_streams))
+         fail(FZ_E_INVALID, "tile_streams must be a multiple of 64 and divide n_streams");
+      require_device();
+      const unsigned nt = 64u / n_wires;
+      const uint64_t gx = (n_streams + 63) / 64, gy = ((uint64_t)n_samples + nt - 1) / nt;
+      const uint64_t blocks = ((gx + 15) / 16) * ((gy + 15) / 16) * 256;
+      if (gx > 0xFFFFFFFFull || blocks > 0x7FFFFFFFull) fail(FZ_E_UNSUPPORTED, "fz_transpose_frames: too many patches for one launch: split the block");
+      if (to_stream_major)
+         hipLaunchKernelGGL(fz_transpose_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, src, dst,
+                            (unsigned long long)n_streams, n_samples, n_wires, tile_streams, nt, (unsigned)gx, (unsigned)gy);
+      else
+         hipLaunchKernelGGL(fz_transpose_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, src, dst,
+                            (unsigned long long)n_streams, n_samples, n_wires, tile_streams, nt, (unsigned)gx, (unsigned)gy);
       FZ_HIP(hipGetLastError());
       return FZ_OK;)
 }

@@ -476,6 +476,43 @@ def rbj_lowpass(freq, q, sample_rate: float, raw6=None, df1=None):
                                  torch.cuda.current_stream().cuda_stream))
 
 
+def frames_from_stream_major(x, tile_streams: int = 0, out=None):
+    """x: CUDA float32 [n_streams, n_samples, n_wires] (one contiguous buffer per stream, as the reference's
+    closures consume them) -> frames for run_block: [n_samples, n_streams, n_wires], or stream-tiled
+    [n_tiles, n_samples, tile_streams, n_wires].  One device pass (fz_transpose_frames)."""
+    import torch
+
+    if x.dim() == 2:
+        x = x.unsqueeze(-1)
+    ns, T, w = x.shape
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    tile = tile_streams if tile_streams and tile_streams < ns else 0
+    shape = (ns // tile, T, tile, w) if tile else (T, ns, w)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    assert tuple(out.shape) == shape and out.is_contiguous()
+    C.check(C.lib.fz_transpose_frames(x.data_ptr(), out.data_ptr(), ns, T, w, tile, 0, torch.cuda.current_stream().cuda_stream))
+    return out
+
+
+def frames_to_stream_major(y, out=None):
+    """frames ([n_samples, n_streams, w] or stream-tiled [n_tiles, n_samples, tile, w]) -> [n_streams, n_samples, w]."""
+    import torch
+
+    assert y.is_cuda and y.dtype == torch.float32 and y.is_contiguous()
+    if y.dim() == 4:
+        n_tiles, T, tile, w = y.shape
+        ns = n_tiles * tile
+    else:
+        T, ns, w = y.shape
+        tile = 0
+    if out is None:
+        out = torch.empty((ns, T, w), dtype=torch.float32, device=y.device)
+    assert tuple(out.shape) == (ns, T, w) and out.is_contiguous()
+    C.check(C.lib.fz_transpose_frames(y.data_ptr(), out.data_ptr(), ns, T, w, tile, 1, torch.cuda.current_stream().cuda_stream))
+    return out
+
+
 def copy_probe(src, dst):
     import torch
 
