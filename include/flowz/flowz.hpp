@@ -457,6 +457,19 @@ struct compile_fn {
 };
 static const compile_fn compile{};
 
+// layout adapter for callers that keep one contiguous buffer per stream ([stream][t][wire], what each
+// closure of the reference loops over): to / from the frames the block API takes (fz_transpose_frames)
+inline void frames_from_stream_major(const float* src_dev, float* frames_dev, uint64_t n_streams, uint32_t n_samples,
+                                     uint32_t n_wires = 1, uint32_t tile_streams = 0, void* hip_stream = nullptr)
+{
+   detail::check(fz_transpose_frames(src_dev, frames_dev, n_streams, n_samples, n_wires, tile_streams, 0, hip_stream));
+}
+inline void frames_to_stream_major(const float* frames_dev, float* dst_dev, uint64_t n_streams, uint32_t n_samples,
+                                   uint32_t n_wires = 1, uint32_t tile_streams = 0, void* hip_stream = nullptr)
+{
+   detail::check(fz_transpose_frames(frames_dev, dst_dev, n_streams, n_samples, n_wires, tile_streams, 1, hip_stream));
+}
+
 static const placeholder<1> _1{};
 static const placeholder<2> _2{};
 static const placeholder<3> _3{};
