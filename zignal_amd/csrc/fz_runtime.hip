@@ -292,6 +292,13 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       if (tile_streams % (v.P * v.block))
          fail(FZ_E_INVALID, "tile_streams must be a multiple of streams_per_lane * block_threads");
    }
+   {  // a chunk of U rows is addressed through ONE buffer descriptor: it must stay below 4 GiB
+      const uint64_t row_bytes = row_streams * std::max(wmax, out_w) * 4;
+      while (row_bytes * v.U >= (1ull << 32) && v.U > 1) {
+         if (uv && uv->unroll) fail(FZ_E_INVALID, "unroll x row bytes must stay below 4 GiB: lower the unroll or tile the streams");
+         v.U /= 2;
+      }
+   }
    void* fn = nullptr;
    auto k = get_kernel(p, v, &fn);
 
