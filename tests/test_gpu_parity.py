@@ -826,3 +826,22 @@ def test_stream_major_buffers_end_to_end(torch_cuda, F):
     y, _ = prog.run_block(fr)
     got = F.frames_to_stream_major(y).cpu().numpy()
     assert ndiff(got, want) == 0
+
+
+def test_wide_rows_shrink_the_chunk_to_stay_below_4GiB(torch_cuda, F):
+    """16 M streams x 4 input wires, time-major: 256 MiB rows.  A chunk of rows is addressed through one
+    buffer descriptor (< 4 GiB), so the library lowers the unroll (16 -> 8 rows); a forced unroll fails."""
+    torch = torch_cuda
+    ns, T = 1 << 24, 20
+    prog = F.compile(F.from_sexpr(G.par4_sum()))
+    x = torch.empty((T, ns, 4), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED)
+    y, _ = prog.run_block(x)
+    ids = np.unique(np.concatenate([[0, 1, ns - 1, ns - 2, 9999999], np.random.default_rng(11).integers(0, ns, 48)]))
+    xh = O.synth_input(SEED, ids, T, n_wires=4)
+    idt = torch.from_numpy(ids).cuda()
+    assert ndiff(y[:, idt].cpu().numpy(), C.par4_sum(G.PAR4_SETS, xh)) == 0
+    with pytest.raises(F.FlowzError):
+        prog.run_block(x, variant=F.make_variant(1, 16))
+    y8, _ = prog.run_block(x, variant=F.make_variant(1, 8))
+    assert torch.equal(y8.view(torch.int32), y.view(torch.int32))
