@@ -327,6 +327,14 @@ public:
       refresh_refs();
       detail::check(fz_bank_process_tiled(bank_, in_dev, out_dev, n_samples, tile_streams, v, hip_stream));
    }
+   // control-rate modulation: the buffers hold rows_total samples; block k (block_len samples) runs with the
+   // per-stream coefficient set params_blocks_dev[k] ([n_blocks][n_param][n_streams]; nullptr: the bank's own)
+   void process_blocks(const float* in_dev, float* out_dev, uint32_t rows_total, uint32_t block_len, const float* params_blocks_dev = nullptr,
+                       uint32_t tile_streams = 0, void* hip_stream = nullptr, const fz_variant* v = nullptr)
+   {
+      refresh_refs();
+      detail::check(fz_bank_process_blocks(bank_, in_dev, out_dev, rows_total, block_len, params_blocks_dev, tile_streams, v, hip_stream));
+   }
    uint32_t recommended_tile_streams() const { return fz_recommended_tile_streams(prog_.get()); }
    // measure the kernel variants for this shape on these buffers once and keep the fastest for later
    // process()/process_tiled() calls (fz_program_tune); the bank's state advances: reset() afterwards

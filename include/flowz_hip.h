@@ -220,6 +220,13 @@ int fz_run_block_tiled(fz_program* p, const float* in, float* out, float* state,
                        const fz_variant* v, void* hip_stream);
 
 /* tile_streams that makes the row segments ~32 KiB for this graph's frame widths (power of two) */
+/* A block that is a WINDOW in time of larger frame buffers: samples [row0, row0 + n_samples) of buffers
+ * holding rows_total samples (per tile when tile_streams != 0, else time-major).  Lets a long stream-tiled
+ * recording be processed in pieces -- e.g. one block per control period with new coefficients -- without
+ * re-laying it out.                                                                                     */
+int  fz_run_block_window(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+                         uint32_t rows_total, uint32_t row0, uint32_t n_samples, uint32_t tile_streams, const fz_variant* v,
+                         void* hip_stream);
 uint32_t fz_recommended_tile_streams(const fz_program* p);
 
 /* Plan selection (what FFTW_MEASURE is to FFTW): time the candidate kernel variants of this program
@@ -251,6 +258,12 @@ int  fz_bank_process(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n
 /* fz_bank_process with stream-tiled frames (see fz_run_block_tiled) */
 int  fz_bank_process_tiled(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples,
                            uint32_t tile_streams, const fz_variant* v, void* hip_stream);
+/* Control-rate modulation (the std::ref terminals of flowz/README.md:42-61 at block rate): the
+ * rows_total samples of the frame buffers are processed in blocks of block_len samples, block k with the
+ * per-stream coefficient set params_blocks[k] (device, [n_blocks][n_param][n_streams]; NULL: the bank's
+ * own set).  ceil(rows_total / block_len) back-to-back launches, state carried.                          */
+int  fz_bank_process_blocks(fz_bank* b, const float* in_dev, float* out_dev, uint32_t rows_total, uint32_t block_len,
+                            const float* params_blocks, uint32_t tile_streams, const fz_variant* v, void* hip_stream);
 /* fz_program_tune on the bank's own state and per-stream coefficients (the state advances: fz_bank_reset) */
 int  fz_bank_tune(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples, uint32_t tile_streams,
                   void* hip_stream, fz_variant* chosen, float* chosen_ms);

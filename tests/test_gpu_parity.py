@@ -845,3 +845,37 @@ def test_wide_rows_shrink_the_chunk_to_stay_below_4GiB(torch_cuda, F):
         prog.run_block(x, variant=F.make_variant(1, 16))
     y8, _ = prog.run_block(x, variant=F.make_variant(1, 8))
     assert torch.equal(y8.view(torch.int32), y.view(torch.int32))
+
+
+def test_block_windows_and_control_rate_coefficients(torch_cuda, F):
+    """fz_run_block_window / fz_bank_process_blocks: a long (stream-tiled) recording processed in blocks,
+    every block with its own per-stream coefficient set (std::ref modulation at block rate)."""
+    torch = torch_cuda
+    ns, T, L, tile = 2048, 200, 64, 512                      # 4 blocks: 64, 64, 64, 8
+    nb = (T + L - 1) // L
+    g = G.osc_chain(6)
+    prog = F.compile(F.from_sexpr(g))
+    x = O.synth_input(SEED + 91, np.arange(ns), T)
+    Ps = [W.osc_chain_params(SEED + 92 + k, np.arange(ns)) for k in range(nb)]
+    # oracle: one closure set, coefficients swapped between blocks
+    f = O.compile(g, ns, params=Ps[0])
+    want = []
+    for k in range(nb):
+        f._params = np.ascontiguousarray(Ps[k], np.float32)
+        want.append(f.run(x[k * L:(k + 1) * L]))
+    want = np.concatenate(want)
+    xt = F.to_tiled(torch.from_numpy(x).cuda(), tile)
+    pb = torch.from_numpy(np.stack(Ps)).cuda()
+    out = torch.empty_like(xt)
+    bank = prog.bank(ns)
+    bank.process_blocks(xt, out, L, pb)
+    assert ndiff(F.from_tiled(out).cpu().numpy(), want) == 0
+    # the same through explicit windows on time-major buffers, mixed variants
+    xd = torch.from_numpy(x).cuda()
+    od = torch.empty_like(xd)
+    st = torch.zeros((prog.n_state, ns), device="cuda")
+    for k, v in zip(range(nb), (None, F.make_variant(2, 8), F.make_variant(1, 16), F.make_variant(4, 4))):
+        prog.run_window(xd, od, st, k * L, min(L, T - k * L), params=pb[k], variant=v)
+    assert ndiff(od.cpu().numpy(), want) == 0
+    with pytest.raises(F.FlowzError):
+        prog.run_window(xd, od, st, T - 10, 20, params=pb[0])          # window beyond the buffer

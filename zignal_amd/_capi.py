@@ -92,6 +92,8 @@ def _load():
         "fz_program_source": (ctypes.c_long, [P, ctypes.POINTER(Variant), ctypes.c_char_p, ctypes.c_size_t]),
         "fz_run_block": (ctypes.c_int, [P, P, P, P, P, u64, u32, ctypes.POINTER(Variant), P]),
         "fz_run_block_tiled": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, ctypes.POINTER(Variant), P]),
+        "fz_run_block_window": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, u32, u32, ctypes.POINTER(Variant), P]),
+        "fz_bank_process_blocks": (ctypes.c_int, [P, P, P, u32, u32, P, u32, ctypes.POINTER(Variant), P]),
         "fz_program_tune": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, P, ctypes.POINTER(Variant), ctypes.POINTER(f32)]),
         "fz_recommended_tile_streams": (u32, [P]),
         "fz_bank_create": (ctypes.c_int, [P, u64, ctypes.POINTER(P)]),

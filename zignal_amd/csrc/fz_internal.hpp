@@ -164,7 +164,8 @@ Variant resolve_variant(const Graph& g, const fz_variant* v, uint64_t n_streams,
 // current device and return its hipFunction_t
 std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out);
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params,
-           uint64_t n_streams, uint32_t n_samples, const fz_variant* v, void* stream, uint32_t tile_streams = 0);
+           uint64_t n_streams, uint32_t n_samples, const fz_variant* v, void* stream, uint32_t tile_streams = 0,
+           uint32_t rows_total = 0, uint32_t row0 = 0);
 int tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
          uint32_t n_samples, uint32_t tile_streams, void* stream, fz_variant* chosen, float* chosen_ms);
 int device_count();

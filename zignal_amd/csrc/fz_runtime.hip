@@ -250,11 +250,15 @@ struct ArgsHeader {
    unsigned int n_groups;
    unsigned int tile_streams;
    unsigned int tile_blocks;
+   unsigned int rows_total;
+   unsigned int row0;
 };
 
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
-           uint32_t n_samples, const fz_variant* uv, void* stream, uint32_t tile_streams)
+           uint32_t n_samples, const fz_variant* uv, void* stream, uint32_t tile_streams, uint32_t rows_total, uint32_t row0)
 {
+   if (rows_total == 0) rows_total = n_samples;             // the block is the whole buffer
+   if ((uint64_t)row0 + n_samples > rows_total) fail(FZ_E_INVALID, "row0 + n_samples exceeds rows_total");
    const Graph& g = p->g;
    if (n_streams == 0 || n_samples == 0) return FZ_OK;      // an empty block: nothing to evaluate, state unchanged
    if (n_samples == 0xFFFFFFFFu) fail(FZ_E_INVALID, "n_samples must be below 2^32 - 1");
@@ -306,7 +310,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    const size_t off64 = (sizeof(ArgsHeader) + sizeof(float) * std::max<size_t>(g.consts.size(), 1) + 7) & ~size_t(7);
    std::vector<char> buf(off64 + sizeof(double) * std::max<size_t>(g.consts64.size(), 1));
    ArgsHeader h{in, out, state, params, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
-                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u};
+                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0};
    std::memcpy(buf.data(), &h, sizeof h);
    {
       std::lock_guard<std::mutex> lock(p->mu);
@@ -801,6 +805,26 @@ int fz_bank_process_tiled(fz_bank* b, const float* in_dev, float* out_dev, uint3
       const Graph& g = b->prog->g;
       return fz::launch(b->prog, in_dev, out_dev, g.n_state ? b->state : nullptr, b->params, b->n_streams, n_samples, v,
                         hip_stream, tile_streams);)
+}
+
+int fz_bank_process_blocks(fz_bank* b, const float* in_dev, float* out_dev, uint32_t rows_total, uint32_t block_len,
+                           const float* params_blocks, uint32_t tile_streams, const fz_variant* v, void* hip_stream)
+{
+   FZ_GUARD(
+      if (!b || !rows_total || !block_len) fail(FZ_E_INVALID, "fz_bank_process_blocks: bad arguments");
+      check_bank_device(b);
+      const Graph& g = b->prog->g;
+      if (params_blocks && !g.n_param) fail(FZ_E_INVALID, "the graph has no per-stream coefficients");
+      const size_t pstride = (size_t)g.n_param * b->n_streams;      // floats of one block's coefficient set
+      uint32_t k = 0;
+      for (uint32_t row0 = 0; row0 < rows_total; row0 += block_len, ++k) {
+         const uint32_t n = std::min(block_len, rows_total - row0);
+         const float* pr = params_blocks ? params_blocks + (size_t)k * pstride : b->params;
+         int rc = fz::launch(b->prog, in_dev, out_dev, g.n_state ? b->state : nullptr, pr, b->n_streams, n, v, hip_stream,
+                             tile_streams, rows_total, row0);
+         if (rc != FZ_OK) return rc;
+      }
+      return FZ_OK;)
 }
 
 int fz_bank_tune(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples, uint32_t tile_streams, void* hip_stream,

@@ -293,6 +293,25 @@ class Program:
             C.check(C.lib.fz_run_block(self._h, in_ptr, out_ptr, state_ptr, params_ptr, int(n_streams),
                                        int(n_samples), vp, stream))
 
+    def run_window(self, x, out, state, row0: int, n_samples: int, params=None, variant: Optional[Variant] = None):
+        """Samples [row0, row0 + n_samples) of the frame buffers x / out (laid out as for run_block, holding
+        more samples than the block): fz_run_block_window.  state advances; params as for run_block."""
+        import torch
+
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+        if x.dim() == 4:
+            n_tiles, rows, tile, _ = x.shape
+            ns = n_tiles * tile
+        else:
+            rows, ns, _ = x.shape
+            tile = 0
+        pp = params.data_ptr() if self.n_param else None
+        vp = ctypes.byref(variant) if variant is not None else None
+        C.check(C.lib.fz_run_block_window(self._h, x.data_ptr() if self.n_in else None, out.data_ptr(),
+                                          state.data_ptr() if self.n_state else None, pp, ns, rows, int(row0), int(n_samples),
+                                          tile, vp, torch.cuda.current_stream().cuda_stream))
+        return out, state
+
     def run_block(self, x, state=None, params=None, out=None, variant: Optional[Variant] = None, out_f64: bool = False):
         """x: CUDA float32 frames, either time-major [T, n_streams, n_in] or stream-tiled
         [n_tiles, T, tile_streams, n_in] (the HBM-friendly layout, see fz_run_block_tiled).
@@ -389,6 +408,24 @@ class Bank:
         p = np.ascontiguousarray(params, dtype=np.float32)
         assert p.shape == (self.prog.n_param, self.n_streams)
         C.check(C.lib.fz_bank_set_params_host(self._h, p.ctypes.data))
+
+    def process_blocks(self, x, out, block_len: int, params_blocks=None, variant: Optional[Variant] = None):
+        """Control-rate modulation: the frame buffers x / out (CUDA, time-major or stream-tiled) are processed in
+        blocks of block_len samples, block k with the per-stream coefficient set params_blocks[k]
+        (CUDA float32 [n_blocks, n_param, n_streams]); fz_bank_process_blocks."""
+        import torch
+
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+        rows, tile = (x.shape[1], x.shape[2]) if x.dim() == 4 else (x.shape[0], 0)
+        pp = None
+        if params_blocks is not None:
+            nb = (rows + block_len - 1) // block_len
+            assert tuple(params_blocks.shape) == (nb, self.prog.n_param, self.n_streams) and params_blocks.is_contiguous()
+            pp = params_blocks.data_ptr()
+        vp = ctypes.byref(variant) if variant is not None else None
+        C.check(C.lib.fz_bank_process_blocks(self._h, x.data_ptr() if self.prog.n_in else None, out.data_ptr(), rows,
+                                             int(block_len), pp, tile, vp, torch.cuda.current_stream().cuda_stream))
+        return out
 
     def process_host(self, x, out=None, out_f64: bool = False):
         """Host frames in, host frames out (time-major [T, n_streams, n_in] float32 -> [T, n_streams, n_out]).
