@@ -170,6 +170,7 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
        FZ_VF_NO_STAGE_PACK = 16u,
        FZ_VF_PREFETCH3 = 32u,   /* three input chunk buffers: loads run two chunks (2 x unroll steps) ahead
                                    (not with delay lines beyond 256 samples)                              */
+       FZ_VF_STREAM_MAJOR = 128u,   /* set by fz_run_block_stream_major (the frame layout is part of the kernel) */
        FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
                                    float*): the results of graphs with double literals leave un-narrowed, float
                                    wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */
@@ -227,6 +228,15 @@ int fz_run_block_tiled(fz_program* p, const float* in, float* out, float* state,
 int  fz_run_block_window(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
                          uint32_t rows_total, uint32_t row0, uint32_t n_samples, uint32_t tile_streams, const fz_variant* v,
                          void* hip_stream);
+/* The block kernel on STREAM-MAJOR buffers, without a layout pass: in [n_streams][rows_total][n_in],
+ * out [n_streams][rows_total][n_out] -- one contiguous buffer per stream, as every closure of the reference
+ * consumes its samples (test/benchmark.cpp:137-147); the block is the window [row0, row0 + n_samples).
+ * Waves fetch [64 streams][unroll samples] patches along the rows and transpose them through LDS.  One
+ * stream per lane (no lane or stage packing: VALU-bound for deep graphs at large stream counts), no delay
+ * lines beyond 256 samples, float32 frames; rows_total * n_in, row0 * n_in (and the same for n_out) must
+ * be multiples of 4 floats.  For the fastest path convert once with fz_transpose_frames instead.      */
+int  fz_run_block_stream_major(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+                               uint32_t rows_total, uint32_t row0, uint32_t n_samples, const fz_variant* v, void* hip_stream);
 uint32_t fz_recommended_tile_streams(const fz_program* p);
 
 /* Plan selection (what FFTW_MEASURE is to FFTW): time the candidate kernel variants of this program

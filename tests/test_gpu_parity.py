@@ -879,3 +879,44 @@ def test_block_windows_and_control_rate_coefficients(torch_cuda, F):
     assert ndiff(od.cpu().numpy(), want) == 0
     with pytest.raises(F.FlowzError):
         prog.run_window(xd, od, st, T - 10, 20, params=pb[0])          # window beyond the buffer
+
+
+SM_GRAPHS = {"cascade6": lambda: G.df1_cascade(6), "par4": G.par4_sum, "cross_wire": G.cross_wire, "integrator": G.integrator,
+             "lds_ring": lambda: G.seq(G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 40))), G.fb(G.add(G.mul(G.lit(0.7), G.DEL(1, 23)), G.IN(2)))),
+             "df2t": G.df2t}
+
+
+@pytest.mark.parametrize("name", sorted(SM_GRAPHS))
+def test_stream_major_kernel_vs_oracle(torch_cuda, F, name):
+    """fz_run_block_stream_major: [stream][t][wire] buffers straight through the block kernel (LDS-transposed
+    chunks), ragged stream counts, tails, windows, chained blocks -- vs the oracle."""
+    torch = torch_cuda
+    g = SM_GRAPHS[name]()
+    prog = F.compile(F.from_sexpr(g))
+    for ns, T in ((1, 4), (64, 32), (200, 100), (777, 68), (1000, 36)):
+        x = O.synth_input(SEED + 95, np.arange(ns), T, n_wires=max(prog.n_in, 1))
+        want = O.compile(g, ns).run(x)                                   # [T, ns, n_out]
+        xs = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))).cuda()
+        y, st = prog.run_block_stream_major(xs)
+        assert ndiff(y.permute(1, 0, 2).contiguous().cpu().numpy(), want) == 0, (ns, T)
+        # same state as the frame kernel leaves
+        _, st_ref = prog.run_block(torch.from_numpy(x).cuda())
+        assert torch.equal(st, st_ref)
+        # two windows of the same buffers, state carried (row0 multiple of 4)
+        if T >= 36:
+            out = torch.zeros_like(y)
+            _, st2 = prog.run_block_stream_major(xs, out=out, n_samples=20)
+            prog.run_block_stream_major(xs, out=out, state=st2, row0=20)
+            assert torch.equal(out, y), (ns, T)
+
+
+def test_stream_major_kernel_rejects_what_it_cannot_do(torch_cuda, F):
+    torch = torch_cuda
+    prog = F.compile(F.from_sexpr(G.df1_cascade(2)))
+    with pytest.raises(F.FlowzError):
+        prog.run_block_stream_major(torch.zeros((8, 30, 1), device="cuda"))                 # rows % 4 != 0
+    with pytest.raises(F.FlowzError):
+        prog.run_block_stream_major(torch.zeros((8, 32, 1), device="cuda"), variant=F.make_variant(2, 8))
+    far = F.compile(F.from_sexpr(("seq", ("in", 1), ("add", ("in", 1), ("del", 1, 300)))))
+    with pytest.raises(F.FlowzError):
+        far.run_block_stream_major(torch.zeros((8, 32, 1), device="cuda"))

@@ -26,6 +26,7 @@ FZ_OK, FZ_E_INVALID, FZ_E_GRAPH, FZ_E_NO_DEVICE, FZ_E_HIP, FZ_E_COMPILE, FZ_E_UN
 FZ_OP_ADD, FZ_OP_SUB, FZ_OP_MUL, FZ_OP_DIV, FZ_OP_NEG = 1, 2, 3, 4, 5
 FZ_VF_NO_NT, FZ_VF_NO_XCD_REMAP, FZ_VF_SLP, FZ_VF_STAGE_PACK, FZ_VF_NO_STAGE_PACK, FZ_VF_OUT_F64 = 1, 2, 4, 8, 16, 64
 FZ_VF_PREFETCH3 = 32
+FZ_VF_STREAM_MAJOR = 128
 
 
 def FZ_VF_MAX_WG(n):
@@ -93,6 +94,7 @@ def _load():
         "fz_run_block": (ctypes.c_int, [P, P, P, P, P, u64, u32, ctypes.POINTER(Variant), P]),
         "fz_run_block_tiled": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, ctypes.POINTER(Variant), P]),
         "fz_run_block_window": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, u32, u32, ctypes.POINTER(Variant), P]),
+        "fz_run_block_stream_major": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, u32, ctypes.POINTER(Variant), P]),
         "fz_bank_process_blocks": (ctypes.c_int, [P, P, P, u32, u32, P, u32, ctypes.POINTER(Variant), P]),
         "fz_program_tune": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, P, ctypes.POINTER(Variant), ctypes.POINTER(f32)]),
         "fz_recommended_tile_streams": (u32, [P]),

@@ -203,6 +203,17 @@ int fz_run_block_window(fz_program* p, const float* in, float* out, float* state
       return launch(p, in, out, state, params, n_streams, n_samples, v, hip_stream, tile_streams, rows_total, row0);)
 }
 
+int fz_run_block_stream_major(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+                              uint32_t rows_total, uint32_t row0, uint32_t n_samples, const fz_variant* v, void* hip_stream)
+{
+   FZ_GUARD(
+      if (!p) fail(FZ_E_INVALID, "null program");
+      if (!rows_total) fail(FZ_E_INVALID, "rows_total must be > 0");
+      fz_variant sm = v ? *v : fz_variant{0, 0, 0, 0};
+      sm.flags |= FZ_VF_STREAM_MAJOR;
+      return launch(p, in, out, state, params, n_streams, n_samples, &sm, hip_stream, 0, rows_total, row0);)
+}
+
 int fz_program_tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
                     uint32_t n_samples, uint32_t tile_streams, void* hip_stream, fz_variant* chosen, float* chosen_ms)
 {

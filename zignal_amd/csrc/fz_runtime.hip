@@ -227,6 +227,26 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    }
    v.flags &= ~(uint32_t)FZ_VF_NO_STAGE_PACK;
    v.block = reqB ? reqB : 256;
+   if (v.flags & FZ_VF_STREAM_MAJOR) {
+      // stream-major frames (fz_run_block_stream_major): one stream per lane, chunks of whole float4 pieces
+      if (reqP > 1) fail(FZ_E_INVALID, "stream-major frames need streams_per_lane == 1");
+      if (reqU % 4) fail(FZ_E_INVALID, "stream-major frames need unroll % 4 == 0");
+      if (!g.far_lines.empty()) fail(FZ_E_UNSUPPORTED, "stream-major frames: delay lines beyond 256 samples are not supported");
+      if (v.flags & (FZ_VF_OUT_F64 | FZ_VF_PREFETCH3)) fail(FZ_E_UNSUPPORTED, "stream-major frames: float32 frames, double buffering only");
+      v.P = 1;
+      v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
+      const uint32_t nw = std::max<uint32_t>(std::max(g.n_in, g.n_out), 1);
+      auto lds = [&](const Variant& w) { return (uint64_t)w.block * (w.U * nw + 4) * 4 + (uint64_t)g.n_lds_slots * w.block * 4; };
+      if (!reqU) {
+         // the longer the run of one stream inside a chunk the better it streams (measured: 128 B per
+         // stream and wire 2x faster than 64 B): the deepest chunk whose patches leave room for two workgroups
+         v.U = 32;
+         while (v.U > 4 && lds(v) > 80 * 1024) v.U /= 2;
+      }
+      while (lds(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
+      if (lds(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "stream-major frames: the LDS patches do not fit (too many wires per frame)");
+      return v;
+   }
    if (g.n_lds_slots) {
       // LDS rings: slots * block * 4P bytes must fit the CU's 160 KiB of LDS (one workgroup may take it all)
       auto bytes = [&](const Variant& w) { return (uint64_t)g.n_lds_slots * w.block * 4u * w.P; };
@@ -259,6 +279,13 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
 {
    if (rows_total == 0) rows_total = n_samples;             // the block is the whole buffer
    if ((uint64_t)row0 + n_samples > rows_total) fail(FZ_E_INVALID, "row0 + n_samples exceeds rows_total");
+   const bool stream_major = uv && (uv->flags & FZ_VF_STREAM_MAJOR);
+   if (stream_major) {
+      if (tile_streams) fail(FZ_E_INVALID, "stream-major frames are not tiled");
+      if (((uint64_t)rows_total * p->g.n_in) % 4 || ((uint64_t)row0 * p->g.n_in) % 4 || ((uint64_t)rows_total * p->g.n_out) % 4 ||
+          ((uint64_t)row0 * p->g.n_out) % 4)
+         fail(FZ_E_INVALID, "stream-major frames: rows_total and row0 times the wires per frame must be multiples of 4 floats");
+   }
    const Graph& g = p->g;
    if (n_streams == 0 || n_samples == 0) return FZ_OK;      // an empty block: nothing to evaluate, state unchanged
    if (n_samples == 0xFFFFFFFFu) fail(FZ_E_INVALID, "n_samples must be below 2^32 - 1");
@@ -272,7 +299,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    if (tile_streams == 0 || tile_streams >= n_streams) tile_streams = 0;    // one tile == plain time-major
    const uint64_t row_streams = tile_streams ? tile_streams : n_streams;
    const uint64_t out_w = (uint64_t)std::max<uint32_t>(g.n_out, 1) * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 2 : 1);
-   if (row_streams * std::max(wmax, out_w) >= (1ull << 30)) fail(FZ_E_UNSUPPORTED, "row longer than 4 GiB: shard or tile the streams");
+   if (!stream_major && row_streams * std::max(wmax, out_w) >= (1ull << 30)) fail(FZ_E_UNSUPPORTED, "row longer than 4 GiB: shard or tile the streams");
    if (n_streams >= (1ull << 32)) fail(FZ_E_UNSUPPORTED, "more than 2^32 streams per launch: shard the streams");
    if (tile_streams && n_streams % tile_streams) fail(FZ_E_INVALID, "n_streams must be a multiple of tile_streams");
    require_device();
@@ -297,7 +324,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
          fail(FZ_E_INVALID, "tile_streams must be a multiple of streams_per_lane * block_threads");
    }
    {  // a chunk of U rows is addressed through ONE buffer descriptor: it must stay below 4 GiB
-      const uint64_t row_bytes = row_streams * std::max(wmax, out_w) * 4;
+      const uint64_t row_bytes = stream_major ? 0 : row_streams * std::max(wmax, out_w) * 4;
       while (row_bytes * v.U >= (1ull << 32) && v.U > 1) {
          if (uv && uv->unroll) fail(FZ_E_INVALID, "unroll x row bytes must stay below 4 GiB: lower the unroll or tile the streams");
          v.U /= 2;

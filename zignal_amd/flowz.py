@@ -312,6 +312,29 @@ class Program:
                                           tile, vp, torch.cuda.current_stream().cuda_stream))
         return out, state
 
+    def run_block_stream_major(self, x, state=None, params=None, out=None, variant: Optional[Variant] = None, row0: int = 0,
+                               n_samples: Optional[int] = None):
+        """x: CUDA float32 [n_streams, rows, n_in] -- one contiguous buffer per stream (the reference's calling
+        convention); out [n_streams, rows, n_out].  No layout pass (fz_run_block_stream_major); the block is
+        rows [row0, row0 + n_samples).  Returns (out, state)."""
+        import torch
+
+        if x.dim() == 2:
+            x = x.unsqueeze(-1)
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == max(self.n_in, 1)
+        ns, rows, _ = x.shape
+        n = rows - row0 if n_samples is None else int(n_samples)
+        if out is None:
+            out = torch.empty((ns, rows, self.n_out), dtype=torch.float32, device=x.device)
+        if state is None:
+            state = torch.zeros((max(self.n_state, 1), ns), dtype=torch.float32, device=x.device)
+        pp = params.data_ptr() if self.n_param else None
+        vp = ctypes.byref(variant) if variant is not None else None
+        C.check(C.lib.fz_run_block_stream_major(self._h, x.data_ptr() if self.n_in else None, out.data_ptr(),
+                                                state.data_ptr() if self.n_state else None, pp, ns, rows, int(row0), n, vp,
+                                                torch.cuda.current_stream().cuda_stream))
+        return out, state
+
     def run_block(self, x, state=None, params=None, out=None, variant: Optional[Variant] = None, out_f64: bool = False):
         """x: CUDA float32 frames, either time-major [T, n_streams, n_in] or stream-tiled
         [n_tiles, T, tile_streams, n_in] (the HBM-friendly layout, see fz_run_block_tiled).
