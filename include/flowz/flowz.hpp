@@ -327,6 +327,14 @@ public:
       refresh_refs();
       detail::check(fz_bank_process_tiled(bank_, in_dev, out_dev, n_samples, tile_streams, v, hip_stream));
    }
+   // one contiguous buffer per stream ([n_streams][rows_total][wires], the reference's calling convention):
+   // samples [row0, row0 + n_samples) straight through the block kernel, no layout pass
+   void process_stream_major(const float* in_dev, float* out_dev, uint32_t rows_total, uint32_t row0, uint32_t n_samples,
+                             void* hip_stream = nullptr, const fz_variant* v = nullptr)
+   {
+      refresh_refs();
+      detail::check(fz_bank_process_stream_major(bank_, in_dev, out_dev, rows_total, row0, n_samples, v, hip_stream));
+   }
    // control-rate modulation: the buffers hold rows_total samples; block k (block_len samples) runs with the
    // per-stream coefficient set params_blocks_dev[k] ([n_blocks][n_param][n_streams]; nullptr: the bank's own)
    void process_blocks(const float* in_dev, float* out_dev, uint32_t rows_total, uint32_t block_len, const float* params_blocks_dev = nullptr,

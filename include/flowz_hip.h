@@ -268,6 +268,9 @@ int  fz_bank_process(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n
 /* fz_bank_process with stream-tiled frames (see fz_run_block_tiled) */
 int  fz_bank_process_tiled(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples,
                            uint32_t tile_streams, const fz_variant* v, void* hip_stream);
+/* fz_run_block_stream_major on the bank's state: in [n_streams][rows_total][n_in], out alike */
+int  fz_bank_process_stream_major(fz_bank* b, const float* in_dev, float* out_dev, uint32_t rows_total, uint32_t row0,
+                                  uint32_t n_samples, const fz_variant* v, void* hip_stream);
 /* Control-rate modulation (the std::ref terminals of flowz/README.md:42-61 at block rate): the
  * rows_total samples of the frame buffers are processed in blocks of block_len samples, block k with the
  * per-stream coefficient set params_blocks[k] (device, [n_blocks][n_param][n_streams]; NULL: the bank's

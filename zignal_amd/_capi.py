@@ -95,6 +95,7 @@ def _load():
         "fz_run_block_tiled": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, ctypes.POINTER(Variant), P]),
         "fz_run_block_window": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, u32, u32, ctypes.POINTER(Variant), P]),
         "fz_run_block_stream_major": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, u32, ctypes.POINTER(Variant), P]),
+        "fz_bank_process_stream_major": (ctypes.c_int, [P, P, P, u32, u32, u32, ctypes.POINTER(Variant), P]),
         "fz_bank_process_blocks": (ctypes.c_int, [P, P, P, u32, u32, P, u32, ctypes.POINTER(Variant), P]),
         "fz_program_tune": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, P, ctypes.POINTER(Variant), ctypes.POINTER(f32)]),
         "fz_recommended_tile_streams": (u32, [P]),

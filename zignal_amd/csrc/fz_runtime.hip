@@ -834,6 +834,19 @@ int fz_bank_process_tiled(fz_bank* b, const float* in_dev, float* out_dev, uint3
                         hip_stream, tile_streams);)
 }
 
+int fz_bank_process_stream_major(fz_bank* b, const float* in_dev, float* out_dev, uint32_t rows_total, uint32_t row0, uint32_t n_samples,
+                                 const fz_variant* v, void* hip_stream)
+{
+   FZ_GUARD(
+      if (!b || !rows_total) fail(FZ_E_INVALID, "fz_bank_process_stream_major: bad arguments");
+      check_bank_device(b);
+      const Graph& g = b->prog->g;
+      fz_variant sm = v ? *v : fz_variant{0, 0, 0, 0};
+      sm.flags |= FZ_VF_STREAM_MAJOR;
+      return fz::launch(b->prog, in_dev, out_dev, g.n_state ? b->state : nullptr, b->params, b->n_streams, n_samples, &sm, hip_stream, 0,
+                        rows_total, row0);)
+}
+
 int fz_bank_process_blocks(fz_bank* b, const float* in_dev, float* out_dev, uint32_t rows_total, uint32_t block_len,
                            const float* params_blocks, uint32_t tile_streams, const fz_variant* v, void* hip_stream)
 {
