@@ -899,6 +899,10 @@ def test_stream_major_kernel_vs_oracle(torch_cuda, F, name):
         xs = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))).cuda()
         y, st = prog.run_block_stream_major(xs)
         assert ndiff(y.permute(1, 0, 2).contiguous().cpu().numpy(), want) == 0, (ns, T)
+        for v in ((2, 0), (2, 8), (1, 4), (1, 16)):                       # two streams per lane, other chunk depths
+            if ns % v[0] == 0:
+                yv, stv = prog.run_block_stream_major(xs, variant=F.make_variant(*v))
+                assert torch.equal(yv, y) and torch.equal(stv, st), (ns, T, v)
         # same state as the frame kernel leaves
         _, st_ref = prog.run_block(torch.from_numpy(x).cuda())
         assert torch.equal(st, st_ref)
@@ -916,7 +920,7 @@ def test_stream_major_kernel_rejects_what_it_cannot_do(torch_cuda, F):
     with pytest.raises(F.FlowzError):
         prog.run_block_stream_major(torch.zeros((8, 30, 1), device="cuda"))                 # rows % 4 != 0
     with pytest.raises(F.FlowzError):
-        prog.run_block_stream_major(torch.zeros((8, 32, 1), device="cuda"), variant=F.make_variant(2, 8))
+        prog.run_block_stream_major(torch.zeros((8, 32, 1), device="cuda"), variant=F.make_variant(4, 8))
     far = F.compile(F.from_sexpr(("seq", ("in", 1), ("add", ("in", 1), ("del", 1, 300)))))
     with pytest.raises(F.FlowzError):
         far.run_block_stream_major(torch.zeros((8, 32, 1), device="cuda"))

@@ -37,12 +37,13 @@ for name, ns, T in (("cascade6", 1 << 20, 1024), ("cascade2", 1 << 20, 1024), ("
     yf = torch.empty((ns // tile, T, tile, prog.n_out), device="cuda") if tile < ns else torch.empty((T, ns, prog.n_out), device="cuda")
     b = ns * T * 4 * (prog.n_in + prog.n_out)
     res = {}
-    for U in (0, 16, 8):
-        v = F.make_variant(0, U) if U else None
+    for P, U in ((0, 0), (1, 32), (2, 32), (2, 16), (1, 16)):
+        v = F.make_variant(P, U) if (P or U) else None
+        label = f"stream-major kernel {'auto' if not (P or U) else f'P={P} U={U}'}"
         try:
-            res[f"stream-major kernel U={U or 'auto'}"] = timed(lambda: prog.run_block_stream_major(x, state=st, out=out, variant=v))
-        except F.FlowzError as e:
-            res[f"stream-major kernel U={U}"] = float("nan")
+            res[label] = timed(lambda: prog.run_block_stream_major(x, state=st, out=out, variant=v))
+        except F.FlowzError:
+            res[label] = float("nan")
 
     def via_adapter():
         F.frames_from_stream_major(x, tile, out=fr)

@@ -229,19 +229,21 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    v.block = reqB ? reqB : 256;
    if (v.flags & FZ_VF_STREAM_MAJOR) {
       // stream-major frames (fz_run_block_stream_major): one stream per lane, chunks of whole float4 pieces
-      if (reqP > 1) fail(FZ_E_INVALID, "stream-major frames need streams_per_lane == 1");
+      if (reqP > 2) fail(FZ_E_INVALID, "stream-major frames take one or two streams per lane");
       if (reqU % 4) fail(FZ_E_INVALID, "stream-major frames need unroll % 4 == 0");
       if (!g.far_lines.empty()) fail(FZ_E_UNSUPPORTED, "stream-major frames: delay lines beyond 256 samples are not supported");
       if (v.flags & (FZ_VF_OUT_F64 | FZ_VF_PREFETCH3)) fail(FZ_E_UNSUPPORTED, "stream-major frames: float32 frames, double buffering only");
-      v.P = 1;
+      // one stream per lane: two (packed FP32) are possible but measured slower everywhere -- twice the
+      // patch traffic per wave and 360 VGPRs (profiles/r01/stream_major_kernel.txt)
+      v.P = reqP ? reqP : 1u;
       v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
       const uint32_t nw = std::max<uint32_t>(std::max(g.n_in, g.n_out), 1);
-      auto lds = [&](const Variant& w) { return (uint64_t)w.block * (w.U * nw + 4) * 4 + (uint64_t)g.n_lds_slots * w.block * 4; };
+      auto lds = [&](const Variant& w) { return (uint64_t)w.block * w.P * (w.U * nw + 4) * 4 + (uint64_t)g.n_lds_slots * w.block * 4 * w.P; };
       if (!reqU) {
          // the longer the run of one stream inside a chunk the better it streams (measured: 128 B per
-         // stream and wire 2x faster than 64 B): the deepest chunk whose patches leave room for two workgroups
+         // stream and wire 2x faster than 64 B): the deepest chunk whose patches fit the CU's LDS
          v.U = 32;
-         while (v.U > 4 && lds(v) > 80 * 1024) v.U /= 2;
+         while (v.U > 4 && lds(v) > kMaxLdsBytes) v.U /= 2;
       }
       while (lds(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
       if (lds(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "stream-major frames: the LDS patches do not fit (too many wires per frame)");
