@@ -51,6 +51,12 @@ for seed in range(first, first + count):
         ya, st = p.run_block(xd[:cut].contiguous())
         yb, _ = p.run_block(xd[cut:].contiguous(), state=st)
         res.append((f"chained at {cut}", same(torch.cat([ya, yb]).cpu().numpy(), want, np.float32)))
+        # the stream-major kernel on [stream][t][wire] buffers (first 60 samples: rows % 4 == 0)
+        xs = torch.from_numpy(np.ascontiguousarray(np.transpose(x[:60], (1, 0, 2)))).cuda()
+        for P in (1, 2):
+            U = int(rng.choice([4, 8, 16, 32]))
+            ys, _ = p.run_block_stream_major(xs, variant=F.make_variant(P, U))
+            res.append((f"stream-major P={P} U={U}", same(ys.permute(1, 0, 2).contiguous().cpu().numpy(), want[:60], np.float32)))
         if all(r for _, r in res):
             ok += 1
         else:
