@@ -23,4 +23,4 @@ print(f"plan: {plan.streams_per_lane} streams/lane, unroll {plan.unroll}, flags 
 y, state = prog.run_block(x)                                   # one launch; state carries to the next block
 y2, state = prog.run_block(x, state=state)
 torch.cuda.synchronize()
-print("kernel:", prog.kernel_name(None, n_streams, n_samples), "| out", tuple(y.shape), "| finite:", bool(torch.isfinite(y2).all()))
+print("kernel:", prog.kernel_name(plan, n_streams, n_samples), "| out", tuple(y.shape), "| finite:", bool(torch.isfinite(y2).all()))
