@@ -358,6 +358,12 @@ public:
       refresh_refs();
       detail::check(fz_bank_process_host(bank_, in_host, out_host, n_samples));
    }
+   // host buffers, one contiguous row per stream ([n_streams][n_samples][wires]): the reference's own convention
+   void process_host_stream_major(const float* in_host, float* out_host, uint32_t n_samples)
+   {
+      refresh_refs();
+      detail::check(fz_bank_process_host_stream_major(bank_, in_host, out_host, n_samples));
+   }
    // float64 result frames: double sub-expression results leave un-narrowed, float wires widen exactly
    void process_host(const float* in_host, double* out_host, uint32_t n_samples)
    {

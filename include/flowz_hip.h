@@ -281,6 +281,10 @@ int  fz_bank_process_blocks(fz_bank* b, const float* in_dev, float* out_dev, uin
 int  fz_bank_tune(fz_bank* b, const float* in_dev, float* out_dev, uint32_t n_samples, uint32_t tile_streams,
                   void* hip_stream, fz_variant* chosen, float* chosen_ms);
 int  fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint32_t n_samples);
+/* host buffers in the reference's own calling convention: one contiguous sample buffer per stream,
+ * in [n_streams][n_samples][n_in] -> out [n_streams][n_samples][n_out] (2-D copies of time chunks, the
+ * stream-major kernel, the same three-stream pipeline)                                               */
+int  fz_bank_process_host_stream_major(fz_bank* b, const float* in_host, float* out_host, uint32_t n_samples);
 /* the same with float64 result frames (FZ_VF_OUT_F64): what a closure with double literals returns
  * in the reference (tuple<double>, flowz.hpp:1225-1229 with the ResultType of test/tests.cpp:201) */
 int  fz_bank_process_host_f64(fz_bank* b, const float* in_host, double* out_host, uint32_t n_samples);

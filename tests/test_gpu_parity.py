@@ -924,3 +924,26 @@ def test_stream_major_kernel_rejects_what_it_cannot_do(torch_cuda, F):
     far = F.compile(F.from_sexpr(("seq", ("in", 1), ("add", ("in", 1), ("del", 1, 300)))))
     with pytest.raises(F.FlowzError):
         far.run_block_stream_major(torch.zeros((8, 32, 1), device="cuda"))
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_host_stream_major_buffers(torch_cuda, F, pinned):
+    """fz_bank_process_host_stream_major: host rows per stream in, host rows per stream out (the reference's
+    calling convention), pipelined 2-D copies + the stream-major kernel; state carried across calls."""
+    torch = torch_cuda
+    ns, T = 32768, 1100                                   # 2 chunks of 256 samples ... ragged last chunk
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    xd = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(xd, SEED + 97)
+    want, st = prog.run_block(xd)
+    xs = torch.empty((ns, T, 1), dtype=torch.float32, pin_memory=pinned)
+    xs.copy_(xd.permute(1, 0, 2))
+    bank = prog.bank(ns)
+    y = bank.process_host_stream_major(xs if pinned else xs.numpy())
+    y = y if pinned else torch.from_numpy(y)
+    assert torch.equal(y.permute(1, 0, 2).contiguous(), want.cpu())
+    x2 = torch.empty((37, ns, 1), dtype=torch.float32, device="cuda")        # a short odd block, carried state
+    F.synth_fill(x2, SEED + 98)
+    want2, _ = prog.run_block(x2, state=st)
+    y2 = bank.process_host_stream_major(np.ascontiguousarray(x2.permute(1, 0, 2).cpu().numpy()))
+    assert np.array_equal(np.transpose(y2, (1, 0, 2)), want2.cpu().numpy())

@@ -41,3 +41,17 @@ for name, pinned in (("pinned", True), ("pageable", False)):
         ts.append(time.perf_counter() - t0)
     t = min(ts[1:])
     print(f"sequential H2D, kernel, D2H, {name:8s}: {t * 1e3:8.2f} ms  {ns * T / t / 1e6:9.1f} Msamples/s  {gb / t:6.1f} GB/s")
+
+# the reference's own calling convention: one contiguous host buffer per stream
+for name, pinned in (("pinned", True), ("pageable", False)):
+    xs = torch.empty((ns, T, 1), dtype=torch.float32, pin_memory=pinned)
+    xs.copy_(xd.permute(1, 0, 2))
+    outs = torch.empty((ns, T, 1), dtype=torch.float32, pin_memory=pinned)
+    ts = []
+    for _ in range(4):
+        bank.reset()
+        t0 = time.perf_counter()
+        bank.process_host_stream_major(xs, out=outs)
+        ts.append(time.perf_counter() - t0)
+    t = min(ts[1:])
+    print(f"stream-major host rows, {name:8s}: {t * 1e3:8.2f} ms  {ns * T / t / 1e6:9.1f} Msamples/s  {gb / t:6.1f} GB/s over PCIe (both directions)")

@@ -109,6 +109,7 @@ def _load():
         "fz_bank_process_tiled": (ctypes.c_int, [P, P, P, u32, u32, ctypes.POINTER(Variant), P]),
         "fz_bank_tune": (ctypes.c_int, [P, P, P, u32, u32, P, ctypes.POINTER(Variant), ctypes.POINTER(f32)]),
         "fz_bank_process_host": (ctypes.c_int, [P, P, P, u32]),
+        "fz_bank_process_host_stream_major": (ctypes.c_int, [P, P, P, u32]),
         "fz_bank_process_host_f64": (ctypes.c_int, [P, P, P, u32]),
         "fz_device_count": (ctypes.c_int, []),
         "fz_synth_fill": (ctypes.c_int, [P, u64, u32, u32, u32, u64, u64, u32, P]),

@@ -973,6 +973,66 @@ int fz_bank_process_host(fz_bank* b, const float* in_host, float* out_host, uint
    return bank_process_host(b, in_host, out_host, n_samples, false);
 }
 
+// Host buffers in the reference's own calling convention: one contiguous sample buffer per stream
+// ([n_streams][n_samples][wires]).  Time chunks travel as 2-D copies (one row per stream) into compact
+// device patches [n_streams][chunk][wires], run through the stream-major kernel and travel back; the
+// same three-stream pipeline as the frame path.
+int fz_bank_process_host_stream_major(fz_bank* b, const float* in_host, float* out_host, uint32_t n_samples)
+{
+   FZ_GUARD(
+      if (!b || !out_host || !n_samples) fail(FZ_E_INVALID, "fz_bank_process_host_stream_major: bad arguments");
+      check_bank_device(b);
+      const Graph& g = b->prog->g;
+      if (g.n_in && !in_host) fail(FZ_E_INVALID, "in_host is null but the graph has input wires");
+      const uint32_t nw = std::max<uint32_t>(std::max(g.n_in, g.n_out), 1);
+      constexpr size_t kChunkBytes = 32u << 20;
+      uint32_t chunk_t = (uint32_t)std::max<size_t>(32, kChunkBytes / ((size_t)b->n_streams * nw * 4) / 32 * 32);
+      chunk_t = std::min(chunk_t, (n_samples + 31u) / 32u * 32u);
+      const size_t ipitch = (size_t)chunk_t * g.n_in * 4, opitch = (size_t)chunk_t * g.n_out * 4;     // device rows
+      const size_t hip = (size_t)n_samples * g.n_in * 4, hop = (size_t)n_samples * g.n_out * 4;       // host rows
+      ensure_stage(b, 2 * ipitch * b->n_streams, 2 * opitch * b->n_streams);
+      if (!b->s_h2d) {
+         FZ_HIP(hipStreamCreateWithFlags(&b->s_h2d, hipStreamNonBlocking));
+         FZ_HIP(hipStreamCreateWithFlags(&b->s_run, hipStreamNonBlocking));
+         FZ_HIP(hipStreamCreateWithFlags(&b->s_d2h, hipStreamNonBlocking));
+         for (int i = 0; i < 2; ++i) {
+            FZ_HIP(hipEventCreateWithFlags(&b->ev_in[i], hipEventDisableTiming));
+            FZ_HIP(hipEventCreateWithFlags(&b->ev_run[i], hipEventDisableTiming));
+            FZ_HIP(hipEventCreateWithFlags(&b->ev_out[i], hipEventDisableTiming));
+         }
+      }
+      FZ_HIP(hipDeviceSynchronize());
+      const fz_variant sm{0, 0, 0, FZ_VF_STREAM_MAJOR};
+      const char* hin = reinterpret_cast<const char*>(in_host);
+      char* hout = reinterpret_cast<char*>(out_host);
+      uint32_t k = 0;
+      for (uint32_t t0 = 0; t0 < n_samples; t0 += chunk_t, ++k) {
+         const uint32_t nt = std::min(chunk_t, n_samples - t0);
+         const int slot = (int)(k & 1u);
+         float* din = reinterpret_cast<float*>(reinterpret_cast<char*>(b->stage_in) + (size_t)slot * ipitch * b->n_streams);
+         float* dout = reinterpret_cast<float*>(reinterpret_cast<char*>(b->stage_out) + (size_t)slot * opitch * b->n_streams);
+         if (g.n_in) {
+            if (k >= 2) FZ_HIP(hipStreamWaitEvent(b->s_h2d, b->ev_run[slot], 0));
+            FZ_HIP(hipMemcpy2DAsync(din, ipitch, hin + (size_t)t0 * g.n_in * 4, hip, (size_t)nt * g.n_in * 4, b->n_streams,
+                                    hipMemcpyHostToDevice, b->s_h2d));
+            FZ_HIP(hipEventRecord(b->ev_in[slot], b->s_h2d));
+            FZ_HIP(hipStreamWaitEvent(b->s_run, b->ev_in[slot], 0));
+         }
+         if (k >= 2) FZ_HIP(hipStreamWaitEvent(b->s_run, b->ev_out[slot], 0));
+         int rc = fz::launch(b->prog, g.n_in ? din : nullptr, dout, g.n_state ? b->state : nullptr, b->params, b->n_streams, nt, &sm,
+                             b->s_run, 0, chunk_t, 0);
+         if (rc != FZ_OK) return rc;
+         FZ_HIP(hipEventRecord(b->ev_run[slot], b->s_run));
+         FZ_HIP(hipStreamWaitEvent(b->s_d2h, b->ev_run[slot], 0));
+         FZ_HIP(hipMemcpy2DAsync(hout + (size_t)t0 * g.n_out * 4, hop, dout, opitch, (size_t)nt * g.n_out * 4, b->n_streams,
+                                 hipMemcpyDeviceToHost, b->s_d2h));
+         FZ_HIP(hipEventRecord(b->ev_out[slot], b->s_d2h));
+      }
+      FZ_HIP(hipStreamSynchronize(b->s_d2h));
+      FZ_HIP(hipStreamSynchronize(b->s_run));
+      return FZ_OK;)
+}
+
 int fz_bank_process_host_f64(fz_bank* b, const float* in_host, double* out_host, uint32_t n_samples)
 {
    return bank_process_host(b, in_host, out_host, n_samples, true);

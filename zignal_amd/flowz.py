@@ -450,6 +450,28 @@ class Bank:
                                              int(block_len), pp, tile, vp, torch.cuda.current_stream().cuda_stream))
         return out
 
+    def process_host_stream_major(self, x, out=None):
+        """Host buffers, one contiguous row per stream: x [n_streams, T, n_in] -> [n_streams, T, n_out] (numpy
+        arrays or CPU torch tensors; pinned memory overlaps the PCIe directions)."""
+        import numpy as np
+
+        is_torch = hasattr(x, "data_ptr")
+        T = int(x.shape[1])
+        if is_torch:
+            import torch
+            assert x.dtype == torch.float32 and x.is_contiguous() and not x.is_cuda
+            if out is None:
+                out = torch.empty((self.n_streams, T, self.prog.n_out), dtype=torch.float32, pin_memory=x.is_pinned())
+            xp, op = x.data_ptr(), out.data_ptr()
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            if out is None:
+                out = np.empty((self.n_streams, T, self.prog.n_out), np.float32)
+            xp, op = x.ctypes.data, out.ctypes.data
+        assert x.shape[0] == self.n_streams
+        C.check(C.lib.fz_bank_process_host_stream_major(self._h, xp if self.prog.n_in else None, op, T))
+        return out
+
     def process_host(self, x, out=None, out_f64: bool = False):
         """Host frames in, host frames out (time-major [T, n_streams, n_in] float32 -> [T, n_streams, n_out]).
         x / out: numpy arrays or CPU torch tensors; pinned tensors let both PCIe directions overlap with
