@@ -444,6 +444,13 @@ PACKABLE = {
     "one_quad_chain": G.one_quad_chain,
     "cascade4_distinct_coeffs": lambda: G.df1_cascade(4, [G.STABLE, G.PAR4_SETS[0], G.PAR4_SETS[1], G.PAR4_SETS[2]]),
     "df2_pair": lambda: G.seq(G.df2(*G.STABLE), G.df2(*G.PAR4_SETS[3])),
+    # scalar SUFFIX behind the chain: output gain, a smoothing one-pole with its own state, a mix with the
+    # chain's own delayed output (a delayed read shared with the last stage), prefix + suffix together
+    "cascade6_output_gain": lambda: G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1))),
+    "cascade4_smoothing_one_pole": lambda: G.seq(G.df1_cascade(4), G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 1)), G.mul(G.lit(0.5), G.IN(2))))),
+    "cascade6_mix_with_delayed_output": lambda: G.seq(G.df1_cascade(6), G.add(G.mul(G.lit(0.6), G.IN(1)), G.mul(G.lit(0.3), G.DEL(1, 2)))),
+    "cascade4_suffix_delay_beyond_the_chain": lambda: G.seq(G.df1_cascade(4), G.sub(G.IN(1), G.mul(G.lit(0.25), G.DEL(1, 5)))),
+    "integrator_cascade4_gain": lambda: G.seq(G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 1)), G.IN(2))), G.seq(G.df1_cascade(4), G.mul(G.IN(1), G.lit(1.5)))),
 }
 
 

@@ -191,7 +191,10 @@ def test_stage_split_detection_and_packed_kernel_builds(tmp_path, monkeypatch):
     monkeypatch.setenv("FLOWZ_HIP_CACHE", str(tmp_path))
     want = {"cascade6": (G.df1_cascade(6), 1), "cascade2": (G.df1_cascade(2), 1), "cascade5": (G.df1_cascade(5), 1),
             "df1": (G.df1(), 0), "osc": (G.osc_chain(6), 1), "one_quad_chain": (G.one_quad_chain(), 1),
-            "par4": (G.par4_sum(), 0), "cross_wire": (G.cross_wire(), 0)}
+            "par4": (G.par4_sum(), 0), "cross_wire": (G.cross_wire(), 0),
+            # a scalar suffix behind the chain (output gain; prefix + suffix)
+            "cascade6_gain": (G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1))), 1),
+            "osc_cascade_mix": (G.seq(G.osc_chain(6), G.add(G.mul(G.lit(0.6), G.IN(1)), G.mul(G.lit(0.3), G.DEL(1, 2)))), 1)}
     for name, (g, ok) in want.items():
         assert F.compile(F.from_sexpr(g)).stage_packable == ok, name
     p = F.compile(F.from_sexpr(G.df1_cascade(6)))
@@ -202,6 +205,10 @@ def test_stage_split_detection_and_packed_kernel_builds(tmp_path, monkeypatch):
     F.compile(F.from_sexpr(G.osc_chain(6))).build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))   # scalar prefix + 6 segments
     with pytest.raises(F.FlowzError):
         F.compile(F.from_sexpr(G.df1())).build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))
+    ps = F.compile(F.from_sexpr(want["osc_cascade_mix"][0]))
+    src = ps.source(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))
+    assert "#define FZ_NSEG 6" in src                         # still six packed segments, prefix and suffix scalar
+    ps.build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))
 
 
 @pytest.mark.parametrize("case", KA["result_types"], ids=lambda c: "tests.cpp:" + c["lines"])

@@ -33,6 +33,7 @@ def main():
     graphs = {"cascade6": lambda: G.df1_cascade(6), "par4": G.par4_sum, "par4f": G.par4_sum_fanout,
               "osc": lambda: G.osc_chain(6), "df1": G.df1, "df2": G.df2, "df1t": G.df1t, "df2t": G.df2t,
               "gain": lambda: G.mul(G.lit(0.5), G.IN(1)), "cascade2": lambda: G.df1_cascade(2), "cascade4": lambda: G.df1_cascade(4),
+              "cascade6g": lambda: G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1))),
               "cascade12": lambda: G.df1_cascade(12), "cascade24": lambda: G.df1_cascade(24)}
     prog = F.compile(F.from_sexpr(graphs[a.graph]()))
     ns, T = a.streams, a.samples

@@ -60,6 +60,8 @@ struct StageSplit {
    std::vector<PackedLine> lines;
    std::vector<uint32_t> prefix;                    // scalar prefix (nodes cuts[0] depends on), evaluation order
    std::vector<uint32_t> prefix_lines;              // delay lines private to the prefix (indices into Graph::lines)
+   std::vector<uint32_t> suffix;                    // scalar suffix (what the output makes of the chain's end wire), evaluation order
+   std::vector<uint32_t> suffix_lines;              // delay lines private to the suffix
 };
 
 // ---- lowered DAG ---------------------------------------------------------------------------------

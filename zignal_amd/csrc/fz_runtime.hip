@@ -373,6 +373,7 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
    std::vector<fz_variant> cands{fz_variant{0, 0, 0, 0}};
    if (d.flags & FZ_VF_STAGE_PACK) {
       cands.push_back(fz_variant{1, 24, 0, FZ_VF_STAGE_PACK});
+      cands.push_back(fz_variant{1, 32, 0, FZ_VF_STAGE_PACK});
    } else if (d.P == 2) {            // many streams, narrow frames: lane packing x prefetch depth x workgroups per CU
       cands.push_back(fz_variant{2, 16, 0, 0});
       cands.push_back(fz_variant{4, 8, 0, 0});

@@ -7,6 +7,8 @@
 // i and i+K/2 share ONE v_pk_mul_f32 / v_pk_add_f32 per node (with a packed coefficient pair).
 // c_0 may also be an internal wire: everything it depends on is then a scalar PREFIX that runs
 // un-packed together with segment 0 (an oscillator in front of a cascade, an odd first stage).
+// Likewise c_K need not be the output: what the output makes of it (an output gain, a smoothing
+// one-pole, the odd last stage) is a scalar SUFFIX that runs un-packed with the last segment.
 // A 6-stage biquad cascade becomes 3 independent packed instruction streams with a dependent
 // chain of 5 instead of one scalar chain of 30: half the instructions, six times the ILP.
 // Same arithmetic, same association order, same roundings per node: only the schedule is skewed
@@ -97,8 +99,8 @@ StageSplit find_stage_split(const Graph& g)
    uint32_t in = N;
    for (uint32_t i = 0; i < N; ++i)
       if (g.nodes[i].kind == FZ_IR_INPUT) in = i;
-   const uint32_t out = g.outputs[0];
-   if (in == N || !is_arith(g.nodes[out].kind)) return none;
+   const uint32_t gout = g.outputs[0];
+   if (in == N || !is_arith(g.nodes[gout].kind)) return none;
 
    // backward closure (operands and delay lines) and its operation count, for every arithmetic node
    std::vector<std::vector<char>> closure(N);
@@ -121,18 +123,43 @@ StageSplit find_stage_split(const Graph& g)
          } else if (n.kind == FZ_IR_DELAY) work.push_back(n.a);
       }
    }
-   if (cnt[out] != g.n_ops) return none;
+   if (cnt[gout] != g.n_ops) return none;
 
+   // chain end candidates: the output itself (no suffix), then every arithmetic wire e such that the
+   // rest of the graph (closure(output) minus closure(e)) is a scalar SUFFIX: it sees the chain only
+   // through e (now or delayed), constants and itself.  Later wires first (the shortest suffix).
+   std::vector<uint32_t> ends{gout};
+   for (uint32_t e = N; e-- > 0;) {
+      if (!is_arith(g.nodes[e].kind) || e == gout || !closure[gout][e] || (g.n_ops - cnt[e]) * 2 > g.n_ops) continue;
+      bool ok = true;
+      for (uint32_t v = 0; v < N && ok; ++v) {
+         if (!closure[gout][v] || closure[e][v]) continue;           // v is a suffix node
+         const Node& n = g.nodes[v];
+         auto fine = [&](uint32_t o) {                                // operand of a suffix node
+            if (!closure[e][o]) return true;                          // another suffix node
+            const uint32_t ok_kind = g.nodes[o].kind;
+            return o == e || ok_kind == FZ_IR_CONST || ok_kind == FZ_IR_PARAM ||
+                   (ok_kind == FZ_IR_DELAY && g.nodes[o].a == e);         // a delayed read of e shared with the chain
+         };
+         if (n.kind == FZ_IR_INPUT) ok = false;
+         else if (n.kind == FZ_IR_DELAY) ok = !closure[e][n.a] || n.a == e;
+         else if (is_arith(n.kind)) ok = fine(n.a) && (n.kind == FZ_IR_NEG || fine(n.b));
+      }
+      if (ok) ends.push_back(e);
+   }
+   // most segments first (the shortest dependent chains), then the shortest suffix, then the shortest prefix
+   for (uint32_t K = 8; K >= 2; K -= 2)
+   for (uint32_t out : ends) {
+   const uint32_t chain_ops = cnt[out];
    // chain input candidates: the graph input itself (no prefix), then every arithmetic wire p whose
    // closure is a scalar PREFIX evaluated at the time of segment 0 (e.g. an oscillator in front of a cascade)
    std::vector<uint32_t> starts{in};
    for (uint32_t c = 0; c < N; ++c)
-      if (is_arith(g.nodes[c].kind) && c != out && cnt[c] * 2 <= g.n_ops) starts.push_back(c);
-   for (uint32_t p0 : starts)
-   for (uint32_t K = 8; K >= 2; K -= 2) {
+      if (is_arith(g.nodes[c].kind) && c != out && closure[out][c] && cnt[c] * 2 <= chain_ops) starts.push_back(c);
+   for (uint32_t p0 : starts) {
       const uint32_t base = p0 == in ? 0u : cnt[p0];
-      if ((g.n_ops - base) % K) continue;
-      const uint32_t unit = (g.n_ops - base) / K;
+      if (chain_ops <= base || (chain_ops - base) % K) continue;
+      const uint32_t unit = (chain_ops - base) / K;
       // cut wires: nested closures with j * unit operations
       std::vector<uint32_t> cuts(K + 1, N);
       cuts[0] = p0;
@@ -152,7 +179,7 @@ StageSplit find_stage_split(const Graph& g)
       // segment of every arithmetic node
       std::vector<int> seg_of(N, -1);                      // -2: prefix
       for (uint32_t v = 0; v < N; ++v) {
-         if (!is_arith(g.nodes[v].kind)) continue;
+         if (!is_arith(g.nodes[v].kind) || !closure[out][v]) continue;   // (suffix nodes stay -1)
          if (p0 != in && closure[p0][v]) { seg_of[v] = -2; continue; }
          for (uint32_t j = 0; j < K; ++j)
             if (closure[cuts[j + 1]][v]) { seg_of[v] = (int)j; break; }
@@ -168,7 +195,7 @@ StageSplit find_stage_split(const Graph& g)
          return seg_of[o] == j;
       };
       for (uint32_t v = 0; v < N && clean; ++v) {
-         if (!is_arith(g.nodes[v].kind) || seg_of[v] == -2) continue;
+         if (!is_arith(g.nodes[v].kind) || seg_of[v] < 0) continue;
          const Node& n = g.nodes[v];
          clean = operand_ok(n.a, seg_of[v]) && (n.kind == FZ_IR_NEG || operand_ok(n.b, seg_of[v]));
       }
@@ -222,11 +249,18 @@ StageSplit find_stage_split(const Graph& g)
          const uint32_t src = g.lines[l].src;
          if (covered.count(src)) continue;
          const bool in_prefix = p0 != in && (src == in || closure[p0][src]);
-         if (!in_prefix) { s.ok = false; break; }
-         s.prefix_lines.push_back((uint32_t)l);
+         const bool in_suffix = out != gout && (src == out || (closure[gout][src] && !closure[out][src]));
+         if (in_prefix) s.prefix_lines.push_back((uint32_t)l);
+         else if (in_suffix) s.suffix_lines.push_back((uint32_t)l);
+         else { s.ok = false; break; }
       }
       if (!s.ok) continue;
+      // suffix: what the output makes of the chain's end wire, in evaluation order
+      if (out != gout)
+         for (uint32_t v = 0; v < N; ++v)
+            if (closure[gout][v] && !closure[out][v]) s.suffix.push_back(v);
       return s;
+   }
    }
    return none;
 }
