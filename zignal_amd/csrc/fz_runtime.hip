@@ -384,7 +384,10 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
       cands.push_back(fz_variant{4, 16, 256, FZ_VF_MAX_WG(1)});
       cands.push_back(fz_variant{4, 8, 128, FZ_VF_MAX_WG(2)});
       cands.push_back(fz_variant{4, 4, 256, FZ_VF_MAX_WG(2)});
-   } else if (n_streams >= (1u << 17)) {
+   } else {
+      cands.push_back(fz_variant{1, 32, 0, 0});
+   }
+   if (!(d.flags & FZ_VF_STAGE_PACK) && d.P != 2 && n_streams >= (1u << 17)) {
       cands.push_back(fz_variant{1, 16, 256, FZ_VF_MAX_WG(1)});
       cands.push_back(fz_variant{1, 8, 256, FZ_VF_MAX_WG(1)});
       cands.push_back(fz_variant{1, 16, 256, FZ_VF_MAX_WG(2)});
