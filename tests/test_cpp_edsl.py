@@ -9,13 +9,13 @@ ROOT = os.path.dirname(HERE)
 BUILD = os.path.join(HERE, "cpp", "_build")
 
 
-def build(name):
+def build(name, extra=()):
     os.makedirs(BUILD, exist_ok=True)
     exe = os.path.join(BUILD, name)
     libdir = os.path.join(ROOT, "zignal_amd", "lib")
     cmd = ["g++", "-std=gnu++14", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
            os.path.join(HERE, "cpp", name + ".cpp"), "-o", exe, "-L", libdir, "-lflowz_hip",
-           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", *extra]
     subprocess.check_call(cmd)
     return exe
 
@@ -31,3 +31,14 @@ def test_cpp_edsl_reference_tests_on_gpu():
     out = subprocess.run([build("test_edsl_gpu")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all GPU EDSL checks passed" in out.stdout
+
+
+def test_cpp_block_api_compiles():
+    build("test_block_api_gpu", ("-L/opt/rocm/lib", "-lamdhip64"))
+
+
+@pytest.mark.gpu
+def test_cpp_block_api_routes_agree_on_gpu():
+    out = subprocess.run([build("test_block_api_gpu", ("-L/opt/rocm/lib", "-lamdhip64"))], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all block API checks passed" in out.stdout
