@@ -671,10 +671,26 @@ def test_far_delay_minimum_and_tiled_layout(torch_cuda, F):
     assert ndiff(F.from_tiled(yt).cpu().numpy(), want) == 0
 
 
-def test_far_delay_with_mid_range_reader_is_rejected(F):
-    with pytest.raises(F.FlowzError) as ei:
-        F.compile(F.from_sexpr(G.add(G.DEL(1, 500), G.DEL(1, 20))))
-    assert ei.value.code == -6
+@pytest.mark.parametrize("mid", [9, 12, 20, 31])
+def test_far_delay_with_mid_range_reader(torch_cuda, F, mid):
+    """A wire delayed beyond the LDS (HBM ring) that is ALSO read 9..31 samples back: the ring read is
+    prefetched a chunk ahead, so the chunk shrinks to half the youngest read (unroll 4 for a 9-sample read)."""
+    torch = torch_cuda
+    g = G.seq(G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 1)), G.IN(2))),
+              G.add(G.add(G.mul(G.lit(0.25), G.DEL(1, 500)), G.mul(G.lit(-0.5), G.DEL(1, mid))), G.mul(G.lit(0.125), G.DEL(1, 3))))
+    prog = F.compile(F.from_sexpr(g))
+    ns, T = 300, 700
+    x = O.synth_input(SEED + 77, np.arange(ns), T)
+    want = O.compile(g, ns).run(x)
+    for P in (1, 2, 4):
+        got, _ = run_gpu(torch, F, prog, x, variant=F.make_variant(P, 0))
+        assert ndiff(got, want) == 0, P
+    xd = torch.from_numpy(x).cuda()
+    ya, st = prog.run_block(xd[:333].contiguous())
+    yb, _ = prog.run_block(xd[333:].contiguous(), state=st)
+    assert ndiff(torch.cat([ya, yb]).cpu().numpy(), want) == 0
+    with pytest.raises(F.FlowzError):
+        prog.run_block(xd, variant=F.make_variant(1, 16))                  # the chunk must stay <= mid / 2
 
 
 def test_large_graph_64_stages_320_coefficients(torch_cuda, F):

@@ -107,6 +107,7 @@ struct Graph {
    StageSplit split;                 // stage packing, when the graph allows it
    std::vector<FarRead> far_reads;   // distinct (far line, delay) pairs, in first-use order
    std::vector<uint32_t> far_lines;  // indices of far lines
+   uint32_t far_min_read = 0;        // smallest delay read from a far line's HBM ring (> kRegMaxDepth); 0: none
 };
 
 StageSplit find_stage_split(const Graph& g);
@@ -114,7 +115,7 @@ StageSplit find_stage_split(const Graph& g);
 // register-resident delay lines up to this depth; deeper ones become LDS rings
 constexpr uint32_t kRegMaxDepth = 8;
 constexpr uint32_t kLdsMaxDepth = 256;   // deeper lines live in HBM (ring in the state buffer)
-constexpr uint32_t kFarMinDelay = 32;    // a far read must be at least two prefetch chunks (2 x 16 steps) old
+constexpr uint32_t kFarMinDelay = 32;    // far reads at least this old allow the full 16-step prefetch chunk (a read must be two chunks old)
 
 Graph lower(const fz_expr* e);   // throws Error
 std::vector<uint32_t> max_input_delays(const fz_expr* e);

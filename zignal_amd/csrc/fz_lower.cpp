@@ -448,13 +448,12 @@ Graph lower(const fz_expr* e)
       for (const Node& n : g.nodes) {
          if (n.kind != FZ_IR_DELAY || n.a != l.src) continue;
          if (n.b <= kRegMaxDepth) l.shadow = std::max(l.shadow, n.b);
-         else if (n.b < kFarMinDelay)
-            fail(FZ_E_UNSUPPORTED, "a wire delayed by more than " + std::to_string(kLdsMaxDepth) + " samples cannot also be read with a delay of 9.." +
-                                      std::to_string(kFarMinDelay - 1) + " (node " + std::to_string(l.src) + ")");
          else {
             bool seen = false;
             for (const FarRead& fr : g.far_reads) seen = seen || (fr.line == li && fr.n == n.b);
             if (!seen) g.far_reads.push_back(FarRead{(uint32_t)li, n.b});
+            // the ring read of step t is prefetched a chunk ahead: the younger the read, the shorter the chunk
+            g.far_min_read = g.far_min_read ? std::min(g.far_min_read, n.b) : n.b;
          }
       }
    }

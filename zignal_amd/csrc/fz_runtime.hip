@@ -209,11 +209,12 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    v.U = reqU ? reqU : ((v.P == 2 && n_streams >= (1u << 19) && g.n_in == 1 && g.n_out == 1 && reg_values <= 40) ? 32 : 16);
    if (!reqU && reg_state * v.P > 60) v.U = 8;
    if (!g.far_lines.empty()) {
-      // far (HBM ring) reads are prefetched one chunk ahead: the chunk must be shorter than half the
-      // smallest far delay (kFarMinDelay = 32)
-      if (reqU > 16) fail(FZ_E_INVALID, "graphs with delays beyond LDS need unroll <= 16");
+      // far (HBM ring) reads are prefetched one chunk ahead: a read must be two chunks old, so the chunk
+      // is at most half the youngest ring read (16 steps from kFarMinDelay = 32 on, 4 for a 9-sample read)
+      const uint32_t cap = std::min(16u, std::max(1u, g.far_min_read ? g.far_min_read / 2 : 16u));
+      if (reqU > cap) fail(FZ_E_INVALID, "graphs with delays beyond LDS need unroll <= " + std::to_string(cap));
       if (v.flags & FZ_VF_PREFETCH3) fail(FZ_E_INVALID, "FZ_VF_PREFETCH3 is not available with delays beyond LDS");
-      v.U = std::min(v.U, 16u);
+      v.U = std::min(v.U, cap);
    }
    // stage packing: one stream per lane, pairs of isomorphic graph segments in one v_pk_* (fz_split.cpp)
    if (v.flags & FZ_VF_STAGE_PACK) {
