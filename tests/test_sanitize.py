@@ -37,7 +37,12 @@ def test_lowering_and_codegen_under_asan_ubsan(tmp_path):
         lines.append(prefix(R.make_typed(seed)[0]))
     for g in (G.df1_cascade(6), G.df1_cascade(7), G.par4_sum(), G.par4_sum_fanout(), G.osc_chain(6), G.cross_wire(),
               G.one_pole_readme(), G.mixed_precision_biquad(), G.complex_mix(), G.df1t(), G.df2t(),
-              ("seq", ("in", 1), ("del", 1, 300)), ("seq", ("in", 1), ("add", ("del", 1, 40), ("del", 1, 5000)))):
+              ("seq", ("in", 1), ("del", 1, 300)), ("seq", ("in", 1), ("add", ("del", 1, 40), ("del", 1, 5000))),
+              ("seq", ("in", 1), ("add", ("del", 1, 12), ("del", 1, 700))),                       # far line + mid-range read
+              G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1))),                               # stage packing with a suffix
+              G.seq(G.osc_chain(6), G.add(G.mul(G.lit(0.6), G.IN(1)), G.mul(G.lit(0.3), G.DEL(1, 2)))),
+              G.seq(G.df1_cascade(4), G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 1)), G.mul(G.lit(0.5), G.IN(2))))),
+              G.seq(G.df1_cascade(4), G.sub(G.IN(1), G.mul(G.lit(0.25), G.DEL(1, 5))))):
         lines.append(prefix(g))
     # malformed: delay-free loop, missing wires, complex into delay, complex with double, bad arity operands
     for g in (("fb", ("add", ("in", 1), ("in", 2))), ("seq", ("in", 1), ("in", 3)), ("fb", ("in", 1)),
