@@ -19,7 +19,12 @@
 // lowers it and builds ONE fused gfx950 kernel, and the closure's state lives in HBM.  The
 // per-sample call works (it launches the kernel for 1 stream x 1 sample), but the intended use
 // is the block API: f.bank(n_streams).process(in, out, n_samples) evaluates n_samples samples
-// of n_streams independent closures per launch.  There is no CPU evaluation path.
+// of n_streams independent closures per launch.  The bank also takes stream-tiled frames
+// (process_tiled), one contiguous buffer per stream (process_stream_major, the reference's own calling
+// convention), host memory (process_host, process_host_stream_major: pipelined over PCIe), blocks with
+// per-block coefficient sets (process_blocks) and can measure its kernel plan once (tune).
+// std::complex<float> terminals make complex wires (results through call_flat), double literals double
+// sub-expressions (call_f64).  There is no CPU evaluation path.
 // Malformed graphs throw flowz::error from compile() instead of failing template instantiation.
 #pragma once
 
