@@ -970,3 +970,29 @@ def test_host_stream_major_buffers(torch_cuda, F, pinned):
     want2, _ = prog.run_block(x2, state=st)
     y2 = bank.process_host_stream_major(np.ascontiguousarray(x2.permute(1, 0, 2).cpu().numpy()))
     assert np.array_equal(np.transpose(y2, (1, 0, 2)), want2.cpu().numpy())
+
+
+def test_autotune_env_measures_the_plan_on_first_use(torch_cuda):
+    """FLOWZ_HIP_AUTOTUNE=1: the first big block of a shape selects its plan by itself; state and results are
+    what a plain launch gives (own process: the knob is read once per process)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import torch, graphs as G
+from zignal_amd import flowz as F
+prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+ns, T, tile = 1 << 18, 256, 8192
+x = torch.empty((ns // tile, T, tile, 1), device="cuda"); F.synth_fill(x, 5)
+ref, st_ref = prog.run_block(x, variant=F.make_variant(1, 8))
+y, st = prog.run_block(x)                     # measures, restores the state, then runs the block
+y2, st2 = prog.run_block(x, state=st.clone())  # uses the remembered plan
+r2, sr2 = prog.run_block(x, state=st_ref.clone(), variant=F.make_variant(1, 8))
+assert torch.equal(y, ref) and torch.equal(st, st_ref) and torch.equal(y2, r2) and torch.equal(st2, sr2)
+print("autotune ok")
+'''
+    env = dict(os.environ, FLOWZ_HIP_AUTOTUNE="1", FLOWZ_HIP_DEBUG="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "autotune ok" in out.stdout, out.stdout + out.stderr[-2000:]
+    assert out.stderr.count("[flowz_hip] tune ") >= 5                   # the candidates were measured

@@ -6,6 +6,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -159,6 +160,7 @@ struct fz_program {
    // measured plans (fz_program_tune): (n_streams, tile_streams, device) -> the variant to use when the
    // caller passes none
    std::map<std::tuple<uint64_t, uint32_t, int>, fz_variant> plans;
+   std::set<std::tuple<uint64_t, uint32_t, int>> tuned_default;   // shapes measured already (FLOWZ_HIP_AUTOTUNE)
 };
 
 namespace fz {

@@ -310,11 +310,49 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    if (!uv) {                                               // a measured plan for this shape on this device?
       int dev = 0;
       FZ_HIP(hipGetDevice(&dev));
-      std::lock_guard<std::mutex> lock(p->mu);
-      auto it = p->plans.find(std::make_tuple(n_streams, tile_streams, dev));
-      if (it != p->plans.end()) {
-         planned = it->second;
-         uv = &planned;
+      const auto key = std::make_tuple(n_streams, tile_streams, dev);
+      bool known = false;
+      {
+         std::lock_guard<std::mutex> lock(p->mu);
+         auto it = p->plans.find(key);
+         known = it != p->plans.end() || p->tuned_default.count(key) != 0;
+         if (it != p->plans.end()) {
+            planned = it->second;
+            uv = &planned;
+         }
+      }
+      // FLOWZ_HIP_AUTOTUNE=1: the first big block of a shape measures the plan by itself (on the caller's
+      // buffers; the state is saved and restored around the measurement, `out` is recomputed below)
+      static const bool autotune = [] { const char* e = std::getenv("FLOWZ_HIP_AUTOTUNE"); return e && *e && *e != '0'; }();
+      if (autotune && !known && rows_total == n_samples && row0 == 0 && n_streams * (uint64_t)n_samples >= (1ull << 26)) {
+         {
+            std::lock_guard<std::mutex> lock(p->mu);
+            p->tuned_default.insert(key);                   // (also stops the recursion through tune -> launch)
+         }
+         const size_t sb = (size_t)g.n_state * n_streams * 4;
+         float* saved = nullptr;
+         if (sb) {
+            FZ_HIP(hipMalloc((void**)&saved, sb));
+            FZ_HIP(hipMemcpyAsync(saved, state, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+         }
+         fz_variant chosen{0, 0, 0, 0};
+         int rc = FZ_OK;
+         try {
+            rc = tune(p, in, out, state, params, n_streams, n_samples, tile_streams, stream, &chosen, nullptr);
+         } catch (...) {
+            if (saved) (void)hipFree(saved);
+            throw;
+         }
+         if (sb) {
+            FZ_HIP(hipMemcpyAsync(state, saved, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            FZ_HIP(hipStreamSynchronize((hipStream_t)stream));
+            (void)hipFree(saved);
+         }
+         if (rc != FZ_OK) return rc;
+         if (chosen.streams_per_lane || chosen.unroll || chosen.block_threads || chosen.flags) {
+            planned = chosen;
+            uv = &planned;
+         }
       }
    }
    Variant v = resolve_variant(g, uv, n_streams, n_samples);
