@@ -94,6 +94,15 @@ def df1_cascade(coefs, x, stream_major=False):
     return _run("fzo_df1_cascade", (_coefs(coefs), ctypes.c_int(len(coefs))), x, 1, 1, stream_major)
 
 
+def df1_cascade_soa(coefs, x):
+    """Vectorised-across-streams variant ("Mode B"): x time-major [T, n_streams] or [T, n_streams, 1] -> same shape."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    T, ns = x.shape[0], x.shape[1]
+    y = np.empty_like(x)
+    lib().fzo_df1_cascade_soa(_coefs(coefs), ctypes.c_int(len(coefs)), _p(x), _p(y), ctypes.c_long(ns), ctypes.c_long(T))
+    return y
+
+
 def df2(c, x, stream_major=False):
     return _run("fzo_df2", (_coefs([c]),), x, 1, 1, stream_major)
 

@@ -64,6 +64,43 @@ void fzo_df1_cascade(const fzo_coef* coef, int n_stage,
    }
 }
 
+/* "Mode B" (SURVEY 8d): the same closures with the streams in SoA form so that the compiler can
+ * vectorise ACROSS streams (the arithmetic per stream is untouched: same operations, same order, no
+ * FMA) -- a CPU stronger than the reference's scalar closure, reported separately by bench.py.
+ * Time-major frames x[t][s], y[t][s]; `work` holds 4 * n_stage * W floats of state (W streams per pass).
+ * target_clones: the library is built in one container and runs on another host.                    */
+#define FZO_SOA_W 256
+__attribute__((target_clones("avx512f", "avx2", "default")))
+void fzo_df1_cascade_soa(const fzo_coef* coef, int n_stage, const float* x, float* y, long n_streams, long T)
+{
+   float st[FZO_MAX_STAGES][4][FZO_SOA_W];
+   float v[FZO_SOA_W];
+   for (long s0 = 0; s0 < n_streams; s0 += FZO_SOA_W) {
+      const long w = n_streams - s0 < FZO_SOA_W ? n_streams - s0 : FZO_SOA_W;
+      for (int k = 0; k < n_stage; ++k)
+         for (int j = 0; j < 4; ++j)
+            for (long i = 0; i < w; ++i) st[k][j][i] = 0.f;
+      for (long t = 0; t < T; ++t) {
+         const float* xp = x + t * n_streams + s0;
+         float* yp = y + t * n_streams + s0;
+         for (long i = 0; i < w; ++i) v[i] = xp[i];
+         for (int k = 0; k < n_stage; ++k) {
+            const fzo_coef c = coef[k];
+            float* x1 = st[k][0]; float* x2 = st[k][1]; float* y1 = st[k][2]; float* y2 = st[k][3];
+            for (long i = 0; i < w; ++i) {
+               const float x0 = v[i];
+               const float f = (c.b0 * x0 + c.b1 * x1[i]) + c.b2 * x2[i];
+               const float o = (f + c.a1 * y1[i]) + c.a2 * y2[i];
+               x2[i] = x1[i]; x1[i] = x0;
+               y2[i] = y1[i]; y1[i] = o;
+               v[i] = o;
+            }
+         }
+         for (long i = 0; i < w; ++i) yp[i] = v[i];
+      }
+   }
+}
+
 /* ---- DF2  `bwd |= fwd` (test/benchmark.cpp:62):
  *   u = (x + a1*u1) + a2*u2 ;  y = (b0*u + b1*u1) + b2*u2                               */
 void fzo_df2(const fzo_coef* c, const float* x, ptrdiff_t xss, ptrdiff_t xts,

@@ -75,6 +75,13 @@ def test_c_osc_chain_vs_python():
     assert np.isfinite(got).all() and np.abs(got).max() > 0
 
 
+def test_vectorised_across_streams_variant_is_bit_identical():
+    """"Mode B" CPU baseline: SoA state, compiler-vectorised over streams -- the same bits as the scalar closures."""
+    x = O.synth_input(5, np.arange(700), 96)                       # ragged: 2 full passes of 256 + 188
+    coefs = [G.STABLE, G.PAR4_SETS[0], G.PAR4_SETS[1], G.PAR4_SETS[2], G.STABLE, G.PAR4_SETS[3]]
+    assert same(C.df1_cascade_soa(coefs, x), C.df1_cascade(coefs, x))
+
+
 def test_stream_major_layout_equivalent():
     x = O.synth_input(3, np.arange(4), 50)
     a = C.df1_cascade([G.STABLE] * 6, x)
