@@ -10,80 +10,250 @@ already resident in HBM.  Rank 0 prints ONE JSON line.
   roofline   dominant kernel fz_block_kernel: algorithmic bytes per launch / its average launch
              duration = HIP-event time over the K back-to-back launches of the timed region / K,
              events recorded on the launch stream (torch's current stream, which run_block uses);
-             peak = 8000 GB/s (HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md)
+             peak = 8000 GB/s (HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md);
+             traffic = PMC bytes of THIS kernel symbol on THIS workload (profiles/pmc_traffic.json,
+             collected by tools/profile_round.sh), null when that symbol was not profiled;
+             sustained = the same launches back to back for >= 2 s (power-managed clocks settle)
   cpu_baseline  the compiled scalar oracle (one closure per stream, one call per sample: what
              the reference's compile()-callable does) timed on this box's host cores on a
-             bounded sample of the same workload, rank 0, N == 1 only; its outputs double as a
-             bitwise parity check of the GPU output for those streams.
+             bounded sample of the same workload, rank 0, N == 1 only (buffers pre-touched, threads
+             pinned); the oracle also checks the GPU output of >= 1024 random streams bit for bit.
+  config2/3/4   the other single-GPU BASELINE configs at full size in the same run (rank 0, N == 1):
+             library-default and tuned plan, roofline fraction, oracle parity on >= 1024 random streams.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-SEED = 20160512
 HBM_PEAK_GBS = 8000.0
+PARITY_STREAMS = 1024
 
 
-def cpu_baseline(n_samples, gpu_out_sampler):
-    """Time the compiled oracle on all host cores; returns (dict, parity string)."""
-    import concurrent.futures as cf
+# ---- CPU baseline --------------------------------------------------------------------------------------------------
+def cpu_topology():
+    """(logical cpus this process may use, one logical cpu per physical core among them)."""
+    avail = sorted(os.sched_getaffinity(0))
+    core_of = {}
+    try:
+        cpu = phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k = k.strip()
+            if k == "processor":
+                cpu, phys, core = int(v), 0, None
+            elif k == "physical id":
+                phys = int(v)
+            elif k == "core id":
+                core = int(v)
+                core_of[cpu] = (phys, core)
+    except OSError:
+        pass
+    seen, one_per_core = set(), []
+    for c in avail:
+        key = core_of.get(c, ("?", c))
+        if key not in seen:
+            seen.add(key)
+            one_per_core.append(c)
+    return avail, one_per_core
+
+
+def _cpu_threads_run(coracle, coefs, cpus, per_thread, n_samples, seed, reps=1, soa=False):
+    """One pinned thread per entry of `cpus`; every thread generates and first-touches its own buffers, then all
+    start together.  Returns (wall seconds of the timed part, outputs of thread 0)."""
+    import threading
 
     import numpy as np
 
-    import graphs as G
+    n = len(cpus)
+    gate = threading.Barrier(n)
+    t_begin, t_end, outs, errs = [0.0] * n, [0.0] * n, [None] * n, []
+
+    def work(i):
+        try:
+            try:
+                os.sched_setaffinity(0, {cpus[i]})           # pid 0 = the calling thread
+            except OSError:
+                pass
+            if soa:                                          # "Mode B": time-major SoA frames [T, streams]
+                x = coracle.synth_fill(seed, i * per_thread, per_thread, n_samples)
+            else:                                            # one contiguous buffer per stream (the CPU-friendly layout)
+                x = coracle.synth_fill(seed, i * per_thread, per_thread, n_samples, stream_major=True)
+            y = np.empty_like(x)
+            y.fill(0.0)                                      # pages mapped by the thread that will write them
+            gate.wait()
+            t_begin[i] = time.perf_counter()
+            for _ in range(reps):
+                if soa:
+                    coracle.df1_cascade_soa(coefs, x, out=y)
+                else:
+                    coracle.df1_cascade(coefs, x, stream_major=True, out=y)
+            t_end[i] = time.perf_counter()
+            outs[i] = y if i == 0 else None
+        except Exception as e:                               # pragma: no cover
+            errs.append(e)
+            try:
+                gate.abort()
+            except Exception:
+                pass
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+    return max(t_end) - min(t_begin), outs[0]
+
+
+def cpu_baseline(n_samples, seed, coefs):
+    """Time the compiled oracle on the host cores (SURVEY 8d Mode A, plus Mode B next to it)."""
+    import numpy as np
+
     from oracle import coracle
 
-    cores = os.cpu_count() or 1
-    coefs = [G.STABLE] * 6
-    per_thread = 64
-    # calibrate on a small piece, then size the sample for ~3 s per thread (bounded: 10-30 s CPU work)
-    x0 = coracle.synth_fill(SEED, 0, per_thread, n_samples, stream_major=True)
+    logical, physical = cpu_topology()
+    # single-thread calibration (pre-touched buffers): sizes the sample and is the per-thread yardstick
+    x0 = coracle.synth_fill(seed, 0, 64, n_samples, stream_major=True)
+    y0 = np.zeros_like(x0)
+    y0.fill(0.0)
+    coracle.df1_cascade(coefs, x0, stream_major=True, out=y0)
     t0 = time.perf_counter()
-    y0 = coracle.df1_cascade(coefs, x0, stream_major=True)
-    dt = time.perf_counter() - t0
-    rate = per_thread * n_samples / dt
-    per_thread = int(min(max(64, (3.0 * rate / n_samples) // 64 * 64), 8192))
-    chunks = [coracle.synth_fill(SEED, i * per_thread, per_thread, n_samples, stream_major=True) for i in range(cores)]
-    with cf.ThreadPoolExecutor(cores) as ex:
-        t0 = time.perf_counter()
-        outs = list(ex.map(lambda c: coracle.df1_cascade(coefs, c, stream_major=True), chunks))
-        wall = time.perf_counter() - t0
-    total = cores * per_thread * n_samples
-    base = {"value": round(total / wall / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{cores * per_thread} streams x {n_samples} samples, 6-stage DF1 cascade, scalar "
-                      f"closure per stream (oracle/flowz_oracle.c, gcc -O3 -ffp-contract=off), "
-                      f"{cores} threads, {wall:.2f} s wall"}
+    coracle.df1_cascade(coefs, x0, stream_major=True, out=y0)
+    rate1 = 64 * n_samples / (time.perf_counter() - t0)
+    per_thread = 1024                                        # streams per thread (32 MiB of frames in + out), passed `reps` times
+    reps = max(1, int(round(2.5 * rate1 / (per_thread * n_samples))))               # ~2.5 s per thread
+    runs = {}
+    for label, cpus in (("one_thread_per_physical_core", physical), ("one_thread_per_logical_cpu", logical)):
+        if label in runs or (label == "one_thread_per_logical_cpu" and len(logical) == len(physical)):
+            continue
+        wall, _ = _cpu_threads_run(coracle, coefs, cpus, per_thread, n_samples, seed, reps=reps)
+        tot = len(cpus) * per_thread * n_samples * reps
+        runs[label] = {"threads": len(cpus), "Msamples_per_s": round(tot / wall / 1e6, 1),
+                       "Msamples_per_s_per_thread": round(tot / wall / 1e6 / len(cpus), 3), "wall_s": round(wall, 2),
+                       "streams": len(cpus) * per_thread, "passes": reps}
+    best = max(runs, key=lambda k: runs[k]["Msamples_per_s"])
+    b = runs[best]
+    base = {"value": b["Msamples_per_s"], "unit": "Msamples/s", "cores": b["threads"], "kind": "port",
+            "Msamples_per_s_per_core": b["Msamples_per_s_per_thread"],
+            "single_thread_calibration_Msamples_per_s": round(rate1 / 1e6, 3),
+            "physical_cores": len(physical), "logical_cpus": len(logical), "threads_pinned": True, "runs": runs,
+            "sample": f"{b['streams']} streams x {n_samples} samples x {b['passes']} passes ({best}: {b['threads']} pinned threads), 6-stage DF1 cascade, "
+                      f"scalar closure per stream, one call per sample (oracle/flowz_oracle.c, gcc -O3 -ffp-contract=off), "
+                      f"buffers allocated and first-touched by their thread before the timed region, {b['wall_s']:.2f} s wall"}
     # "Mode B" (SURVEY 8d): the same closures vectorised ACROSS streams by the compiler (SoA state, avx2/avx512
     # clones) -- a CPU stronger than the reference's scalar closure, reported next to it
     try:
-        vec_streams = 1024                                   # per thread: 16 MiB of frames
-        xv = [coracle.synth_fill(SEED, i * vec_streams, vec_streams, n_samples) for i in range(cores)]      # [T, ns, 1]
-        y1 = coracle.df1_cascade_soa(coefs, xv[0])
-        ok_vec = bool(np.array_equal(y1[:, :64, 0].view(np.uint32), coracle.df1_cascade(coefs, xv[0][:, :64]).view(np.uint32)[:, :, 0]))
-        with cf.ThreadPoolExecutor(cores) as ex:
-            t0 = time.perf_counter()
-            reps = 12
-            list(ex.map(lambda c: [coracle.df1_cascade_soa(coefs, c) for _ in range(reps)], xv))
-            wall_v = time.perf_counter() - t0
+        vec_streams, reps = 1024, 12                           # per thread: 16 MiB of frames
+        xv = coracle.synth_fill(seed, 0, 256, n_samples)
+        ok_vec = bool(np.array_equal(coracle.df1_cascade_soa(coefs, xv).view(np.uint32), coracle.df1_cascade(coefs, xv).view(np.uint32)))
+        cpus = logical if best == "one_thread_per_logical_cpu" else physical
+        wall_v, _ = _cpu_threads_run(coracle, coefs, cpus, vec_streams, n_samples, seed, reps=reps, soa=True)
         base["vectorised_across_streams"] = {
-            "value": round(cores * vec_streams * reps * n_samples / wall_v / 1e6, 1), "unit": "Msamples/s", "cores": cores,
+            "value": round(len(cpus) * vec_streams * reps * n_samples / wall_v / 1e6, 1), "unit": "Msamples/s", "cores": len(cpus),
             "bitwise_equal_to_scalar": ok_vec,
             "note": "same arithmetic per stream, SoA state, compiler-vectorised (stronger than the reference's scalar closure)"}
     except Exception as e:                                  # never let the extra figure break the bench line
         base["vectorised_across_streams"] = {"error": str(e)[:200]}
-    # parity: GPU output of the first 64 streams vs the oracle's
-    got = gpu_out_sampler(64)                       # [T, 64] numpy
-    want = outs[0][:64, :, 0].T
-    nd = int((np.ascontiguousarray(got).view(np.uint32) != np.ascontiguousarray(want).view(np.uint32)).sum())
-    return base, ("bitwise-equal on 64 streams x %d samples" % n_samples) if nd == 0 else f"MISMATCH {nd} samples"
+    return base
+
+
+# ---- GPU side helpers ----------------------------------------------------------------------------------------------
+def frames(torch, dev, ns, T, w, tile):
+    return torch.empty((ns // tile, T, tile, w) if tile else (T, ns, w), dtype=torch.float32, device=dev)
+
+
+def pick_tile(ns, tile):
+    return tile if tile and ns % tile == 0 and tile < ns else 0
+
+
+def event_ms(torch, fn, reps):
+    """HIP events on the launch stream around `reps` back-to-back launches -> ms per launch."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def b_alg_of(prog, ns, T):
+    return ns * (4 * T * (prog.n_in + prog.n_out) + 8 * prog.n_state + 4 * prog.n_param)
+
+
+def gather_streams(torch, y, ids, tile):
+    """[T, len(ids), w] numpy of the streams `ids` (local indices) of a frame tensor."""
+    idt = torch.as_tensor(ids, device=y.device, dtype=torch.long)
+    if tile:
+        return y[idt // tile, :, idt % tile, :].permute(1, 0, 2).contiguous().cpu().numpy()
+    return y[:, idt].contiguous().cpu().numpy()
+
+
+def sample_ids(ns, k, seed):
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    return np.unique(np.concatenate([[0, 1, 63, 64, ns - 1], rng.integers(0, ns, k)]))
+
+
+def ndiff_bits(a, b):
+    import numpy as np
+
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return int((a.view(np.uint32) != b.view(np.uint32)).sum())
+
+
+def parity_string(nd, n_streams, T):
+    return f"bitwise-equal on {n_streams} random streams x {T} samples" if nd == 0 else f"MISMATCH {nd} samples"
+
+
+def traffic_of(kernel, workload_key):
+    """PMC HBM bytes per launch of exactly this kernel symbol on this workload, or None."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    return json.load(open(tpath)).get(f"{kernel}|{workload_key}")
+
+
+def measure_config(torch, F, prog, x, y, state, params, ns, T, tile, steps, workload_key, do_tune=True):
+    """library default and (optionally) the tuned plan of one workload: ms per launch, GB/s, fraction of peak."""
+    b = b_alg_of(prog, ns, T)
+    out = {}
+
+    def run(v):
+        prog.run_block(x, state=state, params=params, out=y, variant=v)
+
+    def timed(label, v):
+        for _ in range(3):
+            run(v)
+        torch.cuda.synchronize()
+        ms = event_ms(torch, lambda: run(v), steps)
+        k = prog.kernel_name(v, ns, T)
+        out[label] = {"kernel": k, "avg_launch_ms": round(ms, 4), "Msamples_per_s": round(ns * T / ms / 1e3, 1),
+                      "achieved_GBs": round(b / ms / 1e6, 1), "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4),
+                      "traffic": traffic_of(k, workload_key)}
+
+    timed("library_default", None)              # before any plan is recorded for this shape: what a caller who never tunes gets
+    tv = None
+    if do_tune:
+        tv, _ = prog.tune(x, state=state, params=params, out=y)
+        timed("tuned", tv)
+    out["algorithmic_bytes_per_launch"] = b
+    out["steps"] = steps
+    best = max((k for k in ("library_default", "tuned") if k in out), key=lambda k: out[k]["frac"])
+    out["frac"] = out[best]["frac"]
+    out["best_plan"] = best
+    return out, tv
 
 
 def main():
@@ -93,6 +263,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=1 << 20, help="streams PER GPU (weak scaling)")
     ap.add_argument("--samples", type=int, default=4096, help="samples per block")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --streams per GPU (config 5: 1 M per GPU); strong: --streams-total divided over the GPUs")
+    ap.add_argument("--streams-total", type=int, default=1 << 23, help="total streams of --scaling strong (SURVEY 8d config 5: 8 M)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl == RCCL over xGMI (default); gloo rehearses the N > 1 path when all ranks share one GPU")
     ap.add_argument("--lanes", type=int, default=0, help="streams per lane (0 = auto)")
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--block", type=int, default=0)
@@ -101,7 +276,11 @@ def main():
                     help="streams per frame tile (stream-tiled layout [tile][t][stream], the HBM-friendly "
                          "default); 0 = plain time-major [t][stream]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-config2", action="store_true", help="skip the secondary 65 536-stream measurement")
+    ap.add_argument("--no-config2", action="store_true", help="skip the 65 536-stream measurement (BASELINE configs[1])")
+    ap.add_argument("--no-config34", action="store_true", help="skip BASELINE configs[2] and [3] (4-parallel sum, oscillator chain)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s back-to-back run")
+    ap.add_argument("--only", default="", help="profiling aid: run ONLY this secondary config (config2|config3|config3f|config4) "
+                                               "with the forced / default variant and print its object")
     ap.add_argument("--no-autotune", action="store_true",
                     help="do not try the alternative kernel variants during warm-up (the pool's boxes differ by a few %%)")
     ap.add_argument("--time-major-too", action="store_true",
@@ -116,34 +295,138 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
-    import graphs as G
     from zignal_amd import dist as zdist
     from zignal_amd import flowz as F
+    from zignal_amd import workloads as W
 
+    SEED = W.SEED
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the flow-graph evaluator has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % n_dev)                # (gloo rehearsal: several ranks may share device 0)
+    dev = torch.device("cuda", local_rank % n_dev)
     distributed = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    stats_dev = dev if args.dist_backend == "nccl" else None
 
-    ns, T = args.streams, args.samples
-    begin, end = zdist.shard_range(ns * world, rank, world)      # this rank's global stream ids
-    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
-    variant = F.make_variant(args.lanes, args.unroll, args.block, args.flags)
-    tile = args.tile if args.tile and ns % args.tile == 0 and args.tile < ns else 0
-    shape = (ns // tile, T, tile, 1) if tile else (T, ns, 1)
-    x = torch.empty(shape, dtype=torch.float32, device=dev)
-    y = torch.empty(shape, dtype=torch.float32, device=dev)
+    T = args.samples
+    total = args.streams_total if args.scaling == "strong" else args.streams * world
+    begin, end = zdist.shard_range(total, rank, world)       # this rank's global stream ids
+    ns = end - begin
+    prog = F.compile(F.from_sexpr(W.df1_cascade(6)))
+    forced = bool(args.lanes or args.unroll or args.block or args.flags)
+    variant = F.make_variant(args.lanes, args.unroll, args.block, args.flags) if forced else None
+    tile = pick_tile(ns, args.tile)
+    lay = f"tile{tile}" if tile else "timemajor"
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- secondary configs (rank 0, N == 1): each frees its buffers before the next ---------------------------------
+    def config2():
+        ns2 = 65536
+        t2 = pick_tile(ns2, args.tile)
+        x2, y2 = frames(torch, dev, ns2, T, 1, t2), frames(torch, dev, ns2, T, 1, t2)
+        st2 = torch.zeros((prog.n_state, ns2), dtype=torch.float32, device=dev)
+        F.synth_fill(x2, SEED)
+        key = f"cascade6_{ns2}x{T}_" + (f"tile{t2}" if t2 else "timemajor")
+        if args.only:
+            for _ in range(20):
+                prog.run_block(x2, state=st2, out=y2, variant=variant)
+            ms = event_ms(torch, lambda: prog.run_block(x2, state=st2, out=y2, variant=variant), 200)
+            return {"kernel": prog.kernel_name(variant, ns2, T), "avg_launch_ms": round(ms, 4)}
+        for _ in range(20):
+            prog.run_block(x2, state=st2, out=y2)
+        res, tv = measure_config(torch, F, prog, x2, y2, st2, None, ns2, T, t2, 200, key, do_tune=not args.no_autotune)
+        st2.zero_()
+        prog.run_block(x2, state=st2, out=y2, variant=tv)
+        ids = sample_ids(ns2, PARITY_STREAMS, 12)
+        from oracle import coracle, flowz_oracle as O
+        want = coracle.df1_cascade([W.STABLE] * 6, O.synth_input(SEED, ids, T))
+        res["parity"] = parity_string(ndiff_bits(gather_streams(torch, y2, ids, t2), want), len(ids), T)
+        res["workload"] = f"6-stage DF1 cascade, {ns2} streams x {T}-sample block (BASELINE configs[1]), " + (f"tiled:{t2}" if t2 else "time-major")
+        # compatibility with round 1's keys: the best plan's figures at top level
+        res.update({k: res[res["best_plan"]][k] for k in ("avg_launch_ms", "Msamples_per_s", "achieved_GBs", "kernel")})
+        return res
+
+    def config3(fanout):
+        g = W.par4_sum_fanout() if fanout else W.par4_sum()
+        p3 = F.compile(F.from_sexpr(g))
+        t3 = pick_tile(ns3, p3.recommended_tile_streams())
+        x3, y3 = frames(torch, dev, ns3, T, p3.n_in, t3), frames(torch, dev, ns3, T, 1, t3)
+        st3 = torch.zeros((p3.n_state, ns3), dtype=torch.float32, device=dev)
+        F.synth_fill(x3, SEED)
+        key = ("par4f_" if fanout else "par4_") + f"{ns3}x{T}_" + (f"tile{t3}" if t3 else "timemajor")
+        if args.only:
+            for _ in range(3):
+                p3.run_block(x3, state=st3, out=y3, variant=variant)
+            ms = event_ms(torch, lambda: p3.run_block(x3, state=st3, out=y3, variant=variant), 5)
+            return {"kernel": p3.kernel_name(variant, ns3, T), "avg_launch_ms": round(ms, 4)}
+        res, tv = measure_config(torch, F, p3, x3, y3, st3, None, ns3, T, t3, 10, key, do_tune=not args.no_autotune)
+        st3.zero_()
+        p3.run_block(x3, state=st3, out=y3, variant=tv)
+        ids = sample_ids(ns3, PARITY_STREAMS, 13)
+        from oracle import coracle, flowz_oracle as O
+        xh = O.synth_input(SEED, ids, T, n_wires=p3.n_in)
+        nd_in = ndiff_bits(gather_streams(torch, x3, ids, t3), xh)
+        want = coracle.par4_sum(W.PAR4_SETS, xh, fanout=fanout)
+        nd = ndiff_bits(gather_streams(torch, y3, ids, t3), want)
+        res["parity"] = parity_string(nd + nd_in, len(ids), T)
+        res["workload"] = (("(_1,_1,_1,_1) |= " if fanout else "") + f"(bq|bq|bq|bq) |= (_1+_2+_3+_4), {p3.n_in} input wire(s), {ns3} streams x {T}-sample "
+                           f"block (BASELINE configs[2]), " + (f"tiled:{t3}" if t3 else "time-major"))
+        return res
+
+    def config4():
+        p4 = F.compile(F.from_sexpr(W.osc_chain(6)))
+        t4 = pick_tile(ns3, args.tile)
+        x4, y4 = frames(torch, dev, ns3, T, 1, t4), frames(torch, dev, ns3, T, 1, t4)
+        st4 = torch.zeros((p4.n_state, ns3), dtype=torch.float32, device=dev)
+        P = W.osc_chain_params(SEED + 1, np.arange(ns3))
+        pd = torch.from_numpy(P).to(dev)
+        x4.zero_()                                           # a dirac at t = 0 on every stream
+        (x4[:, 0] if t4 else x4[0]).fill_(1.0)
+        key = f"osc6_{ns3}x{T}_" + (f"tile{t4}" if t4 else "timemajor")
+        if args.only:
+            for _ in range(3):
+                p4.run_block(x4, state=st4, params=pd, out=y4, variant=variant)
+            ms = event_ms(torch, lambda: p4.run_block(x4, state=st4, params=pd, out=y4, variant=variant), 10)
+            return {"kernel": p4.kernel_name(variant, ns3, T), "avg_launch_ms": round(ms, 4)}
+        res, tv = measure_config(torch, F, p4, x4, y4, st4, pd, ns3, T, t4, 20, key, do_tune=not args.no_autotune)
+        st4.zero_()
+        p4.run_block(x4, state=st4, params=pd, out=y4, variant=tv)
+        ids = sample_ids(ns3, PARITY_STREAMS, 14)
+        from oracle import coracle
+        xh = np.zeros((T, len(ids), 1), np.float32)
+        xh[0] = 1.0
+        want = coracle.osc_chain(np.ascontiguousarray(P[:, ids]), xh)
+        res["parity"] = parity_string(ndiff_bits(gather_streams(torch, y4, ids, t4), want), len(ids), T)
+        res["workload"] = (f"resonator oscillator -> 6 x DF1, 31 per-stream coefficients, dirac drive, {ns3} streams x {T}-sample block "
+                           f"(BASELINE configs[3]), " + (f"tiled:{t4}" if t4 else "time-major"))
+        return res
+
+    ns3 = args.streams
+    if args.only:
+        fn = {"config2": config2, "config3": lambda: config3(False), "config3f": lambda: config3(True), "config4": config4}[args.only]
+        print(json.dumps({args.only: fn()}), flush=True)
+        return
+
+    # ---- the headline workload ------------------------------------------------------------------------------------------
+    x, y = frames(torch, dev, ns, T, 1, tile), frames(torch, dev, ns, T, 1, tile)
     state = torch.zeros((prog.n_state, ns), dtype=torch.float32, device=dev)
     F.synth_fill(x, SEED, stream0=begin)
     torch.cuda.synchronize()
@@ -152,23 +435,18 @@ def main():
     # variants for this shape on THIS board (fz_program_tune, the FFTW_MEASURE of this library; which one
     # wins differs from board to board) -- later launches without a variant use the winner
     tuned = None
-    if not args.no_autotune and not (args.lanes or args.unroll or args.block or args.flags):
+    if not args.no_autotune and not forced:
         variant, _ = prog.tune(x, state=state, out=y)
         tuned = prog.kernel_name(variant, ns, T)
         state.zero_()
 
-    # first block from zero state: kept for the parity check
+    # first block from zero state: kept for the parity check (>= 1024 random streams across all tiles)
     prog.run_block(x, state=state, out=y, variant=variant)
     torch.cuda.synchronize()
-    first64_dev = None
-    first64 = (y[0, :, :64, 0] if tile else y[:, :64, 0]).cpu().numpy() if rank == 0 else None
+    par_ids = sample_ids(ns, PARITY_STREAMS, 11) if rank == 0 else None
+    first_block = gather_streams(torch, y, par_ids, tile) if rank == 0 else None
     for _ in range(max(args.warmup - 1, 0)):
         prog.run_block(x, state=state, out=y, variant=variant)
-
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     # HIP events on the launch stream around the K back-to-back launches (one pair: an event per
     # launch costs tens of microseconds of GPU time each, visible on sub-millisecond kernels)
@@ -183,15 +461,22 @@ def main():
     wall = time.perf_counter() - t0
     kern_avg_s = ev0.elapsed_time(ev1) / args.steps / 1e3
 
-    checksum = float((y[:, -1] if tile else y[-1]).double().sum().item())      # last time step of every stream
-    stats = zdist.reduce_stats(wall, float(ns) * T * args.steps, checksum, device=dev)
+    checksum = zdist.bits_checksum(y[:, -1] if tile else y[-1])      # last time step of every stream: exact, shard-independent
+    stats = zdist.reduce_stats(wall, float(ns) * T * args.steps, checksum, device=stats_dev)
+    b_alg = b_alg_of(prog, ns, T)
+
+    # the same launches back to back for >= 2 s: whatever the power management does to the clocks has happened by then
+    sustained = None
+    if rank == 0 and world == 1 and not args.no_sustained:
+        n_sus = max(args.steps, int(math.ceil(2.0 / max(kern_avg_s, 1e-6))))
+        ms_sus = event_ms(torch, lambda: prog.run_block(x, state=state, out=y, variant=variant), n_sus)
+        sustained = {"launches": n_sus, "seconds": round(ms_sus * n_sus / 1e3, 3), "avg_launch_ms": round(ms_sus, 4),
+                     "achieved_GBs": round(b_alg / ms_sus / 1e6, 1), "frac": round(b_alg / ms_sus / 1e6 / HBM_PEAK_GBS, 4)}
 
     # the same workload on plain time-major frames [t][stream] (secondary figure, rank 0, N == 1)
     tm = None
     if args.time_major_too and tile and rank == 0 and world == 1:
-        del first64_dev
-        x2 = torch.empty((T, ns, 1), dtype=torch.float32, device=dev)
-        y2 = torch.empty((T, ns, 1), dtype=torch.float32, device=dev)
+        x2, y2 = frames(torch, dev, ns, T, 1, 0), frames(torch, dev, ns, T, 1, 0)
         st2 = torch.zeros((prog.n_state, ns), dtype=torch.float32, device=dev)
         F.synth_fill(x2, SEED, stream0=begin)
         vtm = variant
@@ -199,67 +484,36 @@ def main():
             vtm, _ = prog.tune(x2, state=st2, out=y2)               # its own plan: the layouts prefer different ones
         prog.run_block(x2, state=st2, out=y2, variant=vtm)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            prog.run_block(x2, state=st2, out=y2, variant=vtm)
-        e1.record()
-        torch.cuda.synchronize()
-        tm_ms = e0.elapsed_time(e1) / 5
+        tm_ms = event_ms(torch, lambda: prog.run_block(x2, state=st2, out=y2, variant=vtm), 5)
         tm = {"avg_launch_ms": round(tm_ms, 4), "Msamples_per_s": round(ns * T / tm_ms / 1e3, 1)}
-        del x2, y2, st2
-
-    # BASELINE config 2 (65 536 streams x 4096) in the same run, rank 0, N == 1: a different kernel
-    # variant (own symbol in the rocprof stats), 1 GiB of frames
-    cfg2 = None
-    if rank == 0 and world == 1 and not args.no_config2 and ns != 65536:
-        ns2 = 65536
-        t2 = tile if tile and ns2 % tile == 0 else 0
-        shp = (ns2 // t2, T, t2, 1) if t2 else (T, ns2, 1)
-        x2 = torch.empty(shp, dtype=torch.float32, device=dev)
-        y2 = torch.empty(shp, dtype=torch.float32, device=dev)
-        st2 = torch.zeros((prog.n_state, ns2), dtype=torch.float32, device=dev)
-        F.synth_fill(x2, SEED)
-        v2 = None
-        if tuned is not None:
-            v2, _ = prog.tune(x2, state=st2, out=y2)
-        for _ in range(20):
-            prog.run_block(x2, state=st2, out=y2, variant=v2)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(200):
-            prog.run_block(x2, state=st2, out=y2, variant=v2)
-        e1.record()
-        torch.cuda.synchronize()
-        ms2 = e0.elapsed_time(e1) / 200
-        b2 = ns2 * (4 * T * 2 + 8 * prog.n_state)
-        cfg2 = {"workload": f"6-stage DF1 cascade, {ns2} streams x {T}-sample block (BASELINE configs[1])",
-                "steps": 200, "warmup": 20, "avg_launch_ms": round(ms2, 4), "Msamples_per_s": round(ns2 * T / ms2 / 1e3, 1),
-                "achieved_GBs": round(b2 / ms2 / 1e6, 1), "frac": round(b2 / ms2 / 1e6 / HBM_PEAK_GBS, 4),
-                "kernel": prog.kernel_name(v2, ns2, T)}
         del x2, y2, st2
 
     # copy-kernel yardstick (same bytes in + out), rank 0 only
     copy_gbs = None
     if rank == 0:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         F.copy_probe(x, y)
         torch.cuda.synchronize()
-        e0.record()
-        for _ in range(3):
-            F.copy_probe(x, y)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 2.0 * x.numel() * 4 * 3 / (e0.elapsed_time(e1) / 1e3) / 1e9
+        copy_gbs = 2.0 * x.numel() * 4 / (event_ms(torch, lambda: F.copy_probe(x, y), 3) / 1e3) / 1e9
+
+    secondary = {}
+    if rank == 0 and world == 1:
+        del x, y, state
+        torch.cuda.empty_cache()
+        if not args.no_config2 and ns != 65536:
+            secondary["config2_65536_streams"] = config2()
+            torch.cuda.empty_cache()
+        if not args.no_config34:
+            secondary["config3_par4_sum"] = config3(False)
+            torch.cuda.empty_cache()
+            secondary["config3_par4_sum_fanout"] = config3(True)
+            torch.cuda.empty_cache()
+            secondary["config4_osc_chain"] = config4()
+            torch.cuda.empty_cache()
 
     if rank == 0:
-        b_alg = ns * (4 * T * (prog.n_in + prog.n_out) + 8 * prog.n_state + 4 * prog.n_param)
         achieved = b_alg / kern_avg_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"cascade6_{ns}x{T}_" + (f"tile{tile}" if tile else "timemajor"))
+        kname = prog.kernel_name(variant, ns, T)
+        traffic = traffic_of(kname, f"cascade6_{ns}x{T}_{lay}")
         line = {
             "metric": "Msamples/sec/GPU + achieved HBM GB/s, 6-biquad cascade, 1M streams",
             "value": round(stats["samples"] / stats["seconds"] / 1e6, 1),
@@ -267,35 +521,40 @@ def main():
             "per_gpu": round(stats["samples"] / stats["seconds"] / 1e6 / world, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(stats["seconds"] / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"6-stage DF1 biquad cascade (flowz fwd|=bwd x6), {ns} streams/GPU x {T}-sample block, "
                                    f"uniform stable coefficients, "
                                    + (f"stream-tiled frames [tile][t][{tile} streams]" if tile else "time-major frames [t][stream]"),
                        "layout": f"tiled:{tile}" if tile else "time-major",
-                       "streams_per_gpu": ns, "block_samples": T, "streams_total": ns * world,
-                       "parallelism": f"stream-sharded x{world}, no data-path collective",
+                       "streams_per_gpu": ns, "block_samples": T, "streams_total": total,
+                       "parallelism": f"stream-sharded x{world}, no data-path collective"
+                                      + (f" (statistics reduced over {args.dist_backend})" if distributed else ""),
                        "kernel_variant": {"streams_per_lane": args.lanes, "unroll": args.unroll,
                                           "block_threads": args.block, "flags": args.flags,
                                           "autotuned": tuned}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": prog.kernel_name(variant, ns, T), "algorithmic_bytes_per_launch": b_alg,
+                         "traffic_kernel": kname if traffic is not None else None,
+                         "kernel": kname, "algorithmic_bytes_per_launch": b_alg,
                          "avg_launch_ms": round(kern_avg_s * 1e3, 4),
                          "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None},
             "checksum": stats["checksum"],
         }
-        if cfg2 is not None:
-            line["config2_65536_streams"] = cfg2
+        if sustained is not None:
+            line["roofline"]["sustained"] = sustained
+        line.update(secondary)
         if tm is not None:
             tm["achieved_GBs"] = round(b_alg / (tm["avg_launch_ms"] / 1e3) / 1e9, 1)
             tm["frac"] = round(tm["achieved_GBs"] / HBM_PEAK_GBS, 4)
             line["time_major_layout"] = tm
         if world == 1 and not args.no_cpu_baseline:
-            base, parity = cpu_baseline(T, lambda k: first64[:, :k])
-            line["cpu_baseline"] = base
-            line["parity"] = parity
+            from oracle import coracle, flowz_oracle as O
+            coefs = [W.STABLE] * 6
+            want = coracle.df1_cascade(coefs, O.synth_input(SEED, par_ids + begin, T))
+            line["parity"] = parity_string(ndiff_bits(first_block, want), len(par_ids), T)
+            line["cpu_baseline"] = cpu_baseline(T, SEED, coefs)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

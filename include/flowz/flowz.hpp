@@ -28,6 +28,7 @@
 // Malformed graphs throw flowz::error from compile() instead of failing template instantiation.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <functional>
 #include <memory>
@@ -81,8 +82,8 @@ using ref_list = std::vector<std::pair<uint32_t, const float*>>;
 
 inline uint32_t next_uniform_id()
 {
-   static uint32_t n = 0;
-   return n++;
+   static std::atomic<uint32_t> n{0};      // expressions may be built on several threads
+   return n.fetch_add(1, std::memory_order_relaxed);
 }
 
 constexpr int imax(int a, int b) { return a > b ? a : b; }

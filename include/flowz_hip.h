@@ -183,6 +183,8 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
 /* bits 12..14 / 16..18: cache policy of frame loads / stores (experiment knob, see the kernel source) */
 
 int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */
+/* the same with the variant's automatic fields resolved as fz_run_block would for this block shape */
+int fz_program_build_for(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples);
 /* symbol of the variant's kernel as profilers show it, e.g. "fz_block_kernel_p2u32b256f0"; the
  * variant is resolved as fz_run_block would for (n_streams, n_samples); returns length          */
 long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples,
@@ -248,6 +250,10 @@ uint32_t fz_recommended_tile_streams(const fz_program* p);
  * per block.  Synchronises hip_stream.                                                            */
 int fz_program_tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
                     uint32_t n_samples, uint32_t tile_streams, void* hip_stream, fz_variant* chosen, float* chosen_ms);
+
+/* the variants fz_program_tune would measure for this shape (the first entry is the library default {0,0,0,0});
+ * writes min(n, cap) entries, returns n.  Pure host work: lets a build step pre-compile them (fz_program_build). */
+int fz_program_tune_candidates(fz_program* p, uint64_t n_streams, uint32_t n_samples, fz_variant* out, uint32_t cap);
 
 /* ------------------------------------------------------------------------------------------
  * fz_bank -- device-resident closure state for n_streams streams: the `state_` member of

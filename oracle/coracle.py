@@ -80,9 +80,14 @@ def _coefs(cs):
     return arr
 
 
-def _run(fname, pre_args, x, n_in, n_out, stream_major, out_dtype=F32, library=None):
+def _run(fname, pre_args, x, n_in, n_out, stream_major, out_dtype=F32, library=None, out=None):
     x, T, ns = _prep(x, n_in, stream_major)
-    y = np.empty((ns, T, n_out) if stream_major else (T, ns, n_out), out_dtype)
+    shape = (ns, T, n_out) if stream_major else (T, ns, n_out)
+    if out is None:
+        y = np.empty(shape, out_dtype)
+    else:                                   # caller-owned (pre-touched) result buffer: nothing is allocated in the call
+        y = out
+        assert y.shape == shape and y.dtype == out_dtype and y.flags.c_contiguous
     xss, xts = _strides(T, ns, n_in, stream_major)
     yss, yts = _strides(T, ns, n_out, stream_major)
     getattr(library or lib(), fname)(*pre_args, _p(x), _pd(xss), _pd(xts), _p(y), _pd(yss), _pd(yts),
@@ -90,15 +95,16 @@ def _run(fname, pre_args, x, n_in, n_out, stream_major, out_dtype=F32, library=N
     return y
 
 
-def df1_cascade(coefs, x, stream_major=False):
-    return _run("fzo_df1_cascade", (_coefs(coefs), ctypes.c_int(len(coefs))), x, 1, 1, stream_major)
+def df1_cascade(coefs, x, stream_major=False, out=None):
+    return _run("fzo_df1_cascade", (_coefs(coefs), ctypes.c_int(len(coefs))), x, 1, 1, stream_major, out=out)
 
 
-def df1_cascade_soa(coefs, x):
+def df1_cascade_soa(coefs, x, out=None):
     """Vectorised-across-streams variant ("Mode B"): x time-major [T, n_streams] or [T, n_streams, 1] -> same shape."""
     x = np.ascontiguousarray(x, dtype=F32)
     T, ns = x.shape[0], x.shape[1]
-    y = np.empty_like(x)
+    y = np.empty_like(x) if out is None else out
+    assert y.shape == x.shape and y.dtype == F32 and y.flags.c_contiguous
     lib().fzo_df1_cascade_soa(_coefs(coefs), ctypes.c_int(len(coefs)), _p(x), _p(y), ctypes.c_long(ns), ctypes.c_long(T))
     return y
 

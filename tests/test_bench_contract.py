@@ -29,4 +29,45 @@ def test_bench_json_contract_small_workload():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["parity"].startswith("bitwise-equal")
+    assert d["roofline"]["sustained"]["seconds"] >= 1.9 and d["roofline"]["sustained"]["frac"] > 0
+    assert "traffic_kernel" in d["roofline"]
+    for k in ("config2_65536_streams", "config3_par4_sum", "config3_par4_sum_fanout", "config4_osc_chain"):
+        assert d[k]["parity"].startswith("bitwise-equal"), (k, d[k]["parity"])
+        assert d[k]["library_default"]["frac"] > 0 and d[k]["tuned"]["kernel"].startswith("fz_block_kernel_p")
+    assert c["Msamples_per_s_per_core"] > 0 and c["physical_cores"] >= 1 and c["logical_cpus"] >= c["physical_cores"]
     assert abs(d["value"] - 16384 * 512 * 3 / (d["ms_per_step"] * 3 / 1e3) / 1e6) / d["value"] < 1e-2
+
+
+def _run_bench(args, nproc=1, timeout=900):
+    if nproc > 1:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_rehearse_the_sharded_path():
+    """The N > 1 path of bench.py (launcher env, shard_range, per-rank generator offset, barrier, max-over-ranks time,
+    the statistics all-reduce) with 2 ranks that share device 0 and reduce over gloo: the integer checksum of the two
+    shards must equal a single-process run over the union of the global stream ids.  Weak and strong scaling modes."""
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-autotune", "--no-config2", "--no-config34", "--no-sustained"]
+    one = _run_bench(["--gpus", "1", "--streams", "262144"] + common)
+    weak = _run_bench(["--gpus", "2", "--streams", "131072", "--dist-backend", "gloo"] + common, nproc=2)
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak"
+    assert weak["config"]["streams_total"] == 262144 and weak["config"]["streams_per_gpu"] == 131072
+    assert weak["checksum"] == one["checksum"] and isinstance(weak["checksum"], int)
+    assert abs(weak["value"] - 262144 * 4096 * 2 / (weak["ms_per_step"] * 2 / 1e3) / 1e6) / weak["value"] < 1e-2
+    strong = _run_bench(["--gpus", "2", "--scaling", "strong", "--streams-total", "262144", "--dist-backend", "gloo"] + common, nproc=2)
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["config"]["streams_total"] == 262144
+    assert strong["checksum"] == one["checksum"]

@@ -28,7 +28,7 @@ def _worker(rank, world, port, q):
     try:
         b, e = zdist.shard_range(1000, rank, world)
         # rank-local "work": seconds differ per rank, samples = shard size * T, checksum = sum of ids
-        st = zdist.reduce_stats(seconds=1.0 + rank, samples=float((e - b) * 16), checksum=float(sum(range(b, e))))
+        st = zdist.reduce_stats(seconds=1.0 + rank, samples=float((e - b) * 16), checksum=sum(range(b, e)))
         q.put((rank, st))
     finally:
         dist.destroy_process_group()
@@ -52,9 +52,9 @@ def test_reduce_stats_world2_gloo():
         assert res[r]["world"] == 2
         assert res[r]["seconds"] == 2.0                      # max over ranks
         assert res[r]["samples"] == 1000 * 16                # sum over ranks
-        assert res[r]["checksum"] == float(sum(range(1000)))
+        assert res[r]["checksum"] == sum(range(1000)) and isinstance(res[r]["checksum"], int)
 
 
 def test_reduce_stats_single_process_identity():
-    st = zdist.reduce_stats(0.5, 10.0, 3.0)
-    assert st == {"seconds": 0.5, "samples": 10.0, "checksum": 3.0, "world": 1}
+    st = zdist.reduce_stats(0.5, 10.0, 3)
+    assert st == {"seconds": 0.5, "samples": 10.0, "checksum": 3, "world": 1}

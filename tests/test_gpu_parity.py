@@ -342,14 +342,15 @@ def test_config2_cascade6_65536x4096_full_block(torch_cuda, F):
 
 
 def test_config3_par4_sum_1M_streams(torch_cuda, F):
-    """BASELINE config 3: 4 parallel biquads summed, 1 M streams (4 input wires per frame)."""
+    """BASELINE config 3 at full size: 4 parallel biquads summed, 1 M streams x 4096 samples (4 input wires per
+    frame: 64 GiB of input frames, 16 GiB of output)."""
     torch = torch_cuda
-    ns, T = 1 << 20, 1024
+    ns, T = 1 << 20, 4096
     prog = F.compile(F.from_sexpr(G.par4_sum()))
     x = torch.empty((T, ns, 4), dtype=torch.float32, device="cuda")
     F.synth_fill(x, SEED)
     y, _ = prog.run_block(x)
-    ids = _sample_ids(ns, 512, 2)
+    ids = _sample_ids(ns, 1024, 2)
     xh = O.synth_input(SEED, ids, T, n_wires=4)
     idt = torch.from_numpy(ids).cuda()
     assert ndiff(x[:, idt].cpu().numpy(), xh) == 0
@@ -367,11 +368,11 @@ def test_config3_par4_sum_1M_streams(torch_cuda, F):
 
 
 def test_config4_osc_chain_1M_streams(torch_cuda, F):
-    """BASELINE config 4: resonator oscillator -> 6 biquads, per-stream coefficients, 1 M streams."""
+    """BASELINE config 4 at full size: resonator oscillator -> 6 biquads, per-stream coefficients, 1 M streams x 4096."""
     torch = torch_cuda
-    ns, T = 1 << 20, 1024
+    ns, T = 1 << 20, 4096
     prog = F.compile(F.from_sexpr(G.osc_chain(6)))
-    ids = _sample_ids(ns, 512, 3)
+    ids = _sample_ids(ns, 1024, 3)
     P = W.osc_chain_params(SEED + 1, np.arange(ns))
     pd = torch.from_numpy(P).cuda()
     x = torch.zeros((T, ns, 1), dtype=torch.float32, device="cuda")
@@ -764,6 +765,22 @@ def test_host_frames_pipelined_path(torch_cuda, F, pinned):
     y64 = bank.process_host(x if pinned else x.numpy(), out_f64=True)
     y64 = y64 if pinned else torch.from_numpy(y64)
     assert torch.equal(y64, want.cpu().double())
+
+
+def test_host_frames_pipelined_path_odd_stream_count(torch_cuda, F):
+    """n_streams % 4 != 0 with rows above 512 KiB gives an odd chunk length (61 steps): the second
+    pipeline slot must still start 16-byte aligned."""
+    torch = torch_cuda
+    ns, T = 137002, 200
+    prog = F.compile(F.from_sexpr(G.df1_cascade(2)))
+    xd = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(xd, SEED + 53)
+    want, _ = prog.run_block(xd)
+    bank = prog.bank(ns)
+    y = bank.process_host(xd.cpu().numpy())
+    assert np.array_equal(y.view(np.uint32), want.cpu().numpy().view(np.uint32))
+    y64 = prog.bank(ns).process_host(xd.cpu().numpy(), out_f64=True)
+    assert np.array_equal(y64, want.cpu().numpy().astype(np.float64))
 
 
 def test_copy_probe_copies(torch_cuda, F):

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
-import graphs as G  # noqa: E402
+from zignal_amd import workloads as G  # noqa: E402
 from zignal_amd import flowz as F  # noqa: E402
 
 prog = F.compile(F.from_sexpr(G.df1_cascade(6)))

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
-import graphs as G  # noqa: E402
+from zignal_amd import workloads as G  # noqa: E402
 from zignal_amd import flowz as F  # noqa: E402
 
 ns, T = int(sys.argv[1]) if len(sys.argv) > 1 else 65536, int(sys.argv[2]) if len(sys.argv) > 2 else 4096

@@ -26,8 +26,8 @@ def main():
     import numpy as np
     import torch
 
-    import graphs as G
-    import workloads as W
+    from zignal_amd import workloads as G
+    W = G
     from zignal_amd import flowz as F
 
     graphs = {"cascade6": lambda: G.df1_cascade(6), "par4": G.par4_sum, "par4f": G.par4_sum_fanout,

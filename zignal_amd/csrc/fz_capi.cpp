@@ -131,6 +131,14 @@ int fz_program_build(fz_program* p, const fz_variant* v)
       return FZ_OK;)
 }
 
+int fz_program_build_for(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples)
+{
+   FZ_GUARD(
+      if (!p || !n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_build_for: bad arguments");
+      (void)get_kernel(p, resolve_variant(p->g, v, n_streams, n_samples), nullptr);
+      return FZ_OK;)
+}
+
 long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, char* buf, size_t cap)
 {
    try {
@@ -220,6 +228,15 @@ int fz_program_tune(fz_program* p, const float* in, float* out, float* state, co
    FZ_GUARD(
       if (!p) fail(FZ_E_INVALID, "null program");
       return tune(p, in, out, state, params, n_streams, n_samples, tile_streams, hip_stream, chosen, chosen_ms);)
+}
+
+int fz_program_tune_candidates(fz_program* p, uint64_t n_streams, uint32_t n_samples, fz_variant* out, uint32_t cap)
+{
+   FZ_GUARD(
+      if (!p || !n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_tune_candidates: bad arguments");
+      const std::vector<fz_variant> c = tune_candidates(p->g, n_streams, n_samples);
+      for (size_t i = 0; i < c.size() && i < cap && out; ++i) out[i] = c[i];
+      return (int)c.size();)
 }
 
 }  // extern "C"

@@ -146,6 +146,7 @@ struct Kernel {
       void* function;   // hipFunction_t
    };
    std::vector<char> code;        // code object (device independent: gfx950)
+   std::string cache_path;        // on-disk cache file it came from / went to ("" = none)
    std::vector<Loaded> loaded;    // one module per device the kernel ran on
    void* function_on_current_device(const std::string& symbol);   // loads on first use (caller holds the program mutex)
    ~Kernel();                     // unloads the modules (fz_runtime.hip)
@@ -173,5 +174,6 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
            uint32_t rows_total = 0, uint32_t row0 = 0);
 int tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
          uint32_t n_samples, uint32_t tile_streams, void* stream, fz_variant* chosen, float* chosen_ms);
+std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint32_t n_samples);
 int device_count();
 }  // namespace fz

@@ -90,6 +90,9 @@ static uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
    return h;
 }
 
+// Where code objects are cached: FLOWZ_HIP_CACHE, else <package>/_kcache next to the library when that is
+// writable (build() pre-fills it), else a PER-USER directory under /tmp (mode 0700, owner checked: another
+// local user must not be able to plant a code object there).
 static std::string cache_dir()
 {
    if (const char* env = std::getenv("FLOWZ_HIP_CACHE")) return env;
@@ -100,9 +103,75 @@ static std::string cache_dir()
       if (s != std::string::npos) p = p.substr(0, s);
       s = p.rfind('/');
       if (s != std::string::npos) p = p.substr(0, s);
-      return p + "/_kcache";
+      const std::string d = p + "/_kcache";
+      ::mkdir(d.c_str(), 0755);
+      if (::access(d.c_str(), W_OK | X_OK) == 0) return d;
    }
-   return "/tmp/flowz_hip_kcache";
+   const std::string d = "/tmp/flowz_hip_kcache-" + std::to_string((long)getuid());
+   ::mkdir(d.c_str(), 0700);
+   struct stat st;
+   if (::lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0) return "";   // no cache
+   return d;
+}
+
+// cache file = header {magic, payload bytes, fnv1a of the payload} + code object
+struct CacheHeader {
+   char magic[8];
+   uint64_t size;
+   uint64_t hash;
+};
+static const char kCacheMagic[8] = {'F', 'Z', 'K', 'C', '0', '0', '0', '2'};
+
+static uint64_t fnv1a_bytes(const char* d, size_t n)
+{
+   uint64_t h = 1469598103934665603ull;
+   for (size_t i = 0; i < n; ++i) {
+      h ^= (unsigned char)d[i];
+      h *= 1099511628211ull;
+   }
+   return h;
+}
+
+static bool cache_load(const std::string& path, std::vector<char>& code)
+{
+   std::ifstream f(path, std::ios::binary);
+   if (!f) return false;
+   std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+   CacheHeader h;
+   bool ok = raw.size() > sizeof h;
+   if (ok) {
+      std::memcpy(&h, raw.data(), sizeof h);
+      ok = std::memcmp(h.magic, kCacheMagic, 8) == 0 && h.size == raw.size() - sizeof h && h.size > 64 &&
+           h.hash == fnv1a_bytes(raw.data() + sizeof h, (size_t)h.size) && std::memcmp(raw.data() + sizeof h, "\x7f" "ELF", 4) == 0;
+   }
+   if (!ok) {
+      ::unlink(path.c_str());                        // truncated / foreign / stale: never try it again
+      return false;
+   }
+   code.assign(raw.begin() + sizeof h, raw.end());
+   return true;
+}
+
+static void cache_store(const std::string& dir, const std::string& path, const std::vector<char>& code)
+{
+   if (dir.empty()) return;
+   ::mkdir(dir.c_str(), 0755);
+   const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+   CacheHeader h;
+   std::memcpy(h.magic, kCacheMagic, 8);
+   h.size = code.size();
+   h.hash = fnv1a_bytes(code.data(), code.size());
+   bool ok = false;
+   {
+      std::ofstream f(tmp, std::ios::binary);
+      if (f) {
+         f.write(reinterpret_cast<const char*>(&h), sizeof h);
+         f.write(code.data(), (std::streamsize)code.size());
+         f.close();
+         ok = f.good();                              // a short write (ENOSPC ...) must not be installed
+      }
+   }
+   if (!ok || ::rename(tmp.c_str(), path.c_str()) != 0) ::unlink(tmp.c_str());
 }
 
 static std::vector<char> jit_compile(const Graph& g, const Variant& v)
@@ -145,32 +214,26 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
       char name[64];
       std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)fnv1a(key_src));
       const std::string dir = cache_dir(), path = dir + name;
-      bool hit = false;
-      if (!std::getenv("FLOWZ_HIP_NO_CACHE")) {
-         std::ifstream f(path, std::ios::binary);
-         if (f) {
-            k->code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-            hit = k->code.size() > 64;
-         }
-      }
-      if (!hit) {
+      const bool use_cache = !std::getenv("FLOWZ_HIP_NO_CACHE") && !dir.empty();
+      k->cache_path = use_cache ? path : std::string();
+      if (!(use_cache && cache_load(path, k->code))) {
          k->code = jit_compile(p->g, v);
-         if (!std::getenv("FLOWZ_HIP_NO_CACHE")) {
-            ::mkdir(dir.c_str(), 0755);
-            const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-            std::ofstream f(tmp, std::ios::binary);
-            if (f) {
-               f.write(k->code.data(), (std::streamsize)k->code.size());
-               f.close();
-               ::rename(tmp.c_str(), path.c_str());
-            }
-         }
+         if (use_cache) cache_store(dir, path, k->code);
       }
       slot = k;
    }
    if (fn_out) {
       require_device();
-      *fn_out = slot->function_on_current_device(kernel_name(p->g, v));
+      try {
+         *fn_out = slot->function_on_current_device(kernel_name(p->g, v));
+      } catch (const Error&) {
+         // a cached code object the driver refuses: delete it, build afresh, try once more
+         if (slot->cache_path.empty()) throw;
+         ::unlink(slot->cache_path.c_str());
+         slot->cache_path.clear();
+         slot->code = jit_compile(p->g, v);
+         *fn_out = slot->function_on_current_device(kernel_name(p->g, v));
+      }
    }
    return slot;
 }
@@ -324,34 +387,56 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       // FLOWZ_HIP_AUTOTUNE=1: the first big block of a shape measures the plan by itself (on the caller's
       // buffers; the state is saved and restored around the measurement, `out` is recomputed below)
       static const bool autotune = [] { const char* e = std::getenv("FLOWZ_HIP_AUTOTUNE"); return e && *e && *e != '0'; }();
-      if (autotune && !known && rows_total == n_samples && row0 == 0 && n_streams * (uint64_t)n_samples >= (1ull << 26)) {
+      bool can_tune = autotune && !known && rows_total == n_samples && row0 == 0 && n_streams * (uint64_t)n_samples >= (1ull << 26);
+      if (can_tune) {
+         // not while the stream is being captured into a hipGraph (the measurement allocates and synchronises), and not
+         // in place: the candidates run on the caller's buffers, an aliased `in` would be overwritten before the real launch
+         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) (void)hipGetLastError();
+         const char* ib = reinterpret_cast<const char*>(in);
+         const char* ob = reinterpret_cast<const char*>(out);
+         const size_t ibytes = (size_t)n_streams * n_samples * g.n_in * 4, obytes = (size_t)n_streams * n_samples * out_w * 4;
+         const bool overlap = in && ib < ob + obytes && ob < ib + ibytes;
+         can_tune = cap == hipStreamCaptureStatusNone && !overlap;
+      }
+      if (can_tune) {
          {
             std::lock_guard<std::mutex> lock(p->mu);
             p->tuned_default.insert(key);                   // (also stops the recursion through tune -> launch)
          }
          const size_t sb = (size_t)g.n_state * n_streams * 4;
-         float* saved = nullptr;
+         // the state is saved before and restored after the measurement ON EVERY EXIT PATH
+         struct Saved {
+            float* copy = nullptr;
+            float* state;
+            size_t bytes;
+            hipStream_t st;
+            ~Saved()
+            {
+               if (!copy) return;
+               (void)hipMemcpyAsync(state, copy, bytes, hipMemcpyDeviceToDevice, st);
+               (void)hipStreamSynchronize(st);
+               (void)hipFree(copy);
+            }
+         } saved{nullptr, state, sb, (hipStream_t)stream};
+         bool have_copy = true;
          if (sb) {
-            FZ_HIP(hipMalloc((void**)&saved, sb));
-            FZ_HIP(hipMemcpyAsync(saved, state, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            if (hipMalloc((void**)&saved.copy, sb) != hipSuccess) {      // no room for the snapshot (multi-GiB state): do not tune
+               (void)hipGetLastError();
+               saved.copy = nullptr;
+               have_copy = false;
+            } else {
+               FZ_HIP(hipMemcpyAsync(saved.copy, state, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            }
          }
-         fz_variant chosen{0, 0, 0, 0};
-         int rc = FZ_OK;
-         try {
-            rc = tune(p, in, out, state, params, n_streams, n_samples, tile_streams, stream, &chosen, nullptr);
-         } catch (...) {
-            if (saved) (void)hipFree(saved);
-            throw;
-         }
-         if (sb) {
-            FZ_HIP(hipMemcpyAsync(state, saved, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-            FZ_HIP(hipStreamSynchronize((hipStream_t)stream));
-            (void)hipFree(saved);
-         }
-         if (rc != FZ_OK) return rc;
-         if (chosen.streams_per_lane || chosen.unroll || chosen.block_threads || chosen.flags) {
-            planned = chosen;
-            uv = &planned;
+         if (have_copy) {
+            fz_variant chosen{0, 0, 0, 0};
+            const int rc = tune(p, in, out, state, params, n_streams, n_samples, tile_streams, stream, &chosen, nullptr);
+            if (rc != FZ_OK) return rc;
+            if (chosen.streams_per_lane || chosen.unroll || chosen.block_threads || chosen.flags) {
+               planned = chosen;
+               uv = &planned;
+            }
          }
       }
    }
@@ -375,21 +460,26 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    auto k = get_kernel(p, v, &fn);
 
    // kernarg image of `struct fz_args` (8-byte aligned: pad the coefficient tail)
+   // (built on the stack for ordinary graphs: no allocation on the launch path)
    const size_t off64 = (sizeof(ArgsHeader) + sizeof(float) * std::max<size_t>(g.consts.size(), 1) + 7) & ~size_t(7);
-   std::vector<char> buf(off64 + sizeof(double) * std::max<size_t>(g.consts64.size(), 1));
+   const size_t kbytes = off64 + sizeof(double) * std::max<size_t>(g.consts64.size(), 1);
+   alignas(8) char small[1024];
+   std::vector<char> big;
+   char* const kbuf = kbytes <= sizeof small ? small : (big.resize(kbytes), big.data());
    ArgsHeader h{in, out, state, params, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
                 (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0};
-   std::memcpy(buf.data(), &h, sizeof h);
+   std::memcpy(kbuf, &h, sizeof h);
    {
       std::lock_guard<std::mutex> lock(p->mu);
-      if (!g.consts.empty()) std::memcpy(buf.data() + sizeof h, g.consts.data(), sizeof(float) * g.consts.size());
-      if (!g.consts64.empty()) std::memcpy(buf.data() + off64, g.consts64.data(), sizeof(double) * g.consts64.size());
+      if (!g.consts.empty()) std::memcpy(kbuf + sizeof h, g.consts.data(), sizeof(float) * g.consts.size());
+      if (!g.consts64.empty()) std::memcpy(kbuf + off64, g.consts64.data(), sizeof(double) * g.consts64.size());
    }
-   size_t size = buf.size();
-   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+   size_t size = kbytes;
+   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, kbuf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
    const unsigned grid = (unsigned)((h.n_groups + v.block - 1) / v.block);
    FZ_HIP(hipModuleLaunchKernel((hipFunction_t)fn, grid, 1, 1, v.block, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
-   if (std::getenv("FLOWZ_HIP_DEBUG")) {
+   static const bool debug = std::getenv("FLOWZ_HIP_DEBUG") != nullptr;
+   if (debug) {
       FZ_HIP(hipStreamSynchronize((hipStream_t)stream));
       std::fprintf(stderr, "[flowz_hip] launched grid=%u block=%u P=%u U=%u flags=%u n_streams=%llu n_samples=%u kernarg=%zu B\n",
                    grid, v.block, v.P, v.U, v.flags, (unsigned long long)n_streams, n_samples, size);
@@ -397,17 +487,9 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    return FZ_OK;
 }
 
-// ---- plan selection ------------------------------------------------------------------------------------------
-// The variants differ by a few percent, and which one wins depends on the board (measured: the same
-// variant is +5 % on one MI355X of the pool and -3 % on the next), so -- like FFTW_MEASURE -- time the
-// candidates on the caller's own buffers once and remember the winner for this shape.
-int tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
-         uint32_t n_samples, uint32_t tile_streams, void* stream, fz_variant* chosen, float* chosen_ms)
+// the variants fz_program_tune measures for a shape (the first one is the library default)
+std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint32_t n_samples)
 {
-   const Graph& g = p->g;
-   if (!n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_tune: empty block");
-   require_device();
-   if (tile_streams == 0 || tile_streams >= n_streams) tile_streams = 0;
    const Variant d = resolve_variant(g, nullptr, n_streams, n_samples);
    std::vector<fz_variant> cands{fz_variant{0, 0, 0, 0}};
    if (d.flags & FZ_VF_STAGE_PACK) {
@@ -432,6 +514,21 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
       cands.push_back(fz_variant{1, 16, 256, FZ_VF_MAX_WG(2)});
       if (n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) cands.push_back(fz_variant{2, 16, 0, 0});
    }
+   return cands;
+}
+
+// ---- plan selection ------------------------------------------------------------------------------------------
+// The variants differ by a few percent, and which one wins depends on the board (measured: the same
+// variant is +5 % on one MI355X of the pool and -3 % on the next), so -- like FFTW_MEASURE -- time the
+// candidates on the caller's own buffers once and remember the winner for this shape.
+int tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+         uint32_t n_samples, uint32_t tile_streams, void* stream, fz_variant* chosen, float* chosen_ms)
+{
+   const Graph& g = p->g;
+   if (!n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_tune: empty block");
+   require_device();
+   if (tile_streams == 0 || tile_streams >= n_streams) tile_streams = 0;
+   std::vector<fz_variant> cands = tune_candidates(g, n_streams, n_samples);
    hipEvent_t e0, e1;
    FZ_HIP(hipEventCreate(&e0));
    FZ_HIP(hipEventCreate(&e1));
@@ -941,6 +1038,12 @@ static void ensure_stage(fz_bank* b, size_t ib, size_t ob)
    }
 }
 
+static void drain_pipeline(fz_bank* b)
+{
+   for (hipStream_t st : {b->s_h2d, b->s_run, b->s_d2h})
+      if (st) (void)hipStreamSynchronize(st);
+}
+
 // Host frames in, host frames out.  Short blocks (the per-sample call protocol) take one synchronous
 // H2D / kernel / D2H round trip.  Long blocks are cut along TIME into chunks that flow through a
 // three-stage pipeline on three HIP streams -- H2D of chunk k+1, the kernel of chunk k and D2H of chunk
@@ -971,7 +1074,9 @@ static int bank_process_host(fz_bank* b, const float* in_host, void* out_host, u
          return FZ_OK;
       }
       if (chunk_t >= 64) chunk_t &= ~31u;                   // whole prefetch chunks
-      ensure_stage(b, 2 * irow * chunk_t, 2 * orow * chunk_t);
+      // the second pipeline slot must start 16-byte aligned whatever n_streams and chunk_t are
+      const size_t islot = (irow * chunk_t + 255) & ~size_t(255), oslot = (orow * chunk_t + 255) & ~size_t(255);
+      ensure_stage(b, 2 * islot, 2 * oslot);
       if (!b->s_h2d) {
          FZ_HIP(hipStreamCreateWithFlags(&b->s_h2d, hipStreamNonBlocking));
          FZ_HIP(hipStreamCreateWithFlags(&b->s_run, hipStreamNonBlocking));
@@ -989,8 +1094,8 @@ static int bank_process_host(fz_bank* b, const float* in_host, void* out_host, u
       for (uint32_t t0 = 0; t0 < n_samples; t0 += chunk_t, ++k) {
          const uint32_t nt = std::min(chunk_t, n_samples - t0);
          const int slot = (int)(k & 1u);
-         float* din = reinterpret_cast<float*>(reinterpret_cast<char*>(b->stage_in) + (size_t)slot * irow * chunk_t);
-         float* dout = reinterpret_cast<float*>(reinterpret_cast<char*>(b->stage_out) + (size_t)slot * orow * chunk_t);
+         float* din = reinterpret_cast<float*>(reinterpret_cast<char*>(b->stage_in) + (size_t)slot * islot);
+         float* dout = reinterpret_cast<float*>(reinterpret_cast<char*>(b->stage_out) + (size_t)slot * oslot);
          if (irow) {
             if (k >= 2) FZ_HIP(hipStreamWaitEvent(b->s_h2d, b->ev_run[slot], 0));        // kernel k-2 has consumed this slot
             FZ_HIP(hipMemcpyAsync(din, hin + (size_t)t0 * irow, irow * nt, hipMemcpyHostToDevice, b->s_h2d));
@@ -998,9 +1103,18 @@ static int bank_process_host(fz_bank* b, const float* in_host, void* out_host, u
             FZ_HIP(hipStreamWaitEvent(b->s_run, b->ev_in[slot], 0));
          }
          if (k >= 2) FZ_HIP(hipStreamWaitEvent(b->s_run, b->ev_out[slot], 0));            // D2H k-2 has drained this slot
-         int rc = fz::launch(b->prog, g.n_in ? din : nullptr, dout, g.n_state ? b->state : nullptr, b->params, b->n_streams, nt, uv,
-                             b->s_run, 0);
-         if (rc != FZ_OK) return rc;
+         int rc = FZ_OK;
+         try {
+            rc = fz::launch(b->prog, g.n_in ? din : nullptr, dout, g.n_state ? b->state : nullptr, b->params, b->n_streams, nt, uv,
+                            b->s_run, 0);
+         } catch (...) {                                    // chunks already in flight still write into the caller's memory
+            drain_pipeline(b);
+            throw;
+         }
+         if (rc != FZ_OK) {
+            drain_pipeline(b);
+            return rc;
+         }
          FZ_HIP(hipEventRecord(b->ev_run[slot], b->s_run));
          FZ_HIP(hipStreamWaitEvent(b->s_d2h, b->ev_run[slot], 0));
          FZ_HIP(hipMemcpyAsync(hout + (size_t)t0 * orow, dout, orow * nt, hipMemcpyDeviceToHost, b->s_d2h));
@@ -1062,9 +1176,18 @@ int fz_bank_process_host_stream_major(fz_bank* b, const float* in_host, float* o
             FZ_HIP(hipStreamWaitEvent(b->s_run, b->ev_in[slot], 0));
          }
          if (k >= 2) FZ_HIP(hipStreamWaitEvent(b->s_run, b->ev_out[slot], 0));
-         int rc = fz::launch(b->prog, g.n_in ? din : nullptr, dout, g.n_state ? b->state : nullptr, b->params, b->n_streams, nt, &sm,
-                             b->s_run, 0, chunk_t, 0);
-         if (rc != FZ_OK) return rc;
+         int rc = FZ_OK;
+         try {
+            rc = fz::launch(b->prog, g.n_in ? din : nullptr, dout, g.n_state ? b->state : nullptr, b->params, b->n_streams, nt, &sm,
+                            b->s_run, 0, chunk_t, 0);
+         } catch (...) {
+            drain_pipeline(b);
+            throw;
+         }
+         if (rc != FZ_OK) {
+            drain_pipeline(b);
+            return rc;
+         }
          FZ_HIP(hipEventRecord(b->ev_run[slot], b->s_run));
          FZ_HIP(hipStreamWaitEvent(b->s_d2h, b->ev_run[slot], 0));
          FZ_HIP(hipMemcpy2DAsync(hout + (size_t)t0 * g.n_out * 4, hop, dout, opitch, (size_t)nt * g.n_out * 4, b->n_streams,

@@ -17,15 +17,29 @@ def shard_range(n_streams_total: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + q + (1 if rank < r else 0)
 
 
-def reduce_stats(seconds: float, samples: float, checksum: float, device=None) -> Dict[str, float]:
-    """max(seconds), sum(samples), sum(checksum) over all ranks (identity when not distributed)."""
+def reduce_stats(seconds: float, samples: float, checksum: int, device=None) -> Dict[str, float]:
+    """max(seconds), sum(samples), sum(checksum) over all ranks (identity when not distributed).
+
+    `checksum` is an INTEGER (bench.py: the sum of the uint32 bit patterns of the last output row of every
+    stream of the rank), reduced in int64: exact and independent of how the streams are sharded, so an
+    N-rank run can be compared with a single-process run over the union of the global stream ids."""
     import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()):
-        return {"seconds": float(seconds), "samples": float(samples), "checksum": float(checksum), "world": 1}
+        return {"seconds": float(seconds), "samples": float(samples), "checksum": int(checksum), "world": 1}
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    s = torch.tensor([samples, checksum], dtype=torch.float64, device=device)
+    s = torch.tensor([samples], dtype=torch.float64, device=device)
+    c = torch.tensor([int(checksum)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
-    return {"seconds": float(t[0]), "samples": float(s[0]), "checksum": float(s[1]), "world": dist.get_world_size()}
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return {"seconds": float(t[0]), "samples": float(s[0]), "checksum": int(c[0]), "world": dist.get_world_size()}
+
+
+def bits_checksum(last_row) -> int:
+    """Sum of the uint32 bit patterns of a float32 CUDA/CPU tensor (exact in int64 for < 2^31 values)."""
+    import torch
+
+    v = last_row.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    return int(v.sum().item())

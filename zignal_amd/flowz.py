@@ -190,6 +190,18 @@ def make_variant(streams_per_lane=0, unroll=0, block_threads=0, flags=0) -> Vari
     return Variant(int(streams_per_lane), int(unroll), int(block_threads), int(flags))
 
 
+def _check_dev(t, shape, what, dtype=None):
+    """A caller-supplied device buffer handed to the C ABI as a raw pointer: float32 (or `dtype`), CUDA, contiguous and of
+    exactly the shape the kernel will address -- anything else would be a silent out-of-bounds device access."""
+    import torch
+
+    dtype = dtype or torch.float32
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous() and tuple(t.shape) == tuple(shape)):
+        raise FlowzError(C.FZ_E_INVALID, f"{what}: expected a contiguous CUDA {dtype} tensor of shape {tuple(shape)}, got "
+                                         f"{t.dtype} {tuple(t.shape)} on {t.device}" + ("" if t.is_contiguous() else " (not contiguous)"))
+    return t
+
+
 class Program:
     """compile() result: lowered graph + its fused gfx950 kernels (flowz.hpp:1233-1249)."""
 
@@ -277,9 +289,21 @@ class Program:
         C.check(C.lib.fz_program_source(self._h, vp, buf, n + 1))
         return buf.value.decode()
 
-    def build(self, variant: Optional[Variant] = None):
-        """JIT-compile (or fetch from the on-disk cache) the kernel of `variant`; needs no GPU."""
-        C.check(C.lib.fz_program_build(self._h, ctypes.byref(variant) if variant is not None else None))
+    def tune_candidates(self, n_streams: int, n_samples: int):
+        """The variants Program.tune would measure for this shape (the first one is the library default)."""
+        n = C.check(C.lib.fz_program_tune_candidates(self._h, int(n_streams), int(n_samples), None, 0))
+        buf = (Variant * max(n, 1))()
+        C.check(C.lib.fz_program_tune_candidates(self._h, int(n_streams), int(n_samples), buf, n))
+        return [Variant(buf[i].streams_per_lane, buf[i].unroll, buf[i].block_threads, buf[i].flags) for i in range(n)]
+
+    def build(self, variant: Optional[Variant] = None, n_streams: int = 0, n_samples: int = 0):
+        """JIT-compile (or fetch from the on-disk cache) the kernel of `variant`; needs no GPU.  With a block shape the
+        variant's automatic fields resolve as run_block would for it (else as for a large stream count)."""
+        vp = ctypes.byref(variant) if variant is not None else None
+        if n_streams:
+            C.check(C.lib.fz_program_build_for(self._h, vp, int(n_streams), int(n_samples or 4096)))
+        else:
+            C.check(C.lib.fz_program_build(self._h, vp))
         return self
 
     # -- the hot path ----------------------------------------------------------------------
@@ -298,14 +322,19 @@ class Program:
         more samples than the block): fz_run_block_window.  state advances; params as for run_block."""
         import torch
 
-        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == max(self.n_in, 1)
         if x.dim() == 4:
             n_tiles, rows, tile, _ = x.shape
             ns = n_tiles * tile
+            oshape = (n_tiles, rows, tile, self.n_out)
         else:
             rows, ns, _ = x.shape
             tile = 0
-        pp = params.data_ptr() if self.n_param else None
+            oshape = (rows, ns, self.n_out)
+        _check_dev(out, oshape, "out")
+        if self.n_state:
+            _check_dev(state, (self.n_state, ns), "state")
+        pp = _check_dev(params, (self.n_param, ns), "params").data_ptr() if self.n_param else None
         vp = ctypes.byref(variant) if variant is not None else None
         C.check(C.lib.fz_run_block_window(self._h, x.data_ptr() if self.n_in else None, out.data_ptr(),
                                           state.data_ptr() if self.n_state else None, pp, ns, rows, int(row0), int(n_samples),
@@ -328,7 +357,9 @@ class Program:
             out = torch.empty((ns, rows, self.n_out), dtype=torch.float32, device=x.device)
         if state is None:
             state = torch.zeros((max(self.n_state, 1), ns), dtype=torch.float32, device=x.device)
-        pp = params.data_ptr() if self.n_param else None
+        _check_dev(out, (ns, rows, self.n_out), "out")
+        _check_dev(state, (max(self.n_state, 1), ns), "state")
+        pp = _check_dev(params, (self.n_param, ns), "params").data_ptr() if self.n_param else None
         vp = ctypes.byref(variant) if variant is not None else None
         C.check(C.lib.fz_run_block_stream_major(self._h, x.data_ptr() if self.n_in else None, out.data_ptr(),
                                                 state.data_ptr() if self.n_state else None, pp, ns, rows, int(row0), n, vp,
@@ -396,7 +427,9 @@ def _tune(self, x, state=None, params=None, out=None):
         out = torch.empty(oshape, dtype=torch.float32, device=x.device)
     if state is None:
         state = torch.zeros((max(self.n_state, 1), ns), dtype=torch.float32, device=x.device)
-    pp = params.data_ptr() if self.n_param else None
+    _check_dev(out, oshape, "out")
+    _check_dev(state, (max(self.n_state, 1), ns), "state")
+    pp = _check_dev(params, (self.n_param, ns), "params").data_ptr() if self.n_param else None
     chosen, ms = Variant(0, 0, 0, 0), ctypes.c_float(0)
     C.check(C.lib.fz_program_tune(self._h, x.data_ptr() if self.n_in else None, out.data_ptr(),
                                   state.data_ptr() if self.n_state else None, pp, ns, T, tile,
@@ -438,13 +471,16 @@ class Bank:
         (CUDA float32 [n_blocks, n_param, n_streams]); fz_bank_process_blocks."""
         import torch
 
-        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == max(self.prog.n_in, 1)
         rows, tile = (x.shape[1], x.shape[2]) if x.dim() == 4 else (x.shape[0], 0)
+        ns = x.shape[0] * x.shape[2] if x.dim() == 4 else x.shape[1]
+        if ns != self.n_streams:
+            raise FlowzError(C.FZ_E_INVALID, f"frames hold {ns} streams, the bank {self.n_streams}")
+        _check_dev(out, tuple(x.shape[:-1]) + (self.prog.n_out,), "out")
         pp = None
         if params_blocks is not None:
             nb = (rows + block_len - 1) // block_len
-            assert tuple(params_blocks.shape) == (nb, self.prog.n_param, self.n_streams) and params_blocks.is_contiguous()
-            pp = params_blocks.data_ptr()
+            pp = _check_dev(params_blocks, (nb, self.prog.n_param, self.n_streams), "params_blocks").data_ptr()
         vp = ctypes.byref(variant) if variant is not None else None
         C.check(C.lib.fz_bank_process_blocks(self._h, x.data_ptr() if self.prog.n_in else None, out.data_ptr(), rows,
                                              int(block_len), pp, tile, vp, torch.cuda.current_stream().cuda_stream))
@@ -468,7 +504,9 @@ class Bank:
             if out is None:
                 out = np.empty((self.n_streams, T, self.prog.n_out), np.float32)
             xp, op = x.ctypes.data, out.ctypes.data
-        assert x.shape[0] == self.n_streams
+        assert tuple(x.shape) in ((self.n_streams, T, max(self.prog.n_in, 1)), (self.n_streams, T)), x.shape
+        assert tuple(out.shape) == (self.n_streams, T, self.prog.n_out) and (out.is_contiguous() if is_torch else out.flags.c_contiguous)
+        assert (out.dtype == torch.float32) if is_torch else (out.dtype == np.float32)
         C.check(C.lib.fz_bank_process_host_stream_major(self._h, xp if self.prog.n_in else None, op, T))
         return out
 
@@ -493,6 +531,9 @@ class Bank:
                 out = np.empty((T, self.n_streams, self.prog.n_out), np.float64 if out_f64 else np.float32)
             xp, op = x.ctypes.data, out.ctypes.data
         assert tuple(x.shape[1:]) in ((self.n_streams, self.prog.n_in), (self.n_streams,)) or self.prog.n_in == 0
+        assert tuple(out.shape) == (T, self.n_streams, self.prog.n_out) and (out.is_contiguous() if is_torch else out.flags.c_contiguous)
+        want_dt = (torch.float64 if out_f64 else torch.float32) if is_torch else (np.float64 if out_f64 else np.float32)
+        assert out.dtype == want_dt, (out.dtype, want_dt)
         fn = C.lib.fz_bank_process_host_f64 if out_f64 else C.lib.fz_bank_process_host
         C.check(fn(self._h, xp if self.prog.n_in else None, op, T))
         return out
