@@ -151,6 +151,21 @@ def test_kernel_source_and_jit_build_for_gfx950_without_gpu(tmp_path, monkeypatc
     assert len(list(tmp_path.glob("*.hsaco"))) == 1
 
 
+def test_kernel_cache_rejects_damaged_files_and_ignores_literal_values(tmp_path, monkeypatch):
+    """a truncated / foreign cache file is detected (trailer: magic, size, hash), deleted and rebuilt; graphs that
+    differ only in coefficient VALUES share one code object (coefficients travel in the kernarg)."""
+    monkeypatch.setenv("FLOWZ_HIP_CACHE", str(tmp_path))
+    F.compile(F.from_sexpr(G.df1(0.5, 0.25, 0.125, 0.2, -0.8))).build(F.make_variant(1, 4))
+    (obj,) = tmp_path.glob("*.hsaco")
+    good = obj.read_bytes()
+    F.compile(F.from_sexpr(G.df1(0.75, 0.25, 0.125, 0.3, -0.7))).build(F.make_variant(1, 4))      # other literals: same file
+    assert [o.name for o in tmp_path.glob("*.hsaco")] == [obj.name]
+    for bad in (good[: len(good) // 2], b"\x7fELF" + b"x" * 4000, good[:-1] + bytes([good[-1] ^ 1])):
+        obj.write_bytes(bad)
+        F.compile(F.from_sexpr(G.df1(0.5, 0.25, 0.125, 0.2, -0.8))).build(F.make_variant(1, 4))
+        assert obj.read_bytes() == good
+
+
 def test_no_fma_contraction_in_generated_kernel(tmp_path, monkeypatch):
     """contraction changes the 4th impulse-response sample."""
     import subprocess

@@ -114,7 +114,7 @@ static std::string cache_dir()
    return d;
 }
 
-// cache file = header {magic, payload bytes, fnv1a of the payload} + code object
+// cache file = code object (an ELF: llvm-objdump / readelf still read the file) + trailer {magic, payload bytes, fnv1a of the payload}
 struct CacheHeader {
    char magic[8];
    uint64_t size;
@@ -140,15 +140,16 @@ static bool cache_load(const std::string& path, std::vector<char>& code)
    CacheHeader h;
    bool ok = raw.size() > sizeof h;
    if (ok) {
-      std::memcpy(&h, raw.data(), sizeof h);
+      std::memcpy(&h, raw.data() + raw.size() - sizeof h, sizeof h);
       ok = std::memcmp(h.magic, kCacheMagic, 8) == 0 && h.size == raw.size() - sizeof h && h.size > 64 &&
-           h.hash == fnv1a_bytes(raw.data() + sizeof h, (size_t)h.size) && std::memcmp(raw.data() + sizeof h, "\x7f" "ELF", 4) == 0;
+           h.hash == fnv1a_bytes(raw.data(), (size_t)h.size) && std::memcmp(raw.data(), "\x7f" "ELF", 4) == 0;
    }
    if (!ok) {
       ::unlink(path.c_str());                        // truncated / foreign / stale: never try it again
       return false;
    }
-   code.assign(raw.begin() + sizeof h, raw.end());
+   raw.resize((size_t)h.size);
+   code.swap(raw);
    return true;
 }
 
@@ -165,8 +166,8 @@ static void cache_store(const std::string& dir, const std::string& path, const s
    {
       std::ofstream f(tmp, std::ios::binary);
       if (f) {
-         f.write(reinterpret_cast<const char*>(&h), sizeof h);
          f.write(code.data(), (std::streamsize)code.size());
+         f.write(reinterpret_cast<const char*>(&h), sizeof h);
          f.close();
          ok = f.good();                              // a short write (ENOSPC ...) must not be installed
       }
