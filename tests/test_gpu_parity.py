@@ -954,6 +954,57 @@ def test_stream_major_kernel_vs_oracle(torch_cuda, F, name):
             assert torch.equal(out, y), (ns, T)
 
 
+@pytest.mark.parametrize("T", [4, 8, 12, 36, 68, 160, 200, 264])
+@pytest.mark.parametrize("name", ["cascade6", "cascade12_two_stages_per_segment", "cascade7_prefix_plus_6", "cascade4_smoothing_one_pole",
+                                  "integrator_cascade4_gain", "df2_pair"])
+def test_stream_major_stage_packed_kernel_vs_oracle(torch_cuda, F, name, T):
+    """The stage-packed body of the stream-major kernel (segments skewed in time, outputs FZ_SKEW samples behind the
+    inputs, output chunks completed in the next compute phase): every chunk depth, chunk-less blocks, ragged tails,
+    ragged stream counts, windows and mixed-variant chains -- vs the oracle, 0 ULP, canonical state."""
+    torch = torch_cuda
+    g = PACKABLE[name]()
+    prog = F.compile(F.from_sexpr(g))
+    for ns in (1, 64, 333):
+        x = O.synth_input(SEED + 96, np.arange(ns), T)
+        want = O.compile(g, ns).run(x)                                   # [T, ns, 1]
+        xs = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))).cuda()
+        _, st_ref = prog.run_block(torch.from_numpy(x).cuda(), variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+        for U in (8, 16, 32):
+            v = F.make_variant(1, U, 0, STAGE_PACK)
+            assert prog.kernel_name(F.make_variant(1, U, 0, STAGE_PACK | 128), ns, T).endswith("f136")          # ...s<K>f136: packed + stream-major
+            y, st = prog.run_block_stream_major(xs, variant=v)
+            assert ndiff(y.permute(1, 0, 2).contiguous().cpu().numpy(), want) == 0, (ns, T, U)
+            assert torch.equal(st, st_ref), (ns, T, U)
+        if T >= 36:                                                        # two windows, state carried, mixed bodies
+            out = torch.zeros_like(y)
+            _, st2 = prog.run_block_stream_major(xs, out=out, n_samples=20, variant=F.make_variant(1, 8, 0, STAGE_PACK))
+            prog.run_block_stream_major(xs, out=out, state=st2, row0=20, variant=F.make_variant(1, 16, 0, NO_STAGE_PACK))
+            assert torch.equal(out, y), (ns, T)
+            out.zero_()
+            _, st2 = prog.run_block_stream_major(xs, out=out, n_samples=12, variant=F.make_variant(1, 8, 0, NO_STAGE_PACK))
+            prog.run_block_stream_major(xs, out=out, state=st2, row0=12, variant=F.make_variant(1, 16, 0, STAGE_PACK))
+            assert torch.equal(out, y), (ns, T)
+
+
+def test_stream_major_stage_packing_is_automatic_for_long_blocks(torch_cuda, F):
+    """From 32 x (K-1) samples on the stream-major kernel picks the stage-packed body by itself (any stream count);
+    osc -> 6 DF1 with per-stream coefficients (scalar prefix) at a size where every wave of a block is busy."""
+    torch = torch_cuda
+    prog = F.compile(F.from_sexpr(G.osc_chain(6)))
+    ns, T = 4096 + 78, 512
+    assert "s6f" in prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, T)
+    assert "s6f" not in prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, 100)
+    P = W.osc_chain_params(SEED + 3, np.arange(ns))
+    x = np.zeros((T, ns, 1), np.float32)
+    x[0] = 1.0
+    x[100] = -0.5
+    xs = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))).cuda()
+    y, st = prog.run_block_stream_major(xs, params=torch.from_numpy(P).cuda())
+    assert ndiff(y.permute(1, 0, 2).contiguous().cpu().numpy(), C.osc_chain(P, x)) == 0
+    _, st_ref = prog.run_block(torch.from_numpy(x).cuda(), params=torch.from_numpy(P).cuda(), variant=F.make_variant(2, 8))
+    assert torch.equal(st[:, :ns - 1], st_ref[:, :ns - 1]) and torch.equal(st, st_ref)
+
+
 def test_stream_major_kernel_rejects_what_it_cannot_do(torch_cuda, F):
     torch = torch_cuda
     prog = F.compile(F.from_sexpr(G.df1_cascade(2)))

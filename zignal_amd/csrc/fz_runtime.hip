@@ -301,7 +301,10 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // one stream per lane: two (packed FP32) are possible but measured slower everywhere -- twice the
       // patch traffic per wave and 360 VGPRs (profiles/r01/stream_major_kernel.txt)
       v.P = reqP ? reqP : 1u;
-      v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
+      // stage packing (one stream per lane) carries over: the skew only shifts which output chunk a step completes.
+      // It is what lifts deep serial graphs off the VALU floor here, whatever the stream count.
+      if (v.P != 1 || !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
+      else if (!(uv && (uv->flags & FZ_VF_NO_STAGE_PACK)) && n_samples >= 32u * (g.split.K - 1)) v.flags |= FZ_VF_STAGE_PACK;
       const uint32_t nw = std::max<uint32_t>(std::max(g.n_in, g.n_out), 1);
       auto lds = [&](const Variant& w) { return (uint64_t)w.block * w.P * (w.U * nw + 4) * 4 + (uint64_t)g.n_lds_slots * w.block * 4 * w.P; };
       if (!reqU) {
@@ -309,6 +312,10 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
          // stream and wire 2x faster than 64 B): the deepest chunk whose patches fit the CU's LDS
          v.U = 32;
          while (v.U > 4 && lds(v) > kMaxLdsBytes) v.U /= 2;
+      }
+      if ((v.flags & FZ_VF_STAGE_PACK) && v.U <= g.split.K - 1) {
+         if (uv && (uv->flags & FZ_VF_STAGE_PACK)) fail(FZ_E_INVALID, "stage-packed stream-major frames need unroll > number of segments - 1");
+         v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
       }
       while (lds(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
       if (lds(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "stream-major frames: the LDS patches do not fit (too many wires per frame)");
@@ -556,9 +563,11 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
             ms /= (float)reps;
             if (pass == 0) reps = std::max(3, std::min(100, (int)(25.f / std::max(ms, 1e-3f))));
          }
-         if (std::getenv("FLOWZ_HIP_DEBUG"))
-            std::fprintf(stderr, "[flowz_hip] tune P=%u U=%u block=%u flags=%u: %.4f ms\n", cands[c].streams_per_lane,
-                         cands[c].unroll, cands[c].block_threads, cands[c].flags, ms);
+         if (std::getenv("FLOWZ_HIP_DEBUG") || std::getenv("FLOWZ_HIP_TUNE_LOG"))
+            std::fprintf(stderr, "[flowz_hip] tune %s n_streams=%llu tile=%u: P=%u U=%u block=%u flags=%u: %.4f ms%s\n",
+                         kernel_name(g, resolve_variant(g, &cands[c], n_streams, n_samples)).c_str(), (unsigned long long)n_streams,
+                         tile_streams, cands[c].streams_per_lane, cands[c].unroll, cands[c].block_threads, cands[c].flags, ms,
+                         warmup ? " (warm-up pass)" : "");
          if (!warmup && (best < 0 || ms < best_ms)) {
             best = (int)c;
             best_ms = ms;
