@@ -57,10 +57,14 @@ fz_expr* fz_literal_c32(float re, float im);         /* a std::complex<float> te
                                                         (re, im) of the output frame; operators follow
                                                         std::complex<float> (scalar mul/div and add touch the
                                                         parts as <complex> does, complex*complex is the
-                                                        (ac-bd, ad+bc) of __mulsc3 for finite values).  A
-                                                        complex wire cannot enter a delay line (they are
-                                                        float, :1245) nor meet a double operand (no such
-                                                        operator in C++): FZ_E_GRAPH                     */
+                                                        (ac-bd, ad+bc) of __mulsc3 for finite values; z/w and
+                                                        s/w are libgcc's __divsc3 as g++ links it: the four
+                                                        parts widened to double, x = (ac+bd)/(cc+dd),
+                                                        y = (bc-ad)/(cc+dd), rounded to float once).  Under
+                                                        fz_compile a complex wire cannot enter a delay line
+                                                        (they are float, :1245; fz_compile_typed stores it)
+                                                        nor meet a double operand (no such operator in C++):
+                                                        FZ_E_GRAPH                                        */
 fz_expr* fz_stream_param(uint32_t k);                /* per-stream, block-constant coefficient k:
                                                         the std::ref terminal of flowz/README.md:42-61,
                                                         one value per stream                          */
@@ -105,9 +109,34 @@ typedef struct fz_info {
    uint32_t stage_packable; /* 1 when the graph is a series of isomorphic segments (FZ_VF_STAGE_PACK) */
    uint32_t n_const64;   /* distinct float64 literal terminals                                */
    uint32_t n_out_wires; /* output wires (output_arity); < n_out when some wires are complex         */
+   uint32_t n_in_wires;  /* input wires (input_arity); < n_in when a typed program has double / complex inputs */
+   uint32_t typed;       /* 1 for fz_compile_typed programs                                           */
 } fz_info;
 
 int  fz_compile(const fz_expr* e, fz_program** out);
+
+/* compile() with the wire types of the reference's ResultType transform (flowz.hpp:585-644, asserted by
+ * test/tests.cpp:184-232) carried through INPUTS, STATE and OUTPUTS instead of the float state that compile()
+ * hard-codes today (flowz.hpp:1245, "TODO" there):
+ *   - input wire i arrives as in_dtypes[i] (fz_dtype; NULL or n_in_wires == 0: all float) -- the reference's callable
+ *     is a template over its argument types (flowz.hpp:1225-1229), so f(1.0) or f(std::complex<float>{..}) are legal;
+ *   - a delay line stores the type that is pushed into it and a delayed read returns that type (tests.cpp:219);
+ *     the type of a fed-back wire is what the "absorber" rule of ResultType gives: the least type that is consistent
+ *     around the loop, e.g. ~(_1[_1] + 1.0*_2) is double (tests.cpp:224-226); a loop that never meets another type
+ *     stays float;
+ *   - frames carry every wire in its own type: float = 1 float slot, double = 2 slots (low word, high word: the
+ *     frame is a double[] there), std::complex<float> = 2 slots (re, im).  n_in / n_out of fz_info count SLOTS,
+ *     n_in_wires / n_out_wires count wires.  FZ_VF_OUT_F64 does not apply (rejected).
+ * State rows: double lines come first and take two float rows per delay slot (one row of n_streams doubles);
+ * a complex wire has one float line for each part.  Double lines are register-resident: depth <= 8.
+ * Not offered: std::complex<double>.                                                                             */
+typedef enum fz_dtype { FZ_DT_F32 = 0, FZ_DT_F64 = 1, FZ_DT_CF32 = 2 } fz_dtype;
+int  fz_compile_typed(const fz_expr* e, const uint32_t* in_dtypes, uint32_t n_in_wires, fz_program** out);
+/* type of every input wire (fz_dtype); writes min(n, cap), returns n = n_in_wires */
+int  fz_program_input_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap);
+/* storage type of every delay line, in fz_program_lines order: 0 float, 1 double (two state rows per slot),
+ * 2 / 3 the real / imaginary part of a std::complex<float> wire (float rows); writes min(n, cap), returns n */
+int  fz_program_line_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap);
 void fz_program_destroy(fz_program* p);
 int  fz_program_info(const fz_program* p, fz_info* info);
 
@@ -118,7 +147,10 @@ typedef enum fz_ir_kind {
    FZ_IR_PARAM = 3,   /* a = per-stream coefficient index                                      */
    FZ_IR_DELAY = 4,   /* a = source node, b = n : value of node a, n samples ago               */
    FZ_IR_ADD = 5, FZ_IR_SUB = 6, FZ_IR_MUL = 7, FZ_IR_DIV = 8,   /* a (op) b                    */
-   FZ_IR_NEG = 9      /* -a                                                                    */
+   FZ_IR_NEG = 9,     /* -a                                                                    */
+   FZ_IR_WIDEN = 10,  /* (double)a : float -> double, exact                                    */
+   FZ_IR_NARROW = 11  /* (float)a  : double -> float, one IEEE rounding (both only appear where C++ itself converts
+                         inside an operator: the float complex division of libgcc's __divsc3, see fz_arith)           */
 } fz_ir_kind;
 
 typedef struct fz_ir_node {
@@ -133,7 +165,8 @@ int fz_program_ir(const fz_program* p, fz_ir_node* nodes, uint32_t cap);
 /* node id of each output frame slot (a complex wire takes two: re, im); writes min(n_out, cap), returns n_out */
 int fz_program_outputs(const fz_program* p, uint32_t* node_ids, uint32_t cap);
 /* arithmetic type of each output frame slot before it is narrowed to the float32 frame: 0 = float, 1 = double,
- * 2 / 3 = real / imaginary part of a std::complex<float> wire
+ * 2 / 3 = real / imaginary part of a std::complex<float> wire; fz_compile_typed programs: 4 / 5 = low / high word
+ * of a double wire (never 1: nothing is narrowed)
  * (the ResultType inference of flowz.hpp:585-644 / test/tests.cpp:200-231, with compile()'s float delay
  * lines: a delayed read is float whatever was pushed, flowz.hpp:1245); writes min(n_out, cap), returns n_out */
 int fz_program_output_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap);

@@ -34,3 +34,38 @@ extern "C" void fzo_complex_mix_std(float are, float aim, float bre, float bim, 
       }
    }
 }
+
+// typed programs: complex state and both spellings of the complex division, with std::complex<float>
+extern "C" void fzo_complex_one_pole_std(float cre, float cim, const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                                         float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   using cplx = std::complex<float>;
+   const cplx c{cre, cim};
+   for (long s = 0; s < n_streams; ++s) {
+      cplx z1{0.f, 0.f};
+      for (long t = 0; t < T; ++t) {
+         const cplx z = c * z1 + x[s * xss + t * xts];
+         float* o = y + s * yss + t * yts;
+         o[0] = z.real();
+         o[1] = z.imag();
+         z1 = z;
+      }
+   }
+}
+
+extern "C" void fzo_complex_div_mix_std(float are, float aim, float bre, float bim, const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                                        float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   using cplx = std::complex<float>;
+   const cplx A{are, aim}, B{bre, bim};
+   for (long s = 0; s < n_streams; ++s)
+      for (long t = 0; t < T; ++t) {
+         const float x0 = x[s * xss + t * xts];
+         const cplx z1 = A * x0;
+         const cplx w = B + x0;
+         const cplx r = z1 / w + x0 / w;
+         float* o = y + s * yss + t * yts;
+         o[0] = r.real();
+         o[1] = r.imag();
+      }
+}

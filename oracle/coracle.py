@@ -167,6 +167,27 @@ def complex_mix(x, A=(0.6, 0.8), B=(0.3, -0.4), c=(0.5, 0.25, 1.5, -0.125, 0.75)
     return _run("fzo_complex_mix", pre, x, 1, 3, stream_major)
 
 
+def complex_one_pole(x, c=(0.6, 0.7), stream_major=False, std=False):
+    """-> frames (re, im): tests/graphs.py complex_one_pole (typed programs: complex state)"""
+    pre = (ctypes.c_float(float(F32(c[0]))), ctypes.c_float(float(F32(c[1]))))
+    if std:
+        return _run("fzo_complex_one_pole_std", pre, x, 1, 2, stream_major, library=lib_std())
+    return _run("fzo_complex_one_pole", pre, x, 1, 2, stream_major)
+
+
+def complex_div_mix(x, A=(0.6, 0.8), B=(1.5, -0.75), stream_major=False, std=False):
+    """-> frames (re, im): tests/graphs.py complex_div_mix (complex / complex and scalar / complex)"""
+    pre = tuple(ctypes.c_float(float(F32(v))) for v in (*A, *B))
+    if std:
+        return _run("fzo_complex_div_mix_std", pre, x, 1, 2, stream_major, library=lib_std())
+    return _run("fzo_complex_div_mix", pre, x, 1, 2, stream_major)
+
+
+def double_accumulator(x, stream_major=False):
+    """-> float64 frames: tests/graphs.py double_accumulator with double state"""
+    return _run("fzo_double_accumulator", (), x, 1, 1, stream_major, np.float64)
+
+
 def rbj_lowpass(freq, q, sr, libmf=False):
     """-> (raw6 [6,n], df1 [5,n]); libmf=True: the reference's own float sinf/cosf spelling (raw6 only)."""
     freq = np.ascontiguousarray(freq, F32)

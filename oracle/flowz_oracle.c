@@ -350,6 +350,57 @@ void fzo_complex_mix(float are, float aim, float bre, float bim, const float* c 
    }
 }
 
+/* ---- typed programs (fz_compile_typed): ResultType carried through state (flowz.hpp:585-644) -------------------
+ * tests/graphs.py: complex_one_pole  ~( c*_1[_1] + _2 ): z = c*z1 + x, complex state.  frame = (re, im)           */
+void fzo_complex_one_pole(float cre, float cim, const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                          float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   const float _Complex c = __builtin_complex(cre, cim);
+   for (long s = 0; s < n_streams; ++s) {
+      float _Complex z1 = 0.f;
+      for (long t = 0; t < T; ++t) {
+         float _Complex z = c; z *= z1;                       /* complex * complex: __mulsc3 */
+         z += x[s * xss + t * xts];                           /* complex + float: real part only */
+         float* o = y + s * yss + t * yts;
+         o[0] = __real__ z;
+         o[1] = __imag__ z;
+         z1 = z;
+      }
+   }
+}
+
+/* tests/graphs.py: complex_div_mix  z1 = A*x ; w = B + x ; out = z1/w + x/w   (both are __divsc3)               */
+void fzo_complex_div_mix(float are, float aim, float bre, float bim, const float* x, ptrdiff_t xss, ptrdiff_t xts,
+                         float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
+{
+   const float _Complex A = __builtin_complex(are, aim), B = __builtin_complex(bre, bim);
+   for (long s = 0; s < n_streams; ++s)
+      for (long t = 0; t < T; ++t) {
+         const float x0 = x[s * xss + t * xts];
+         float _Complex z1 = A;  z1 *= x0;
+         float _Complex w = B;   w += x0;
+         float _Complex z2 = z1; z2 /= w;
+         float _Complex z3 = x0; z3 /= w;                     /* operator/(T, complex): r = s; r /= w */
+         float _Complex r = z2;  r += z3;
+         float* o = y + s * yss + t * yts;
+         o[0] = __real__ r;
+         o[1] = __imag__ r;
+      }
+}
+
+/* tests/graphs.py: double_accumulator  ~( _1[_1] + 1.0*_2 ) with a DOUBLE accumulator (typed state); y: doubles   */
+void fzo_double_accumulator(const float* x, ptrdiff_t xss, ptrdiff_t xts, double* y, ptrdiff_t yss, ptrdiff_t yts,
+                            long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      double acc = 0.0;
+      for (long t = 0; t < T; ++t) {
+         acc = acc + 1.0 * x[s * xss + t * xts];
+         y[s * yss + t * yts] = acc;
+      }
+   }
+}
+
 /* ---- RBJ low-pass coefficients, reactive_equations/reactive_filter_coeff.cpp:38-58, with the
  * reference's types: every PARAMETER is float, `1.` `2.` are double literals; std::cos/std::sin of a
  * float.  sin/cos are taken in double and rounded to float, which is within 1 ULP of (and almost

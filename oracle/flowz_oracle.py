@@ -152,7 +152,12 @@ class _Cplx:
          z * w                 _Complex float multiply = __mulsc3: ac = a*c, bd = b*d, ad = a*d,
                                bc = b*c, (ac - bd, ad + bc), every operation rounded to float (its
                                inf/nan recovery branch is not restated: finite values only)
-       s / z, z / w (__divsc3) are not restated."""
+       z / w, s / w          _Complex float divide = libgcc's __divsc3 as g++ links it here ("float is handled with
+                             double precision", libgcc2.c): aa..dd = the four parts widened to double,
+                             denom = cc*cc + dd*dd, x = (float)((aa*cc + bb*dd)/denom), y = (float)((bb*cc - aa*dd)/denom);
+                             s / w is complex<float>(s) /= w (<complex>), i.e. b = +0.f.  Its NaN-recovery branch is not
+                             restated (finite values, nonzero divisor).  tests/test_oracle_c.py pins this against
+                             std::complex<float> compiled by g++ (oracle/complex_std.cpp)."""
 
     __array_ufunc__ = None            # numpy arrays defer to the reflected operators below
     __slots__ = ("re", "im")
@@ -196,14 +201,23 @@ class _Cplx:
         o = self._scalar(o)
         return _Cplx(self.re * o, self.im * o)
 
+    @staticmethod
+    def _wide_div(a, b, c, d):
+        aa, bb, cc, dd = (np.asarray(v, F32).astype(np.float64) for v in (a, b, c, d))
+        denom = (cc * cc) + (dd * dd)
+        x = ((aa * cc) + (bb * dd)) / denom
+        y = ((bb * cc) - (aa * dd)) / denom
+        return _Cplx(x.astype(F32), y.astype(F32))
+
     def __truediv__(self, o):
         if isinstance(o, _Cplx):
-            raise GraphError("division by a std::complex wire (__divsc3) is not restated")
+            return self._wide_div(self.re, self.im, o.re, o.im)
         o = self._scalar(o)
         return _Cplx(self.re / o, self.im / o)
 
     def __rtruediv__(self, o):
-        raise GraphError("division by a std::complex wire (__divsc3) is not restated")
+        o = self._scalar(o)
+        return self._wide_div(o, np.zeros_like(self.re), self.re, self.im)
 
     def __neg__(self):
         return _Cplx(-self.re, -self.im)
@@ -232,8 +246,14 @@ class FlowzOracle:
 
     step(*inputs) == one call of stateful_lambda::operator() per stream (flowz.hpp:1225)."""
 
-    def __init__(self, expr, n_streams: int = 1, params=None, out_f64: bool = False):
+    def __init__(self, expr, n_streams: int = 1, params=None, out_f64: bool = False, typed: bool = False, in_dtypes=None):
+        """typed: the wire types of the reference's ResultType transform (flowz.hpp:585-644, test/tests.cpp:184-232) carried
+        through inputs (in_dtypes: 'f32' / 'f64' / 'cf32' per input wire -- the reference's callable is a template over
+        its argument types, :1225-1229), delay lines (a line stores what is pushed: tests.cpp:219; a fed-back wire gets
+        the least type consistent around its loop = what the absorber of :602-620 leaves) and outputs (nothing narrowed)."""
         self.expr = expr
+        self.typed = bool(typed or in_dtypes is not None)
+        self.in_dtypes = list(in_dtypes) if in_dtypes is not None else None
         self.out_dtype = np.float64 if out_f64 else F32      # float64: outputs leave un-narrowed
         self.n_streams = int(n_streams)
         self.n_in = input_arity(expr)
@@ -256,15 +276,38 @@ class FlowzOracle:
         self._delayed = [w for w in self._wires if w.depth > 0]
         for w in self._delayed:                      # zero-initialised float state (:1245)
             w.fifo = [np.zeros(self.n_streams, F32) for _ in range(w.depth)]
+        if self.in_dtypes is None:
+            self.in_dtypes = ["f32"] * self.n_in
+        if len(self.in_dtypes) != self.n_in:
+            raise GraphError("one input dtype per input wire")
+
+        def zero_of(kind):
+            if kind == "cf32":
+                return _Cplx(np.zeros(self.n_streams, F32), np.zeros(self.n_streams, F32))
+            return np.zeros(self.n_streams, np.float64 if kind == "f64" else F32)
+
+        def kind_of(v):
+            return "cf32" if isinstance(v, _Cplx) else ("f64" if np.asarray(v).dtype == np.float64 else "f32")
+
         # output frame slots: a complex wire takes two (re, im).  Types are static: probe them once.
-        self._t += 1
         for i in range(self.n_in):
-            self._cur_in[i] = np.zeros(self.n_streams, F32)
+            self._cur_in[i] = zero_of(self.in_dtypes[i])
         with np.errstate(all="ignore"):
+            for _ in range(8):                       # typed state: raise the lines' types until they settle (least fixpoint from float)
+                self._t += 1
+                changed = False
+                for w in self._delayed:
+                    k = kind_of(self._value(w))
+                    if k == "cf32" and not self.typed:
+                        raise GraphError("a std::complex wire cannot enter a delay line: compile() stores float state")
+                    if self.typed and k != kind_of(w.fifo[0]):
+                        if {k, kind_of(w.fifo[0])} == {"f64", "cf32"}:
+                            raise GraphError("a delayed wire is both double and std::complex<float>")
+                        w.fifo = [zero_of(k) for _ in range(w.depth)]
+                        changed = True
+                if not changed:
+                    break
             probe = [self._value(w) for w in self._outs]
-            for w in self._delayed:
-                if isinstance(self._value(w), _Cplx):
-                    raise GraphError("a std::complex wire cannot enter a delay line: compile() stores float state")
         self.out_types = ["cf32" if isinstance(v, _Cplx) else ("f64" if np.asarray(v).dtype == np.float64 else "f32") for v in probe]
         self.n_slots = sum(2 if k == "cf32" else 1 for k in self.out_types)
 
@@ -374,8 +417,13 @@ class FlowzOracle:
             raise GraphError(f"expected {self.n_in} inputs, got {len(inputs)}")
         self._t += 1
         for i, x in enumerate(inputs):
-            self._cur_in[i] = np.ascontiguousarray(
-                np.broadcast_to(np.asarray(x, dtype=F32), (self.n_streams,)))
+            dt = self.in_dtypes[i]
+            if dt == "cf32":
+                z = np.broadcast_to(np.asarray(x, dtype=np.complex64), (self.n_streams,))
+                self._cur_in[i] = _Cplx(np.ascontiguousarray(z.real), np.ascontiguousarray(z.imag))
+            else:
+                self._cur_in[i] = np.ascontiguousarray(
+                    np.broadcast_to(np.asarray(x, dtype=np.float64 if dt == "f64" else F32), (self.n_streams,)))
         outs = []
         for w in self._outs:                       # complex wires come out as numpy complex (exact pair)
             v = self._value(w)
@@ -383,10 +431,18 @@ class FlowzOracle:
                 c = np.empty(self.n_streams, np.complex128 if self.out_dtype == np.float64 else np.complex64)
                 c.real, c.imag = v.re, v.im
                 outs.append(c)
+            elif self.typed:
+                outs.append(np.array(v, copy=True))                     # its own type: nothing is narrowed
             else:
                 outs.append(np.array(v, dtype=self.out_dtype, copy=True))
         # consumers first, pushes last (:994, :1067)
-        new = [np.array(self._value(w), dtype=F32, copy=True) for w in self._delayed]
+        if self.typed:                               # a line stores the type that is pushed (ResultType)
+            new = []
+            for w in self._delayed:
+                v = self._value(w)
+                new.append(_Cplx(v.re.copy(), v.im.copy()) if isinstance(v, _Cplx) else np.array(v, copy=True))
+        else:
+            new = [np.array(self._value(w), dtype=F32, copy=True) for w in self._delayed]
         for w, v in zip(self._delayed, new):
             w.fifo.pop(0)               # rotate_push_back :130-137
             w.fifo.append(v)
@@ -415,6 +471,26 @@ class FlowzOracle:
         return y
 
 
+def run_typed(orc, wires):
+    """orc: a typed FlowzOracle; wires: per input wire an array [T, n_streams] in its own dtype (float32 / float64 /
+    complex64) -> per output wire an array [T, n_streams] in ITS dtype."""
+    T = np.shape(wires[0])[0] if wires else 0
+    outs = None
+    with np.errstate(all="ignore"):
+        for t in range(T):
+            o = orc.step(*[w[t] for w in wires])
+            if outs is None:
+                outs = [np.empty((T, orc.n_streams), v.dtype) for v in o]
+            for j, v in enumerate(o):
+                outs[j][t] = v
+    return outs
+
+
+def output_dtypes_typed(expr, in_dtypes=None):
+    """ResultType of the expression (flowz.hpp:585-644): the type of every output wire when state keeps the pushed type."""
+    return list(FlowzOracle(expr, 1, typed=True, in_dtypes=in_dtypes).out_types)
+
+
 def output_dtypes(expr):
     """Arithmetic type of every output wire as the evaluator produces it: 'f32', 'f64' or 'cf32'
     (std::complex<float>, tests.cpp:206-207).
@@ -424,8 +500,8 @@ def output_dtypes(expr):
     return list(FlowzOracle(expr, 1).out_types)
 
 
-def compile(expr, n_streams: int = 1, params=None, out_f64: bool = False) -> FlowzOracle:  # noqa: A001 (mirrors flowz::compile)
-    return FlowzOracle(expr, n_streams, params, out_f64)
+def compile(expr, n_streams: int = 1, params=None, out_f64: bool = False, typed: bool = False, in_dtypes=None) -> FlowzOracle:  # noqa: A001 (mirrors flowz::compile)
+    return FlowzOracle(expr, n_streams, params, out_f64, typed, in_dtypes)
 
 
 # ----------------------------------------------------------------------------------------

@@ -63,3 +63,30 @@ def complex_mix(A=(0.6, 0.8), B=(0.3, -0.4), c=(0.5, 0.25, 1.5, -0.125, 0.75)):
     z9 = add(lit(c[3]), z8)
     z10 = sub(z9, lit(c[4]))
     return chan(z10, fb(add(DEL(1, 1), IN(2))))
+
+
+# ---- typed programs (fz_compile_typed: ResultType through inputs, state and outputs) -------------------------
+def complex_one_pole(c=(0.6, 0.7)):
+    """~( c*_1[_1] + _2 ) with a std::complex<float> coefficient: the fed-back wire and its delay line are complex
+    (ResultType, flowz.hpp:585-644: the absorber takes the type it meets).  oracle: fzo_complex_one_pole[_std]"""
+    return fb(add(mul(litc(*c), DEL(1, 1)), IN(2)))
+
+
+def complex_div_mix(A=(0.6, 0.8), B=(1.5, -0.75)):
+    """z1 = A*x ; w = B + x ; z2 = z1 / w (complex / complex) ; z3 = x / w (scalar / complex) ; out = z2 + z3
+    -- both spellings of __divsc3.  oracle: fzo_complex_div_mix[_std]"""
+    x = IN(1)
+    z1 = mul(litc(*A), x)
+    w = add(litc(*B), x)
+    return add(("div", z1, w), ("div", x, w))
+
+
+def double_accumulator():
+    """test/tests.cpp:223  ~( _1[_1] + 1.0*_2 ): ResultType says the loop is double (tuple<double>); with typed state the
+    accumulator itself is a double.  oracle: fzo_double_accumulator"""
+    return fb(add(DEL(1, 1), mul(lit64(1.0), IN(2))))
+
+
+def typed_delay_of_double():
+    """test/tests.cpp:219  (_1[_1], 1.0*_1) |= _2[_1]: the delayed read of a double wire is double (ResultType)"""
+    return seq(chan(DEL(1, 1), mul(lit64(1.0), IN(1))), DEL(2, 1))

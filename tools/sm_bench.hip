@@ -72,6 +72,137 @@ __global__ void __launch_bounds__(BLOCK) k_walk(const float* __restrict__ s, flo
    }
 }
 
+// read runs of RI floats per stream and phase, write runs of RO floats (RI = k * RO): the wave reads a long run, then
+// writes it back as k shorter runs spread over k sub-phases (other streams' pieces in between), or the reverse
+template <int RI, int RO, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_sm_rw(const float* __restrict__ src, float* __restrict__ dst, unsigned n_streams, unsigned T)
+{
+   constexpr int R = RI > RO ? RI : RO;      // floats per stream and phase
+   constexpr int PP = R / 4, NP = 64 * PP / 64;
+   unsigned blk = blockIdx.x;
+   {
+      const unsigned nb = gridDim.x, xcd = blk & 7u, idx = blk >> 3, q = nb >> 3, r = nb & 7u;
+      blk = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+   }
+   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+   const size_t s_base = ((size_t)blk * (BLOCK / 64) + wave) * 64;
+   if (s_base >= n_streams) return;
+   const unsigned nch = T / R;
+   // piece i of lane: read mapping uses runs of RI, write mapping runs of RO
+   auto off_of = [&](int i, int RUN, unsigned c) -> size_t {
+      // the phase moves R floats per stream as R/RUN sub-runs; sub-run j of all 64 streams is one "sweep"
+      constexpr int dummy = 0; (void)dummy;
+      const int ppr = RUN / 4;                       // pieces per run
+      const unsigned e = (unsigned)i * 64u + lane;   // piece index in the phase: [sub-run j][stream sl][piece q]
+      const unsigned j = e / (64u * ppr), r = e - j * 64u * ppr, sl = r / ppr, q = r - sl * ppr;
+      return (s_base + sl) * (size_t)T + (size_t)c * R + j * RUN + q * 4;
+   };
+   f4 a[NP], b[NP];
+   if (nch > 0)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) a[i] = __builtin_nontemporal_load((const f4*)(src + off_of(i, RI, 0)));
+   for (unsigned c = 0; c < nch; c += 2) {
+      if (c + 1 < nch)
+#pragma unroll
+         for (int i = 0; i < NP; ++i) b[i] = __builtin_nontemporal_load((const f4*)(src + off_of(i, RI, c + 1)));
+      // (values are written where the WRITE mapping says: a pure bandwidth test, contents do not matter)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) __builtin_nontemporal_store(a[i], (f4*)(dst + off_of(i, RO, c)));
+      if (c + 2 < nch)
+#pragma unroll
+         for (int i = 0; i < NP; ++i) a[i] = __builtin_nontemporal_load((const f4*)(src + off_of(i, RI, c + 2)));
+      if (c + 1 < nch)
+#pragma unroll
+         for (int i = 0; i < NP; ++i) __builtin_nontemporal_store(b[i], (f4*)(dst + off_of(i, RO, c + 1)));
+   }
+}
+
+// read-only (sum into one float per lane) / write-only walks with runs of R floats
+template <int R, int BLOCK, bool WRITE>
+__global__ void __launch_bounds__(BLOCK) k_sm_one(const float* __restrict__ src, float* __restrict__ dst, unsigned n_streams, unsigned T)
+{
+   constexpr int PP = R / 4, NP = 64 * PP / 64;
+   unsigned blk = blockIdx.x;
+   {
+      const unsigned nb = gridDim.x, xcd = blk & 7u, idx = blk >> 3, q = nb >> 3, r = nb & 7u;
+      blk = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+   }
+   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+   const size_t s_base = ((size_t)blk * (BLOCK / 64) + wave) * 64;
+   if (s_base >= n_streams) return;
+   const unsigned nch = T / R;
+   size_t off[NP];
+#pragma unroll
+   for (int i = 0; i < NP; ++i) {
+      const unsigned e = i * 64 + lane, sl = e / PP, q = e - sl * PP;
+      off[i] = (s_base + sl) * (size_t)T + q * 4;
+   }
+   f4 acc = {0, 0, 0, 0};
+   for (unsigned c = 0; c < nch; ++c) {
+      if (WRITE) {
+#pragma unroll
+         for (int i = 0; i < NP; ++i) __builtin_nontemporal_store(acc, (f4*)(dst + off[i] + (size_t)c * R));
+      } else {
+         f4 v[NP];
+#pragma unroll
+         for (int i = 0; i < NP; ++i) v[i] = __builtin_nontemporal_load((const f4*)(src + off[i] + (size_t)c * R));
+#pragma unroll
+         for (int i = 0; i < NP; ++i) acc += v[i];
+      }
+   }
+   if (!WRITE && acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) dst[s_base + lane] = acc[0];
+}
+
+// 128-byte pieces per stream and chunk as the kernel reads them today, but every 4th chunk the wave first TOUCHES the
+// next 512-byte run of every stream (one dword per 128-byte line, default cache policy) so that DRAM sees long runs and
+// the later piece loads hit in L2 / Infinity Cache
+template <int BLOCK, bool TOUCH>
+__global__ void __launch_bounds__(BLOCK) k_sm_touch(const float* __restrict__ src, float* __restrict__ dst, unsigned n_streams, unsigned T)
+{
+   constexpr int R = 32, PP = 8, NP = 8;
+   unsigned blk = blockIdx.x;
+   {
+      const unsigned nb = gridDim.x, xcd = blk & 7u, idx = blk >> 3, q = nb >> 3, r = nb & 7u;
+      blk = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+   }
+   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+   const size_t s_base = ((size_t)blk * (BLOCK / 64) + wave) * 64;
+   if (s_base >= n_streams) return;
+   const unsigned nch = T / R;
+   size_t off[NP];
+#pragma unroll
+   for (int i = 0; i < NP; ++i) {
+      const unsigned e = i * 64 + lane, sl = e / PP, q = e - sl * PP;
+      off[i] = (s_base + sl) * (size_t)T + q * 4;
+   }
+   float sink = 0.f;
+   f4 a[NP], b[NP];
+#pragma unroll
+   for (int i = 0; i < NP; ++i) a[i] = __builtin_nontemporal_load((const f4*)(src + off[i]));
+   for (unsigned c = 0; c < nch; c += 2) {
+      if (TOUCH && (c & 3u) == 0 && c + 8 <= nch) {
+         // lines of chunks c+4 .. c+7 (the run after the next one): 64 streams x 4 lines = 256 touches = 4 per lane
+#pragma unroll
+         for (int k = 0; k < 4; ++k) {
+            const unsigned e = k * 64 + lane, sl = e >> 2, ln = e & 3u;
+            sink += src[(s_base + sl) * (size_t)T + (size_t)(c + 4 + ln) * R];
+         }
+      }
+      if (c + 1 < nch)
+#pragma unroll
+         for (int i = 0; i < NP; ++i) b[i] = __builtin_nontemporal_load((const f4*)(src + off[i] + (size_t)(c + 1) * R));
+#pragma unroll
+      for (int i = 0; i < NP; ++i) __builtin_nontemporal_store(a[i], (f4*)(dst + off[i] + (size_t)c * R));
+      if (c + 2 < nch)
+#pragma unroll
+         for (int i = 0; i < NP; ++i) a[i] = __builtin_nontemporal_load((const f4*)(src + off[i] + (size_t)(c + 2) * R));
+      if (c + 1 < nch)
+#pragma unroll
+         for (int i = 0; i < NP; ++i) __builtin_nontemporal_store(b[i], (f4*)(dst + off[i] + (size_t)(c + 1) * R));
+   }
+   if (sink == 12345.678f) dst[s_base + lane] = sink;
+}
+
 struct Case { std::string name; std::function<void()> run; std::vector<float> ms; };
 
 int main(int argc, char** argv)
@@ -90,6 +221,14 @@ int main(int argc, char** argv)
    SM(32, 3, 256, 64) SM(32, 4, 256, 64) SM(64, 3, 256, 64)
    SM(32, 2, 64, 64) SM(32, 2, 128, 64) SM(64, 2, 64, 64) SM(64, 2, 128, 64)
    SM(64, 2, 256, 32) SM(128, 2, 256, 32) SM(128, 2, 256, 16) SM(256, 2, 256, 16) SM(256, 2, 256, 8)
+#define RW(RI, RO, B) cases.push_back({"stream-major read runs " + std::to_string(RI * 4) + " B, write runs " + std::to_string(RO * 4) + " B, blk=" #B, \
+      [&] { k_sm_rw<RI, RO, B><<<dim3((ns / 64 + B / 64 - 1) / (B / 64)), dim3(B)>>>(s, d, ns, T); }, {}});
+   RW(128, 128, 256) RW(128, 32, 256) RW(32, 128, 256) RW(128, 64, 256) RW(64, 128, 256) RW(32, 32, 256)
+#define ONE(R, B, W) cases.push_back({std::string(W ? "write-only" : "read-only") + " runs " + std::to_string(R * 4) + " B blk=" #B " (GB/s of ONE direction x2 shown)", \
+      [&] { k_sm_one<R, B, W><<<dim3((ns / 64 + B / 64 - 1) / (B / 64)), dim3(B)>>>(s, d, ns, T); }, {}});
+   ONE(32, 256, false) ONE(128, 256, false) ONE(32, 256, true) ONE(128, 256, true)
+   cases.push_back({"128 B pieces, no touch (baseline of the next line)", [&] { k_sm_touch<256, false><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T); }, {}});
+   cases.push_back({"128 B pieces + 512 B run touched one run ahead", [&] { k_sm_touch<256, true><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T); }, {}});
    const size_t row = ns;
    cases.push_back({"frames tiled 8192 W=1 U=16", [&] { k_walk<1, 16, 256><<<dim3((row + 255) / 256), dim3(256)>>>(s, d, row, 8192, 8192, (size_t)8192 * T, T); }, {}});
    cases.push_back({"frames tiled 8192 W=2 U=16", [&] { k_walk<2, 16, 256><<<dim3((row / 2 + 255) / 256), dim3(256)>>>(s, d, row / 2, 4096, 8192, (size_t)8192 * T, T); }, {}});

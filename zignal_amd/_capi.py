@@ -32,13 +32,15 @@ FZ_VF_STREAM_MAJOR = 128
 def FZ_VF_MAX_WG(n):
     """at most n workgroups per CU (flags bits 20..22)"""
     return (int(n) & 7) << 20
-IR_KINDS = {1: "input", 2: "const", 3: "param", 4: "delay", 5: "add", 6: "sub", 7: "mul", 8: "div", 9: "neg"}
+IR_KINDS = {1: "input", 2: "const", 3: "param", 4: "delay", 5: "add", 6: "sub", 7: "mul", 8: "div", 9: "neg", 10: "widen", 11: "narrow"}
+FZ_DT_F32, FZ_DT_F64, FZ_DT_CF32 = 0, 1, 2
+DTYPES = {"f32": 0, "f64": 1, "cf32": 2}
 
 
 class Info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in
                 ("n_in", "n_out", "n_nodes", "n_ops", "n_lines", "n_state", "n_const", "n_param", "max_delay", "n_lds_slots",
-                 "stage_packable", "n_const64", "n_out_wires")]
+                 "stage_packable", "n_const64", "n_out_wires", "n_in_wires", "typed")]
 
 
 class IrNode(ctypes.Structure):
@@ -80,6 +82,9 @@ def _load():
         "fz_output_arity": (ctypes.c_int, [P]),
         "fz_max_input_delays": (ctypes.c_int, [P, ctypes.POINTER(u32), u32]),
         "fz_compile": (ctypes.c_int, [P, ctypes.POINTER(P)]),
+        "fz_compile_typed": (ctypes.c_int, [P, ctypes.POINTER(u32), u32, ctypes.POINTER(P)]),
+        "fz_program_input_dtypes": (ctypes.c_int, [P, ctypes.POINTER(u32), u32]),
+        "fz_program_line_dtypes": (ctypes.c_int, [P, ctypes.POINTER(u32), u32]),
         "fz_program_destroy": (None, [P]),
         "fz_program_info": (ctypes.c_int, [P, ctypes.POINTER(Info)]),
         "fz_program_ir": (ctypes.c_int, [P, ctypes.POINTER(IrNode), u32]),

@@ -2,6 +2,7 @@
 // kernel build (hiprtc needs no GPU), and the fz_run_block wrapper.
 #include <cmath>
 #include <cstring>
+#include <memory>
 
 #include "fz_internal.hpp"
 
@@ -29,6 +30,39 @@ int fz_compile(const fz_expr* e, fz_program** out)
       return FZ_OK;)
 }
 
+int fz_compile_typed(const fz_expr* e, const uint32_t* in_dtypes, uint32_t n_in_wires, fz_program** out)
+{
+   FZ_GUARD(
+      if (!e || !out) fail(FZ_E_INVALID, "fz_compile_typed: null argument");
+      if (in_dtypes && n_in_wires != (uint32_t)e->in_arity)
+         fail(FZ_E_INVALID, "fz_compile_typed: in_dtypes must have one entry per input wire (input_arity)");
+      LowerOptions opt;
+      opt.typed = true;
+      for (uint32_t i = 0; in_dtypes && i < n_in_wires; ++i) {
+         if (in_dtypes[i] > FZ_DT_CF32) fail(FZ_E_INVALID, "fz_compile_typed: unknown fz_dtype");
+         opt.in_dtype.push_back((uint8_t)in_dtypes[i]);
+      }
+      std::unique_ptr<fz_program> p(new fz_program());
+      p->g = lower(e, opt);
+      *out = p.release();
+      return FZ_OK;)
+}
+
+int fz_program_input_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap)
+{
+   if (!p) { set_error("null program"); return FZ_E_INVALID; }
+   for (size_t k = 0; k < p->g.in_dtype.size() && k < cap && dtypes; ++k) dtypes[k] = p->g.in_dtype[k];
+   return (int)p->g.in_dtype.size();
+}
+
+int fz_program_line_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap)
+{
+   if (!p) { set_error("null program"); return FZ_E_INVALID; }
+   for (size_t k = 0; k < p->g.lines.size() && k < cap && dtypes; ++k)
+      dtypes[k] = p->g.lines[k].f64 ? 1u : (p->g.lines[k].part ? 1u + p->g.lines[k].part : 0u);
+   return (int)p->g.lines.size();
+}
+
 void fz_program_destroy(fz_program* p) { delete p; }
 
 int fz_program_info(const fz_program* p, fz_info* info)
@@ -49,6 +83,8 @@ int fz_program_info(const fz_program* p, fz_info* info)
       info->stage_packable = g.split.ok ? 1u : 0u;
       info->n_const64 = (uint32_t)g.consts64.size();
       info->n_out_wires = g.n_out_wires;
+      info->n_in_wires = (uint32_t)g.in_dtype.size();
+      info->typed = g.typed ? 1u : 0u;
       return FZ_OK;)
 }
 

@@ -78,6 +78,8 @@ struct Line {
    uint32_t src;     // node whose value is pushed every sample
    uint32_t depth;   // deepest delayed read
    uint32_t row0;    // first state row
+   bool f64 = false; // typed programs: the line stores doubles (two float rows per slot)
+   uint8_t part = 0; // typed programs: 1 / 2 = the real / imaginary part of a std::complex<float> wire
    bool in_lds;      // ring buffer in LDS instead of registers
    uint32_t lds_slot0 = 0, lds_size = 0;   // ring placement (size is a power of two >= depth)
    // FAR lines (depth > kLdsMaxDepth): the line's state rows ARE a ring buffer in HBM, written
@@ -94,10 +96,12 @@ struct FarRead {
 };
 
 struct Graph {
-   uint32_t n_in = 0, n_out = 0, n_param = 0;
+   uint32_t n_in = 0, n_out = 0, n_param = 0;   // n_in / n_out: frame SLOTS (floats per frame)
+   bool typed = false;               // fz_compile_typed: wire types carried through inputs, state and outputs
+   std::vector<uint8_t> in_dtype;    // per input wire: fz_dtype
    std::vector<Node> nodes;          // topological order
    std::vector<uint32_t> outputs;    // node ids, one per output frame slot
-   std::vector<uint8_t> out_part;    // per slot: 0 real wire, 1 / 2 = re / im of a complex wire
+   std::vector<uint8_t> out_part;    // per slot: 0 real wire, 1 / 2 = re / im of a complex wire, 3 / 4 = low / high word of a double (typed)
    uint32_t n_out_wires = 0;         // output_arity (complex wires take two slots)
    std::vector<Line> lines;          // ordered by src
    std::vector<float> consts;        // uniform coefficient slots
@@ -118,7 +122,11 @@ constexpr uint32_t kRegMaxDepth = 8;
 constexpr uint32_t kLdsMaxDepth = 256;   // deeper lines live in HBM (ring in the state buffer)
 constexpr uint32_t kFarMinDelay = 32;    // far reads at least this old allow the full 16-step prefetch chunk (a read must be two chunks old)
 
-Graph lower(const fz_expr* e);   // throws Error
+struct LowerOptions {
+   bool typed = false;               // ResultType semantics for inputs, state and outputs
+   std::vector<uint8_t> in_dtype;    // per input wire (typed only); missing entries: float
+};
+Graph lower(const fz_expr* e, const LowerOptions& opt = LowerOptions());   // throws Error
 std::vector<uint32_t> max_input_delays(const fz_expr* e);
 
 // ---- code generation -------------------------------------------------------------------------------

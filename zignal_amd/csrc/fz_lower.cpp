@@ -39,6 +39,7 @@ struct Raw {
 };
 
 struct Elab {
+   bool typed = false;      // fz_compile_typed: delay lines keep the pushed type (ResultType, flowz.hpp:585-644)
    std::vector<Raw> raw;
    // std::complex<float> wires (test/tests.cpp:206-207) are lowered to PAIRS of float nodes while the
    // wire graph is built: a complex wire is known by its real part (always a fresh node), imag_of maps
@@ -46,7 +47,7 @@ struct Elab {
    //   z*s, s*z = (re*s, im*s)    z/s = (re/s, im/s)    z+s, s+z = (re+s, im)    z-s = (re-s, im)
    //   s-z = ((-re)+s, -im)   [complex r = -z; r += s]    z+-w componentwise    -z = (-re, -im)
    //   z*w = (ac-bd, ad+bc): the arithmetic of __mulsc3 (_Complex float) for finite values; its
-   //         inf/nan recovery branch is not reproduced.   s/z, z/w (__divsc3): not supported.
+   //         inf/nan recovery branch is not reproduced.   s/z, z/w: __divsc3, see wide_div below.
    std::map<int, int> imag_of;
 
    int add(uint32_t kind, int a = -1, int b = -1, float value = 0.f, uint32_t n = 0)
@@ -77,9 +78,20 @@ struct Elab {
             return {ins[e->i - 1]};
          case EK::Delayed:                                              // place_delay :950-958
             if (e->i > ins.size()) fail(FZ_E_GRAPH, "placeholder _" + std::to_string(e->i) + " has no wire to bind to");
-            if (imag_of.count(ins[e->i - 1]))
-               fail(FZ_E_GRAPH, "a std::complex wire cannot be read through a delay line: compile() stores float state (flowz.hpp:1245)");
-            return {add(FZ_IR_DELAY, ins[e->i - 1], -1, 0.f, e->n)};
+            if (imag_of.count(ins[e->i - 1])) {
+               if (!typed)
+                  fail(FZ_E_GRAPH, "a std::complex wire cannot be read through a delay line: compile() stores float state (flowz.hpp:1245); "
+                                   "fz_compile_typed keeps the wire's type");
+               // one float line per part
+               const int src = ins[e->i - 1];
+               const int re = add(FZ_IR_DELAY, src, -1, 0.f, e->n), im = add(FZ_IR_DELAY, imag_of[src], -1, 0.f, e->n);
+               imag_of[re] = im;
+               return {re};
+            } else {
+               const int id = add(FZ_IR_DELAY, ins[e->i - 1], -1, 0.f, e->n);
+               if (typed) raw[(size_t)id].f64 = raw[(size_t)ins[e->i - 1]].f64;   // the line stores what is pushed (tests.cpp:219)
+               return {id};
+            }
          case EK::Literal: {
             if (e->cplx) {
                int re = add(FZ_IR_CONST, -1, -1, e->value), im = add(FZ_IR_CONST, -1, -1, e->value_im);
@@ -130,17 +142,60 @@ struct Elab {
          }
          case EK::Feedback: {                                           // :1031-1074, arity-table routing
             size_t k = (size_t)e->a->out_arity;
-            std::vector<int> in2;
-            for (size_t j = 0; j < k; ++j) in2.push_back(add(K_FWD));
-            std::vector<int> fwd = in2;
-            in2.insert(in2.end(), ins.begin(), ins.end());
-            auto ao = run(e->a, in2);
-            if (ao.size() != k) fail(FZ_E_GRAPH, "feedback body arity mismatch");
-            for (int w : ao)
-               if (imag_of.count(w))
-                  fail(FZ_E_GRAPH, "a std::complex wire cannot be fed back: compile() stores float state (flowz.hpp:1245)");
-            for (size_t j = 0; j < k; ++j) raw[(size_t)fwd[j]].a = ao[j];
-            return ao;
+            if (!typed) {
+               std::vector<int> in2;
+               for (size_t j = 0; j < k; ++j) in2.push_back(add(K_FWD));
+               std::vector<int> fwd = in2;
+               in2.insert(in2.end(), ins.begin(), ins.end());
+               auto ao = run(e->a, in2);
+               if (ao.size() != k) fail(FZ_E_GRAPH, "feedback body arity mismatch");
+               for (int w : ao)
+                  if (imag_of.count(w))
+                     fail(FZ_E_GRAPH, "a std::complex wire cannot be fed back: compile() stores float state (flowz.hpp:1245); "
+                                      "fz_compile_typed keeps the wire's type");
+               for (size_t j = 0; j < k; ++j) raw[(size_t)fwd[j]].a = ao[j];
+               return ao;
+            }
+            // Typed: the type of a fed-back wire is the least one that is consistent around the loop -- what ResultType's
+            // absorber computes (:602-620: the recursion variable is absorbed by whatever it meets; float is the bottom of
+            // the usual arithmetic conversions).  Start from float, elaborate, raise, repeat (at most twice per wire).
+            std::vector<uint8_t> assume(k, 0);
+            for (int round = 0;; ++round) {
+               if (round > 4) fail(FZ_E_GRAPH, "internal: feedback wire types do not settle");
+               const size_t mark = raw.size();
+               const std::map<int, int> imag_mark = imag_of;
+               std::vector<int> in2, fwd_re(k), fwd_im(k, -1);
+               for (size_t j = 0; j < k; ++j) {
+                  fwd_re[j] = add(K_FWD);
+                  if (assume[j] == 1) raw[(size_t)fwd_re[j]].f64 = true;
+                  if (assume[j] == 2) {
+                     fwd_im[j] = add(K_FWD);
+                     imag_of[fwd_re[j]] = fwd_im[j];
+                  }
+                  in2.push_back(fwd_re[j]);
+               }
+               in2.insert(in2.end(), ins.begin(), ins.end());
+               auto ao = run(e->a, in2);
+               if (ao.size() != k) fail(FZ_E_GRAPH, "feedback body arity mismatch");
+               bool same = true;
+               for (size_t j = 0; j < k; ++j) {
+                  const uint8_t act = imag_of.count(ao[j]) ? 2 : (raw[(size_t)ao[j]].f64 ? 1 : 0);
+                  if (act == assume[j]) continue;
+                  same = false;
+                  if ((act == 1 && assume[j] == 2) || (act == 2 && assume[j] == 1))
+                     fail(FZ_E_GRAPH, "a fed-back wire is both double and std::complex<float> (no such conversion in C++)");
+                  assume[j] = std::max(assume[j], act);
+               }
+               if (same) {
+                  for (size_t j = 0; j < k; ++j) {
+                     raw[(size_t)fwd_re[j]].a = ao[j];
+                     if (fwd_im[j] >= 0) raw[(size_t)fwd_im[j]].a = imag_of[ao[j]];
+                  }
+                  return ao;
+               }
+               raw.resize(mark);                                  // forget this attempt
+               imag_of = imag_mark;
+            }
          }
       }
       fail(FZ_E_GRAPH, "unknown expression node");
@@ -172,7 +227,7 @@ struct Elab {
                im = arith(FZ_IR_ADD, ad, bc);
                break;
             }
-            default: fail(FZ_E_UNSUPPORTED, "division by a std::complex wire (__divsc3) is not supported");
+            default: return wide_div(ar, ai, br, bi);
          }
       } else if (ca) {                                      // complex (op) scalar
          const int ar = a, ai = imag_of[a];
@@ -186,9 +241,34 @@ struct Elab {
             case FZ_IR_ADD: re = arith(FZ_IR_ADD, br, a); im = bi; break;
             case FZ_IR_SUB: re = arith(FZ_IR_ADD, arith(FZ_IR_NEG, br), a); im = arith(FZ_IR_NEG, bi); break;
             case FZ_IR_MUL: re = arith(FZ_IR_MUL, br, a); im = arith(FZ_IR_MUL, bi, a); break;
-            default: fail(FZ_E_UNSUPPORTED, "division by a std::complex wire (__divsc3) is not supported");
+            default: {                                      // s / w: complex<float> r = s; r /= w  (<complex>), b = +0.f
+               const int zero = add(FZ_IR_CONST, -1, -1, 0.f);
+               return wide_div(a, zero, br, bi);
+            }
          }
       }
+      imag_of[re] = im;
+      return re;
+   }
+
+   // (a + ib) / (c + id) as g++ computes it for std::complex<float> / float _Complex: libgcc's __divsc3, which handles
+   // float with double precision (libgcc2.c, "float is handled with double precision when double precision hardware is
+   // available": the simple formula, no Smith scaling):
+   //    aa = a, bb = b, cc = c, dd = d (double);  denom = cc*cc + dd*dd;
+   //    x = (float)((aa*cc + bb*dd) / denom);     y = (float)((bb*cc - aa*dd) / denom)
+   // Its recovery branch for NaN results (zero or infinite operands) is not reproduced: finite values, nonzero divisor.
+   int wide_div(int a, int b, int c, int d)
+   {
+      auto widen = [&](int v) {
+         const int id = add(FZ_IR_WIDEN, v);
+         raw[(size_t)id].f64 = true;
+         return id;
+      };
+      const int aa = widen(a), bb = widen(b), cc = widen(c), dd = widen(d);
+      const int denom = arith(FZ_IR_ADD, arith(FZ_IR_MUL, cc, cc), arith(FZ_IR_MUL, dd, dd));
+      const int xn = arith(FZ_IR_ADD, arith(FZ_IR_MUL, aa, cc), arith(FZ_IR_MUL, bb, dd));
+      const int yn = arith(FZ_IR_SUB, arith(FZ_IR_MUL, bb, cc), arith(FZ_IR_MUL, aa, dd));
+      const int re = add(FZ_IR_NARROW, arith(FZ_IR_DIV, xn, denom)), im = add(FZ_IR_NARROW, arith(FZ_IR_DIV, yn, denom));
       imag_of[re] = im;
       return re;
    }
@@ -221,17 +301,33 @@ uint64_t bits_of64(double f)
 
 }  // namespace
 
-Graph lower(const fz_expr* e)
+Graph lower(const fz_expr* e, const LowerOptions& opt)
 {
    if (!e) fail(FZ_E_INVALID, "null expression");
    Elab el;
-   const uint32_t n_in = (uint32_t)e->in_arity;
+   el.typed = opt.typed;
+   const uint32_t n_in_wires = (uint32_t)e->in_arity;
+   // front panel: one wire per external input; typed programs: a double wire takes two frame slots (low, high word),
+   // a std::complex<float> wire two (re, im)
    std::vector<int> ins;
-   for (uint32_t i = 0; i < n_in; ++i) ins.push_back(el.add(FZ_IR_INPUT, -1, -1, 0.f, i));   // front panel
+   std::vector<uint8_t> in_dtype(n_in_wires, 0);
+   uint32_t n_in = 0;                                        // frame slots
+   for (uint32_t i = 0; i < n_in_wires; ++i) {
+      const uint8_t dt = (opt.typed && i < opt.in_dtype.size()) ? opt.in_dtype[i] : 0;
+      if (dt > 2) fail(FZ_E_INVALID, "unknown input wire type");
+      in_dtype[i] = dt;
+      const int id = el.add(FZ_IR_INPUT, -1, -1, 0.f, n_in);
+      if (dt == 1) el.raw[(size_t)id].f64 = true;
+      if (dt == 2) el.imag_of[id] = el.add(FZ_IR_INPUT, -1, -1, 0.f, n_in + 1);
+      n_in += dt ? 2 : 1;
+      ins.push_back(id);
+   }
+   std::vector<int> input_nodes;                             // every INPUT node (kept alive even when unused)
+   for (size_t i = 0; i < el.raw.size(); ++i) input_nodes.push_back((int)i);
    std::vector<int> out_wires = el.run(e, ins);
    if ((int)out_wires.size() != e->out_arity) fail(FZ_E_GRAPH, "output arity mismatch between arity table and routing");
    if (out_wires.empty()) fail(FZ_E_GRAPH, "graph has no output wire");
-   // output frame slots: a complex wire takes two (re, im)
+   // output frame slots: a complex wire takes two (re, im); typed programs: a double wire two (low, high word)
    std::vector<int> outs;
    std::vector<uint8_t> out_part;
    for (int w : out_wires) {
@@ -258,7 +354,7 @@ Graph lower(const fz_expr* e)
    std::vector<char> live(N, 0);
    {
       std::vector<int> work(outs.begin(), outs.end());
-      for (uint32_t i = 0; i < n_in; ++i) work.push_back(ins[i]);
+      for (int v : input_nodes) work.push_back(v);
       while (!work.empty()) {
          int v = work.back();
          work.pop_back();
@@ -303,7 +399,7 @@ Graph lower(const fz_expr* e)
             }
          }
       };
-      for (uint32_t i = 0; i < n_in; ++i) visit(ins[i]);
+      for (int v : input_nodes) visit(v);
       for (int o : outs) visit(o);
       // sources of delayed reads that are not otherwise needed this sample
       for (size_t i = 0; i < N; ++i)
@@ -322,6 +418,12 @@ Graph lower(const fz_expr* e)
             break;
          case FZ_IR_NEG: r.f64 = raw[(size_t)r.a].f64; break;
          case FZ_IR_CONST: break;
+         case FZ_IR_WIDEN: r.f64 = true; break;
+         case FZ_IR_NARROW: r.f64 = false; break;
+         case FZ_IR_DELAY:
+         case FZ_IR_INPUT:
+            if (!opt.typed) r.f64 = false;               // typed: set when the node was made (the line / wire type)
+            break;
          default: r.f64 = false; break;
       }
    }
@@ -372,7 +474,7 @@ Graph lower(const fz_expr* e)
                break;
             case FZ_IR_PARAM: key = {r.kind, -1, -1, r.n}; break;
             case FZ_IR_DELAY: key = {r.kind, rep[(size_t)r.a], -1, r.n}; break;
-            case FZ_IR_NEG: key = {r.kind, rep[(size_t)r.a], -1, 0}; break;
+            case FZ_IR_NEG: case FZ_IR_WIDEN: case FZ_IR_NARROW: key = {r.kind, rep[(size_t)r.a], -1, 0}; break;
             default: key = {r.kind, rep[(size_t)r.a], rep[(size_t)r.b], 0}; break;
          }
          auto it = seen.find(key);
@@ -404,15 +506,27 @@ Graph lower(const fz_expr* e)
             break;
          case FZ_IR_PARAM: n.a = r.n; g.n_param = std::max(g.n_param, r.n + 1); break;
          case FZ_IR_DELAY: n.a = nid(r.a); n.b = r.n; break;
-         case FZ_IR_NEG: n.a = nid(r.a); ++g.n_ops; break;
+         case FZ_IR_NEG: case FZ_IR_WIDEN: case FZ_IR_NARROW: n.a = nid(r.a); ++g.n_ops; break;
          default: n.a = nid(r.a); n.b = nid(r.b); ++g.n_ops; break;
       }
    }
    g.n_in = n_in;
-   g.n_out = (uint32_t)outs.size();
+   g.typed = opt.typed;
+   g.in_dtype = in_dtype;
    g.n_out_wires = (uint32_t)out_wires.size();
-   g.out_part = out_part;
-   for (int o : outs) g.outputs.push_back(nid(o));
+   for (size_t k = 0; k < outs.size(); ++k) {
+      const uint32_t id = nid(outs[k]);
+      if (opt.typed && out_part[k] == 0 && g.nodes[id].f64) {   // a double wire leaves un-narrowed: two slots
+         g.outputs.push_back(id);
+         g.out_part.push_back(3);
+         g.outputs.push_back(id);
+         g.out_part.push_back(4);
+      } else {
+         g.outputs.push_back(id);
+         g.out_part.push_back(out_part[k]);
+      }
+   }
+   g.n_out = (uint32_t)g.outputs.size();
 
    // delay lines: one per delayed wire, depth = deepest reader
    std::map<uint32_t, uint32_t> depth;
@@ -420,13 +534,29 @@ Graph lower(const fz_expr* e)
       if (n.kind == FZ_IR_DELAY) depth[n.a] = std::max(depth[n.a], n.b);
    g.line_of_node.assign(g.nodes.size(), -1);
    uint32_t row = 0, lds = 0;
+   // which delayed nodes are parts of complex wires (typed programs; informational)
+   std::map<uint32_t, uint8_t> part_of;
+   if (opt.typed)
+      for (auto& kv : el.imag_of) {
+         if (newid[(size_t)rep[(size_t)kv.first]] >= 0 && !part_of.count(nid(kv.first))) part_of[nid(kv.first)] = 1;
+         if (newid[(size_t)rep[(size_t)kv.second]] >= 0 && !part_of.count(nid(kv.second))) part_of[nid(kv.second)] = 2;
+      }
+   // double lines first (two float rows per slot: their rows start at even row numbers, so a row of n_streams doubles
+   // is 8-byte aligned whatever n_streams is), then the float lines; inside each group in node order
+   for (int pass = 0; pass < 2; ++pass)
    for (auto& kv : depth) {
+      const bool f64 = opt.typed && g.nodes[kv.first].f64;
+      if (f64 != (pass == 0)) continue;
       Line l{};
       l.src = kv.first;
       l.depth = kv.second;
       l.row0 = row;
+      l.f64 = f64;
+      l.part = part_of.count(kv.first) ? part_of[kv.first] : 0;
       l.far = l.depth > kLdsMaxDepth;
       l.in_lds = l.depth > kRegMaxDepth && !l.far;
+      if (f64 && l.depth > kRegMaxDepth)
+         fail(FZ_E_UNSUPPORTED, "a double delay line deeper than " + std::to_string(kRegMaxDepth) + " samples (double state is register-resident)");
       if (l.in_lds) {
          uint32_t sz = 1;
          while (sz < l.depth) sz <<= 1;
@@ -434,7 +564,7 @@ Graph lower(const fz_expr* e)
          l.lds_size = sz;
          lds += sz;
       }
-      row += l.depth;
+      row += l.depth * (f64 ? 2u : 1u);
       g.max_delay = std::max(g.max_delay, l.depth);
       g.line_of_node[l.src] = (int)g.lines.size();
       g.lines.push_back(l);

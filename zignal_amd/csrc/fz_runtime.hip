@@ -248,6 +248,8 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    const uint32_t reqP = uv ? uv->streams_per_lane : 0, reqU = uv ? uv->unroll : 0, reqB = uv ? uv->block_threads : 0;
    v.flags = uv ? uv->flags : 0;
    if (reqP != 0 && reqP != 1 && reqP != 2 && reqP != 4) fail(FZ_E_INVALID, "streams_per_lane must be 0, 1, 2 or 4");
+   if (g.typed && (v.flags & FZ_VF_OUT_F64))
+      fail(FZ_E_INVALID, "FZ_VF_OUT_F64 does not apply to fz_compile_typed programs: their frames carry every wire in its own type");
    if (reqU > 32) fail(FZ_E_INVALID, "unroll must be <= 32");
    if (reqB != 0 && (reqB % 64 != 0 || reqB > 1024)) fail(FZ_E_INVALID, "block_threads must be a multiple of 64, <= 1024");
    if (reqP) {

@@ -205,10 +205,17 @@ def _check_dev(t, shape, what, dtype=None):
 class Program:
     """compile() result: lowered graph + its fused gfx950 kernels (flowz.hpp:1233-1249)."""
 
-    def __init__(self, expr):
+    def __init__(self, expr, typed: bool = False, in_dtypes: Optional[Sequence[str]] = None):
         self.expr = as_expr(expr)
         h = ctypes.c_void_p()
-        C.check(C.lib.fz_compile(self.expr._h, ctypes.byref(h)))
+        if typed or in_dtypes is not None:
+            # ResultType semantics (flowz.hpp:585-644): wire types carried through inputs, state and outputs
+            n = self.expr.ins
+            dts = list(in_dtypes) if in_dtypes is not None else ["f32"] * n
+            arr = (ctypes.c_uint32 * max(n, 1))(*[C.DTYPES[d] for d in dts])
+            C.check(C.lib.fz_compile_typed(self.expr._h, arr, len(dts), ctypes.byref(h)))
+        else:
+            C.check(C.lib.fz_compile(self.expr._h, ctypes.byref(h)))
         self._h = h
         info = C.Info()
         C.check(C.lib.fz_program_info(self._h, ctypes.byref(info)))
@@ -249,7 +256,22 @@ class Program:
         (a 'cf32' wire, std::complex<float>, takes two frame slots: re, im)."""
         buf = (ctypes.c_uint32 * max(self.n_out, 1))()
         C.check(C.lib.fz_program_output_dtypes(self._h, buf, self.n_out))
-        return [("f32", "f64", "cf32")[buf[i]] for i in range(self.n_out) if buf[i] != 3]
+        return [("f32", "f64", "cf32", None, "f64")[buf[i]] for i in range(self.n_out) if buf[i] not in (3, 5)]
+
+    def input_dtypes(self):
+        """'f32' / 'f64' / 'cf32' per input WIRE (typed programs; all 'f32' otherwise)"""
+        n = max(self.n_in_wires, 1)
+        buf = (ctypes.c_uint32 * n)()
+        k = C.check(C.lib.fz_program_input_dtypes(self._h, buf, n))
+        return [("f32", "f64", "cf32")[buf[i]] for i in range(k)]
+
+    def line_dtypes(self):
+        """storage type per delay line (in lines() order): 'f32', 'f64' (two state rows per slot), 're' / 'im' (the
+        float lines of a std::complex<float> wire)"""
+        n = max(self.n_lines, 1)
+        buf = (ctypes.c_uint32 * n)()
+        k = C.check(C.lib.fz_program_line_dtypes(self._h, buf, n))
+        return [("f32", "f64", "re", "im")[buf[i]] for i in range(k)]
 
     def lines(self):
         n = self.n_lines
@@ -558,8 +580,43 @@ def from_tiled(y):
     return z.reshape(T, n_tiles * tile, w)
 
 
-def compile(expr) -> Program:  # noqa: A001  (mirrors flowz::compile)
-    return Program(expr)
+def compile(expr, typed: bool = False, in_dtypes: Optional[Sequence[str]] = None) -> Program:  # noqa: A001  (mirrors flowz::compile)
+    """typed / in_dtypes: fz_compile_typed -- every wire keeps its C++ type through inputs, state and outputs (ResultType,
+    flowz.hpp:585-644); frames then hold 'f64' and 'cf32' wires in two float slots (see pack_typed / unpack_typed)."""
+    return Program(expr, typed, in_dtypes)
+
+
+def pack_typed(wires, dtypes):
+    """numpy helper: per-wire arrays [T, n_streams] (float32 / float64 / complex64) -> float32 frames [T, n_streams, slots]
+    as a typed program reads them."""
+    import numpy as np
+
+    cols = []
+    for w, dt in zip(wires, dtypes):
+        if dt == "f32":
+            cols.append(np.asarray(w, np.float32)[..., None])
+        elif dt == "f64":
+            cols.append(np.ascontiguousarray(np.asarray(w, np.float64)).view(np.float32).reshape(np.shape(w) + (2,)))
+        else:
+            cols.append(np.ascontiguousarray(np.asarray(w, np.complex64)).view(np.float32).reshape(np.shape(w) + (2,)))
+    return np.ascontiguousarray(np.concatenate(cols, axis=-1))
+
+
+def unpack_typed(frames, dtypes):
+    """inverse of pack_typed: float32 frames [T, n_streams, slots] -> list of per-wire arrays in their own dtype"""
+    import numpy as np
+
+    frames = np.ascontiguousarray(frames, np.float32)
+    out, k = [], 0
+    for dt in dtypes:
+        if dt == "f32":
+            out.append(frames[..., k].copy())
+            k += 1
+        else:
+            pair = np.ascontiguousarray(frames[..., k:k + 2])
+            out.append(pair.view(np.float64 if dt == "f64" else np.complex64)[..., 0])
+            k += 2
+    return out
 
 
 def device_count() -> int:
