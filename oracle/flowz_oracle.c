@@ -369,6 +369,20 @@ void fzo_complex_one_pole(float cre, float cim, const float* x, ptrdiff_t xss, p
    }
 }
 
+/* std::complex<float> division as g++ links it: operator/= forwards to the _Complex float divide, i.e. libgcc's
+ * __divsc3, which "handles float with double precision" (libgcc2.c): the simple formula on the widened parts, one
+ * rounding to float at the end.  Spelled out here because gcc's C front end lowers a `float _Complex` divide with a
+ * real-only numerator differently from the library call the C++ operator makes; oracle/complex_std.cpp is the pin.
+ * (NaN-recovery branch of __divsc3 not restated: finite values, nonzero divisor.)                                   */
+static float _Complex cdiv_wide(float _Complex z, float _Complex w)
+{
+   const double aa = __real__ z, bb = __imag__ z, cc = __real__ w, dd = __imag__ w;
+   const double denom = (cc * cc) + (dd * dd);
+   const float x = (float)(((aa * cc) + (bb * dd)) / denom);
+   const float y = (float)(((bb * cc) - (aa * dd)) / denom);
+   return __builtin_complex(x, y);
+}
+
 /* tests/graphs.py: complex_div_mix  z1 = A*x ; w = B + x ; out = z1/w + x/w   (both are __divsc3)               */
 void fzo_complex_div_mix(float are, float aim, float bre, float bim, const float* x, ptrdiff_t xss, ptrdiff_t xts,
                          float* y, ptrdiff_t yss, ptrdiff_t yts, long n_streams, long T)
@@ -379,8 +393,8 @@ void fzo_complex_div_mix(float are, float aim, float bre, float bim, const float
          const float x0 = x[s * xss + t * xts];
          float _Complex z1 = A;  z1 *= x0;
          float _Complex w = B;   w += x0;
-         float _Complex z2 = z1; z2 /= w;
-         float _Complex z3 = x0; z3 /= w;                     /* operator/(T, complex): r = s; r /= w */
+         float _Complex z2 = cdiv_wide(z1, w);
+         float _Complex z3 = cdiv_wide(__builtin_complex(x0, 0.f), w);   /* operator/(T, complex): r = s; r /= w */
          float _Complex r = z2;  r += z3;
          float* o = y + s * yss + t * yts;
          o[0] = __real__ r;

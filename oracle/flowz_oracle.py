@@ -471,10 +471,11 @@ class FlowzOracle:
         return y
 
 
-def run_typed(orc, wires):
+def run_typed(orc, wires, T=None):
     """orc: a typed FlowzOracle; wires: per input wire an array [T, n_streams] in its own dtype (float32 / float64 /
-    complex64) -> per output wire an array [T, n_streams] in ITS dtype."""
-    T = np.shape(wires[0])[0] if wires else 0
+    complex64) -> per output wire an array [T, n_streams] in ITS dtype.  T: number of samples (needed without inputs)."""
+    if T is None:
+        T = np.shape(wires[0])[0] if wires else 0
     outs = None
     with np.errstate(all="ignore"):
         for t in range(T):

@@ -402,6 +402,94 @@ def test_config5_shard_equals_global_stream_ids(torch_cuda, F):
         assert torch.equal(ys.view(torch.int32), y[:, r * shard:(r + 1) * shard].contiguous().view(torch.int32))
 
 
+# ---- typed programs: ResultType through inputs, state and outputs ---------------------------------------
+def _typed_gpu(torch, F, prog, frames_host, variant=None, state=None, tile=0, stream_major=False):
+    x = torch.from_numpy(np.ascontiguousarray(frames_host)).cuda()
+    if stream_major:
+        y, st = prog.run_block_stream_major(x.permute(1, 0, 2).contiguous(), state=state, variant=variant)
+        return y.permute(1, 0, 2).contiguous().cpu().numpy(), st
+    if tile:
+        y, st = prog.run_block(F.to_tiled(x, tile), state=state, variant=variant)
+        return F.from_tiled(y).contiguous().cpu().numpy(), st
+    y, st = prog.run_block(x, state=state, variant=variant)
+    return y.cpu().numpy(), st
+
+
+@pytest.mark.parametrize("P", [0, 1, 2, 4])
+def test_typed_programs_complex_state_division_double_state(torch_cuda, F, P):
+    """fz_compile_typed on the GPU vs std::complex<float> compiled by g++ / compiled C with double state: the complex
+    one-pole ~(c*_1[_1] + _2) (complex delay line), z/w and s/w (__divsc3), the double accumulator of tests.cpp:223;
+    every lane packing, ragged stream counts, chained blocks, tiled and stream-major frames."""
+    torch = torch_cuda
+    ns, T = 776, 93
+    v = F.make_variant(P, 8) if P else None
+    x = O.synth_input(SEED + 61, np.arange(ns), T)
+    for g, want in ((G.complex_one_pole(), C.complex_one_pole(x, std=True)), (G.complex_div_mix(), C.complex_div_mix(x, std=True))):
+        prog = F.compile(F.from_sexpr(g), typed=True)
+        got, st = _typed_gpu(torch, F, prog, x, v)
+        assert ndiff(got, want) == 0
+        a, st1 = _typed_gpu(torch, F, prog, x[:40], v)                         # two blocks chained through the typed state
+        b, st2 = _typed_gpu(torch, F, prog, x[40:], v, state=st1)
+        assert ndiff(np.concatenate([a, b]), want) == 0 and torch.equal(st2, st)
+    prog = F.compile(F.from_sexpr(G.double_accumulator()), typed=True)
+    want = C.double_accumulator(x)[:, :, 0]
+    got, st = _typed_gpu(torch, F, prog, x, v)
+    assert np.array_equal(F.unpack_typed(got, ["f64"])[0], want)
+    assert np.array_equal(st.cpu().numpy().reshape(-1)[:2 * ns].view(np.float64), want[-1])      # state row 0 = ns doubles
+    a, st1 = _typed_gpu(torch, F, prog, x[:17], v)
+    b, _ = _typed_gpu(torch, F, prog, x[17:], v, state=st1)
+    assert np.array_equal(F.unpack_typed(np.concatenate([a, b]), ["f64"])[0], want)
+    if P in (0, 1):
+        for kw in ({"tile": 0, "stream_major": True},):
+            got, _ = _typed_gpu(torch, F, prog, x[:92], None, **kw)             # (stream-major rows: multiples of 4 floats)
+            assert np.array_equal(F.unpack_typed(got, ["f64"])[0], want[:92])
+    with pytest.raises(F.FlowzError):
+        prog.run_block(torch.zeros((4, 8, 1), device="cuda"), out_f64=True)    # FZ_VF_OUT_F64 does not apply to typed programs
+
+
+@pytest.mark.parametrize("P", [0, 1, 2, 4])
+def test_typed_programs_double_and_complex_input_frames(torch_cuda, F, P):
+    """double and std::complex<float> INPUT wires (the reference's callable is a template over its argument types,
+    flowz.hpp:1225-1229): frames carry them in two float slots; mixed float / double lines in the state; vs the typed oracle."""
+    torch = torch_cuda
+    ns, T = 512, 41
+    g = G.chan(G.chan(G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 2)), G.IN(2))),                        # double in -> double loop, depth 2
+                      G.add(G.mul(G.IN(2), G.litc(0.25, -0.5)), G.DEL(2, 3))),                      # complex in, its own delayed value
+               G.fb(G.add(G.mul(G.lit(0.75), G.DEL(1, 1)), G.mul(G.IN(4), G.IN(4)))))               # float in -> float loop
+    dts = ["f64", "cf32", "f32"]
+    prog = F.compile(F.from_sexpr(g), in_dtypes=dts)
+    assert prog.output_dtypes() == dts and prog.line_dtypes().count("f64") == 1 and (prog.n_in, prog.n_out) == (5, 5)
+    rng = np.random.default_rng(7)
+    w = [rng.standard_normal((T, ns)), (rng.standard_normal((T, ns)) + 1j * rng.standard_normal((T, ns))).astype(np.complex64),
+         rng.standard_normal((T, ns)).astype(np.float32)]
+    want = O.run_typed(O.compile(g, ns, typed=True, in_dtypes=dts), w)
+    fr = F.pack_typed(w, dts)
+    v = F.make_variant(P, 4) if P else None
+    got, st = _typed_gpu(torch, F, prog, fr, v)
+    for a, b in zip(F.unpack_typed(got, dts), want):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    got_t, st_t = _typed_gpu(torch, F, prog, fr, v, tile=128)
+    assert np.array_equal(got_t.view(np.uint32), got.view(np.uint32)) and torch.equal(st, st_t)
+    a, st1 = _typed_gpu(torch, F, prog, fr[:19], v)
+    b, st2 = _typed_gpu(torch, F, prog, fr[19:], v, state=st1)
+    assert np.array_equal(np.concatenate([a, b]).view(np.uint32), got.view(np.uint32)) and torch.equal(st2, st)
+
+
+@pytest.mark.parametrize("case", KA["result_types"], ids=lambda c: "tests.cpp:" + c["lines"])
+def test_typed_programs_tests_cpp_result_types_on_gpu(torch_cuda, F, case):
+    """test_result_type_transform (tests.cpp:184-232) evaluated on the GPU under fz_compile_typed: the output frames carry
+    exactly the types the reference asserts (tests.cpp:219 included) and the values of the typed oracle."""
+    g = tup(case["graph"])
+    prog = F.compile(F.from_sexpr(g), typed=True)
+    assert prog.output_dtypes() == case.get("result_type", case["types"])
+    ns, T = 70, 21
+    x = O.synth_input(SEED + 62, np.arange(ns), T, n_wires=max(prog.n_in, 1))
+    want = O.run_typed(O.compile(g, ns, typed=True), [x[:, :, i] for i in range(prog.n_in)], T=T)
+    got, _ = _typed_gpu(torch_cuda, F, prog, x)
+    for a, b in zip(F.unpack_typed(got, prog.output_dtypes()), want):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+
+
 # ---- stream-tiled frames (fz_run_block_tiled) ---------------------------------------------------------
 @pytest.mark.parametrize("P,tile", [(1, 256), (2, 512), (4, 1024), (0, 2048), (2, 1024)])
 def test_tiled_layout_equals_time_major(torch_cuda, F, P, tile):

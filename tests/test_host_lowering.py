@@ -12,6 +12,7 @@ import pytest
 import graphs as G
 import workloads as W
 from ir_interp import run_ir
+from oracle import coracle as C
 from oracle import flowz_oracle as O
 from zignal_amd import _capi, flowz as F
 
@@ -230,6 +231,13 @@ def test_stage_split_detection_and_packed_kernel_builds(tmp_path, monkeypatch):
 def test_output_dtypes_match_tests_cpp_result_types(case):
     p = F.compile(F.from_sexpr(tup(case["graph"])))
     assert p.output_dtypes() == case["types"]
+    # fz_compile_typed == ResultType itself (tests.cpp:219 included: the delayed read of a double wire is double)
+    pt = F.compile(F.from_sexpr(tup(case["graph"])), typed=True)
+    assert pt.output_dtypes() == case.get("result_type", case["types"]) and pt.typed == 1 and p.typed == 0
+    x = O.synth_input(9, np.arange(3), 12, n_wires=max(pt.n_in, 1))
+    want = O.run_typed(O.compile(tup(case["graph"]), 3, typed=True), [x[:, :, i] for i in range(pt.n_in)], T=12)
+    got = F.unpack_typed(run_ir(pt, x)[0], pt.output_dtypes())
+    assert all(a.dtype == b.dtype and np.array_equal(a, b) for a, b in zip(got, want))
 
 
 def test_complex_wires_lower_to_float_pairs():
@@ -246,7 +254,59 @@ def test_complex_wires_lower_to_float_pairs():
     assert q.output_dtypes() == ["cf32"] and q.n_out == 2
     for bad in (("mul", ("litc", 1.0, 0.0), ("lit64", 2.0)),
                 ("seq", ("mul", ("litc", 1.0, 0.0), ("in", 1)), ("del", 1, 1)),
-                ("fb", ("mul", ("litc", 1.0, 0.0), ("add", ("del", 1, 1), ("in", 2)))),
-                ("div", ("in", 1), ("litc", 1.0, 1.0))):
+                ("fb", ("mul", ("litc", 1.0, 0.0), ("add", ("del", 1, 1), ("in", 2))))):
         with pytest.raises(F.FlowzError):
             F.compile(F.from_sexpr(bad))
+
+
+def test_typed_programs_lowering_vs_oracle_and_std_complex():
+    """fz_compile_typed: complex and double STATE, complex division (both spellings of __divsc3), double
+    and complex INPUT wires -- lowered IR (test interpreter) == typed Python oracle == std::complex<float> compiled by g++."""
+    x = O.synth_input(5, np.arange(7), 60)
+    for g, want in ((G.complex_one_pole(), C.complex_one_pole(x, std=True)), (G.complex_div_mix(), C.complex_div_mix(x, std=True))):
+        p = F.compile(F.from_sexpr(g), typed=True)
+        assert p.output_dtypes() == ["cf32"] and p.n_out == 2 and p.info.n_out_wires == 1
+        assert np.array_equal(run_ir(p, x)[0].view(np.uint32), want.view(np.uint32))
+        y = O.run_typed(O.compile(g, 7, typed=True), [x[:, :, 0]])[0]
+        assert np.array_equal(np.stack([y.real, y.imag], -1).view(np.uint32), want.view(np.uint32))
+    p = F.compile(F.from_sexpr(G.complex_one_pole()), typed=True)
+    assert p.line_dtypes() == ["re", "im"] and p.n_state == 2
+    # untyped division works too (no state involved); complex state does not
+    assert np.array_equal(run_ir(F.compile(F.from_sexpr(G.complex_div_mix())), x)[0].view(np.uint32), C.complex_div_mix(x, std=True).view(np.uint32))
+    with pytest.raises(F.FlowzError):
+        F.compile(F.from_sexpr(G.complex_one_pole()))
+    # double state: the accumulator of tests.cpp:223 is a double; two float rows per slot, double lines first
+    p = F.compile(F.from_sexpr(G.double_accumulator()), typed=True)
+    assert p.line_dtypes() == ["f64"] and p.n_state == 2 and p.output_dtypes() == ["f64"] and p.n_out == 2
+    y, st = run_ir(p, x)
+    want = C.double_accumulator(x)
+    assert np.array_equal(F.unpack_typed(y, ["f64"])[0], want[:, :, 0])
+    assert np.array_equal(st.reshape(-1)[:14].view(np.float64), want[-1, :, 0])          # the state row IS the accumulator
+    # the same graph under compile(): float state, double arithmetic above it (different values!)
+    assert not np.array_equal(run_ir(F.compile(F.from_sexpr(G.double_accumulator())), x)[0][:, :, 0].astype(np.float64), want[:, :, 0])
+    # mixed: a float line next to a double line -- double lines come first in the state layout
+    g = G.chan(G.fb(G.add(G.DEL(1, 2), G.IN(2))), G.fb(G.add(G.DEL(1, 1), G.mul(G.lit64(0.5), G.IN(2)))))
+    p = F.compile(F.from_sexpr(g), typed=True)
+    assert p.line_dtypes() == ["f64", "f32"] and p.n_state == 4 and p.output_dtypes() == ["f32", "f64"]
+    got = F.unpack_typed(run_ir(p, x)[0], p.output_dtypes())
+    want = O.run_typed(O.compile(g, 7, typed=True), [x[:, :, 0]])
+    assert all(a.dtype == b.dtype and np.array_equal(a, b) for a, b in zip(got, want))
+    # typed INPUT wires (the reference's callable is a template over its argument types): double, complex, float
+    g = G.chan(G.chan(G.mul(G.IN(1), G.lit(0.5)), G.add(G.IN(2), G.DEL(2, 1))), G.mul(G.IN(3), G.IN(3)))
+    dts = ["f64", "cf32", "f32"]
+    p = F.compile(F.from_sexpr(g), in_dtypes=dts)
+    assert (p.n_in, p.n_in_wires, p.input_dtypes(), p.output_dtypes()) == (5, 3, dts, dts)
+    rng = np.random.default_rng(1)
+    w = [rng.standard_normal((20, 3)), (rng.standard_normal((20, 3)) + 1j * rng.standard_normal((20, 3))).astype(np.complex64),
+         rng.standard_normal((20, 3)).astype(np.float32)]
+    got = F.unpack_typed(run_ir(p, F.pack_typed(w, dts))[0], p.output_dtypes())
+    want = O.run_typed(O.compile(g, 3, typed=True, in_dtypes=dts), w)
+    assert all(a.dtype == b.dtype and np.array_equal(a, b) for a, b in zip(got, want))
+    # what C++ would not compile / this build does not offer
+    for bad, kw in ((("fb", ("add", ("mul", ("litc", 1.0, 0.0), ("del", 1, 1)), ("mul", ("lit64", 1.0), ("in", 2)))), {}),   # complex meets double
+                    (("add", ("in", 1), ("lit64", 1.0)), {"in_dtypes": ["cf32"]}),
+                    (("fb", ("add", ("del", 1, 9), ("mul", ("lit64", 1.0), ("in", 2)))), {})):                               # double line deeper than 8
+        with pytest.raises(F.FlowzError):
+            F.compile(F.from_sexpr(bad), typed=True, **kw)
+    with pytest.raises(F.FlowzError):
+        F.compile(F.from_sexpr(G.df1()), in_dtypes=["f32", "f32"])                   # one dtype per input wire

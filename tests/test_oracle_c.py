@@ -124,8 +124,23 @@ def test_complex_wires_three_spellings_agree():
         O.compile(("mul", ("litc", 1.0, 0.0), ("lit64", 2.0)))                    # complex<float> * double
     with pytest.raises(O.GraphError):
         O.compile(("seq", ("mul", ("litc", 1.0, 0.0), ("in", 1)), ("del", 1, 1)))  # float delay line
+
+
+def test_typed_state_and_complex_division_three_spellings_agree():
+    """complex STATE (~(c*_1[_1] + _2)), both spellings of the complex division (z/w, s/w = libgcc's
+    __divsc3 as g++ links it: float handled with double precision) and a double accumulator -- the typed Python oracle,
+    the C restatement and std::complex<float> compiled by g++ are bit-identical."""
+    x = O.synth_input(78, np.arange(129), 200)
+    for g, cf in ((G.complex_one_pole(), C.complex_one_pole), (G.complex_div_mix(), C.complex_div_mix)):
+        want = cf(x, std=True)
+        assert same(cf(x), want) and np.isfinite(want).all() and (want[..., 1] != 0).any()
+        assert O.output_dtypes_typed(g) == ["cf32"]
+        y = O.run_typed(O.compile(g, 129, typed=True), [x[:, :, 0]])[0]
+        assert y.dtype == np.complex64 and same(np.stack([y.real, y.imag], -1), want)
+    y = O.run_typed(O.compile(G.double_accumulator(), 129, typed=True), [x[:, :, 0]])[0]
+    assert y.dtype == np.float64 and np.array_equal(y, C.double_accumulator(x)[:, :, 0])
     with pytest.raises(O.GraphError):
-        O.compile(("div", ("in", 1), ("litc", 1.0, 1.0)))
+        O.compile(G.complex_one_pole())                                           # compile(): float state (flowz.hpp:1245)
 
 
 def test_rbj_lowpass_oracle_matches_reference_spelling_within_1ulp():

@@ -110,3 +110,5 @@ def test_synth_input_range_and_determinism():
 def test_result_types_float_double(case):
     """test_result_type_transform (tests.cpp:184-232), float/double cases: the oracle's evaluated types"""
     assert O.output_dtypes(tup(case["graph"])) == case["types"]
+    # ... and with typed state (what ResultType itself computes, incl. tests.cpp:219 where a double goes THROUGH a delay line)
+    assert O.output_dtypes_typed(tup(case["graph"])) == case.get("result_type", case["types"])

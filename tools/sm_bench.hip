@@ -15,8 +15,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 // R floats per stream and chunk, D chunks in flight (register buffers), BLOCK threads, SW streams per wave
 template <int R, int D, int BLOCK, int SW>
-__global__ void __launch_bounds__(BLOCK) k_sm(const float* __restrict__ src, float* __restrict__ dst, unsigned n_streams, unsigned T)
+__global__ void __launch_bounds__(BLOCK) k_sm(const float* __restrict__ src, float* __restrict__ dst, unsigned n_streams, unsigned T, int dshift = 0)
 {
+   dst += dshift;                            // write runs start `dshift` floats off the run boundary (dshift = 8: 32 B)
    constexpr int PP = R / 4;                 // float4 pieces per stream and chunk
    constexpr int NP = SW * PP / 64;          // pieces per lane and chunk
    unsigned blk = blockIdx.x;
@@ -229,6 +230,8 @@ int main(int argc, char** argv)
    ONE(32, 256, false) ONE(128, 256, false) ONE(32, 256, true) ONE(128, 256, true)
    cases.push_back({"128 B pieces, no touch (baseline of the next line)", [&] { k_sm_touch<256, false><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T); }, {}});
    cases.push_back({"128 B pieces + 512 B run touched one run ahead", [&] { k_sm_touch<256, true><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T); }, {}});
+   cases.push_back({"stream-major R=128 (512 B runs), WRITE runs shifted by 32 B (T-128: rate shown is 3 % high)", [&] { k_sm<128, 2, 256, 64><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T - 128, 8); }, {}});
+   cases.push_back({"stream-major R=128 (512 B runs), blk=64", [&] { k_sm<128, 2, 64, 64><<<dim3(ns / 64), dim3(64)>>>(s, d, ns, T); }, {}});
    const size_t row = ns;
    cases.push_back({"frames tiled 8192 W=1 U=16", [&] { k_walk<1, 16, 256><<<dim3((row + 255) / 256), dim3(256)>>>(s, d, row, 8192, 8192, (size_t)8192 * T, T); }, {}});
    cases.push_back({"frames tiled 8192 W=2 U=16", [&] { k_walk<2, 16, 256><<<dim3((row / 2 + 255) / 256), dim3(256)>>>(s, d, row / 2, 4096, 8192, (size_t)8192 * T, T); }, {}});

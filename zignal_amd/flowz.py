@@ -212,7 +212,7 @@ class Program:
             # ResultType semantics (flowz.hpp:585-644): wire types carried through inputs, state and outputs
             n = self.expr.ins
             dts = list(in_dtypes) if in_dtypes is not None else ["f32"] * n
-            arr = (ctypes.c_uint32 * max(n, 1))(*[C.DTYPES[d] for d in dts])
+            arr = (ctypes.c_uint32 * max(len(dts), 1))(*[C.DTYPES[d] for d in dts])
             C.check(C.lib.fz_compile_typed(self.expr._h, arr, len(dts), ctypes.byref(h)))
         else:
             C.check(C.lib.fz_compile(self.expr._h, ctypes.byref(h)))
@@ -257,6 +257,13 @@ class Program:
         buf = (ctypes.c_uint32 * max(self.n_out, 1))()
         C.check(C.lib.fz_program_output_dtypes(self._h, buf, self.n_out))
         return [("f32", "f64", "cf32", None, "f64")[buf[i]] for i in range(self.n_out) if buf[i] not in (3, 5)]
+
+    def output_slot_codes(self):
+        """raw per-slot codes of fz_program_output_dtypes: 0 float, 1 double (narrowed to the float frame), 2 / 3 re / im
+        of a complex wire, 4 / 5 low / high word of a double wire (typed programs)"""
+        buf = (ctypes.c_uint32 * max(self.n_out, 1))()
+        C.check(C.lib.fz_program_output_dtypes(self._h, buf, self.n_out))
+        return [buf[i] for i in range(self.n_out)]
 
     def input_dtypes(self):
         """'f32' / 'f64' / 'cf32' per input WIRE (typed programs; all 'f32' otherwise)"""
