@@ -204,6 +204,10 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
        FZ_VF_PREFETCH3 = 32u,   /* three input chunk buffers: loads run two chunks (2 x unroll steps) ahead
                                    (not with delay lines beyond 256 samples)                              */
        FZ_VF_STREAM_MAJOR = 128u,   /* set by fz_run_block_stream_major (the frame layout is part of the kernel) */
+       FZ_VF_SM_LONG = 256u,    /* stream-major frames, 1-in/1-out graphs: the long-run body -- 512-byte runs per stream (unroll 128;
+                                   64 selectable), one in-place LDS patch per wave, one wave per SIMD; chosen automatically for
+                                   blocks of >= 256 samples; FZ_VF_SM_SHORT keeps the 32-sample chunks                          */
+       FZ_VF_SM_SHORT = 512u,
        FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
                                    float*): the results of graphs with double literals leave un-narrowed, float
                                    wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */

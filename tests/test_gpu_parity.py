@@ -469,10 +469,11 @@ def test_typed_programs_double_and_complex_input_frames(torch_cuda, F, P):
     for a, b in zip(F.unpack_typed(got, dts), want):
         assert a.dtype == b.dtype and np.array_equal(a, b)
     got_t, st_t = _typed_gpu(torch, F, prog, fr, v, tile=128)
-    assert np.array_equal(got_t.view(np.uint32), got.view(np.uint32)) and torch.equal(st, st_t)
+    # (state rows of double lines hold double words: compare bit patterns, a float32 view may read as NaN)
+    assert np.array_equal(got_t.view(np.uint32), got.view(np.uint32)) and torch.equal(st.view(torch.int32), st_t.view(torch.int32))
     a, st1 = _typed_gpu(torch, F, prog, fr[:19], v)
     b, st2 = _typed_gpu(torch, F, prog, fr[19:], v, state=st1)
-    assert np.array_equal(np.concatenate([a, b]).view(np.uint32), got.view(np.uint32)) and torch.equal(st2, st)
+    assert np.array_equal(np.concatenate([a, b]).view(np.uint32), got.view(np.uint32)) and torch.equal(st2.view(torch.int32), st.view(torch.int32))
 
 
 @pytest.mark.parametrize("case", KA["result_types"], ids=lambda c: "tests.cpp:" + c["lines"])
@@ -1091,6 +1092,67 @@ def test_stream_major_stage_packing_is_automatic_for_long_blocks(torch_cuda, F):
     assert ndiff(y.permute(1, 0, 2).contiguous().cpu().numpy(), C.osc_chain(P, x)) == 0
     _, st_ref = prog.run_block(torch.from_numpy(x).cuda(), params=torch.from_numpy(P).cuda(), variant=F.make_variant(2, 8))
     assert torch.equal(st[:, :ns - 1], st_ref[:, :ns - 1]) and torch.equal(st, st_ref)
+
+
+SM_LONG, SM_SHORT = 256, 512
+LONG_GRAPHS = {"cascade6": lambda: G.df1_cascade(6), "cascade7_prefix_plus_6": PACKABLE["cascade7_prefix_plus_6"],
+               "cascade4_smoothing_one_pole": PACKABLE["cascade4_smoothing_one_pole"], "df2_pair": PACKABLE["df2_pair"],
+               "cascade12_two_stages_per_segment": PACKABLE["cascade12_two_stages_per_segment"],
+               "df1": G.df1, "df2t": G.df2t, "integrator": G.integrator,
+               "depth8_fir": lambda: G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 8)))}
+
+
+@pytest.mark.parametrize("name", sorted(LONG_GRAPHS))
+def test_stream_major_long_run_kernel_vs_oracle(torch_cuda, F, name):
+    """The long-run body of the stream-major kernel (FZ_VF_SM_LONG: 512-byte runs per stream, in-place LDS patch, outputs
+    taken 4 / 8 samples back in time under stage packing): automatic from 256 samples on, phases of 128 and 64 samples,
+    ragged tails and stream counts, windows, chains with the short-chunk body -- vs the oracle, 0 ULP, canonical state."""
+    torch = torch_cuda
+    g = LONG_GRAPHS[name]()
+    prog = F.compile(F.from_sexpr(g))
+    for ns, T in ((333, 256), (64, 388), (1, 520), (777, 300)):
+        x = O.synth_input(SEED + 98, np.arange(ns), T)
+        want = O.compile(g, ns).run(x)
+        xs = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))).cuda()
+        assert prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, T).endswith(("f384", "f392"))      # 128 | 256 [| 8]: long-run body
+        y, st = prog.run_block_stream_major(xs)                              # automatic: the long-run body
+        assert ndiff(y.permute(1, 0, 2).contiguous().cpu().numpy(), want) == 0, (ns, T)
+        _, st_ref = prog.run_block(torch.from_numpy(x).cuda(), variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+        assert torch.equal(st, st_ref), (ns, T)
+        for v in (F.make_variant(1, 64, 0, SM_LONG), F.make_variant(1, 128, 0, SM_LONG | NO_STAGE_PACK), F.make_variant(1, 0, 64, SM_LONG)):
+            yv, stv = prog.run_block_stream_major(xs, variant=v)
+            assert torch.equal(yv, y) and torch.equal(stv, st), (ns, T, v.unroll, v.flags)
+        # windows: long body, then the short-chunk body continues (and the other way round); row0 multiples of 4
+        out = torch.zeros_like(y)
+        cut = 132 if T > 260 else 128
+        _, st2 = prog.run_block_stream_major(xs, out=out, n_samples=cut, variant=F.make_variant(1, 64, 0, SM_LONG))
+        prog.run_block_stream_major(xs, out=out, state=st2, row0=cut, variant=F.make_variant(0, 0, 0, SM_SHORT))
+        assert torch.equal(out, y), (ns, T)
+        out.zero_()
+        _, st2 = prog.run_block_stream_major(xs, out=out, n_samples=20, variant=F.make_variant(0, 0, 0, SM_SHORT))
+        prog.run_block_stream_major(xs, out=out, state=st2, row0=20)
+        assert torch.equal(out, y), (ns, T)
+
+
+def test_stream_major_long_run_osc_chain_per_stream_coefficients_64k(torch_cuda, F):
+    """resonator -> 6 DF1 with 31 per-stream coefficients (scalar prefix + 6 packed segments) through the long-run body at
+    a size where every SIMD has a wave; the full output against the frame kernel, sampled streams against the C oracle."""
+    torch = torch_cuda
+    ns, T = 65536 + 64, 1024
+    prog = F.compile(F.from_sexpr(G.osc_chain(6)))
+    P = W.osc_chain_params(SEED + 3, np.arange(ns))
+    pd = torch.from_numpy(P).cuda()
+    x = torch.zeros((T, ns, 1), dtype=torch.float32, device="cuda")
+    x[0] = 1.0
+    x[500] = -0.25
+    yf, stf = prog.run_block(x, params=pd)
+    ys, sts = prog.run_block_stream_major(x.permute(1, 0, 2).contiguous(), params=pd)
+    assert prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, T).endswith("s6f392")
+    assert torch.equal(ys.permute(1, 0, 2).contiguous(), yf) and torch.equal(sts, stf)
+    ids = _sample_ids(ns, 256, 5)
+    xh = np.zeros((T, len(ids), 1), np.float32)
+    xh[0], xh[500] = 1.0, -0.25
+    assert ndiff(yf[:, torch.from_numpy(ids).cuda()].cpu().numpy(), C.osc_chain(np.ascontiguousarray(P[:, ids]), xh)) == 0
 
 
 def test_stream_major_kernel_rejects_what_it_cannot_do(torch_cuda, F):

@@ -25,7 +25,7 @@ def timed(fn, reps=5):
 
 
 graphs = {"cascade6": lambda: G.df1_cascade(6), "cascade2": lambda: G.df1_cascade(2), "df1": G.df1, "par4": G.par4_sum}
-for name, ns, T in (("cascade6", 1 << 20, 1024), ("cascade2", 1 << 20, 1024), ("df1", 1 << 20, 1024), ("par4", 1 << 18, 1024),
+for name, ns, T in (("cascade6", 1 << 20, 4096), ("cascade6", 1 << 20, 1024), ("cascade2", 1 << 20, 1024), ("df1", 1 << 20, 1024), ("par4", 1 << 18, 1024),
                     ("cascade6", 65536, 4096)):
     prog = F.compile(F.from_sexpr(graphs[name]()))
     w = max(prog.n_in, 1)
@@ -37,9 +37,9 @@ for name, ns, T in (("cascade6", 1 << 20, 1024), ("cascade2", 1 << 20, 1024), ("
     yf = torch.empty((ns // tile, T, tile, prog.n_out), device="cuda") if tile < ns else torch.empty((T, ns, prog.n_out), device="cuda")
     b = ns * T * 4 * (prog.n_in + prog.n_out)
     res = {}
-    for P, U in ((0, 0), (1, 32), (2, 32), (2, 16), (1, 16)):
-        v = F.make_variant(P, U) if (P or U) else None
-        label = f"stream-major kernel {'auto' if not (P or U) else f'P={P} U={U}'}"
+    for P, U, fl in ((0, 0, 0), (1, 128, 256), (1, 64, 256), (1, 128, 256 | 16), (0, 0, 512), (1, 32, 16), (2, 32, 0)):
+        v = F.make_variant(P, U, 0, fl) if (P or U or fl) else None
+        label = f"stream-major kernel {'auto' if v is None else f'P={P} U={U} flags={fl}'}"
         try:
             res[label] = timed(lambda: prog.run_block_stream_major(x, state=st, out=out, variant=v))
         except F.FlowzError:

@@ -250,7 +250,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    if (reqP != 0 && reqP != 1 && reqP != 2 && reqP != 4) fail(FZ_E_INVALID, "streams_per_lane must be 0, 1, 2 or 4");
    if (g.typed && (v.flags & FZ_VF_OUT_F64))
       fail(FZ_E_INVALID, "FZ_VF_OUT_F64 does not apply to fz_compile_typed programs: their frames carry every wire in its own type");
-   if (reqU > 32) fail(FZ_E_INVALID, "unroll must be <= 32");
+   if (reqU > 32 && !((v.flags & FZ_VF_SM_LONG) && (reqU == 64 || reqU == 128))) fail(FZ_E_INVALID, "unroll must be <= 32");
    if (reqB != 0 && (reqB % 64 != 0 || reqB > 1024)) fail(FZ_E_INVALID, "block_threads must be a multiple of 64, <= 1024");
    if (reqP) {
       if (n_streams % reqP) fail(FZ_E_INVALID, "n_streams must be a multiple of streams_per_lane");
@@ -308,6 +308,25 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       if (v.P != 1 || !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
       else if (!(uv && (uv->flags & FZ_VF_NO_STAGE_PACK)) && n_samples >= 32u * (g.split.K - 1)) v.flags |= FZ_VF_STAGE_PACK;
       const uint32_t nw = std::max<uint32_t>(std::max(g.n_in, g.n_out), 1);
+      // long-run body (512-byte runs per stream): 1-in/1-out graphs with register-resident state, blocks of at least two phases
+      const bool long_ok = g.n_in == 1 && g.n_out == 1 && v.P == 1 && g.n_lds_slots == 0 && (!g.split.ok || g.split.K <= 8);
+      const bool want_short = uv && (uv->flags & FZ_VF_SM_SHORT);
+      v.flags &= ~(uint32_t)FZ_VF_SM_SHORT;
+      if (v.flags & FZ_VF_SM_LONG) {
+         if (!long_ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: needs a 1-in/1-out graph, one stream per lane, no delay lines beyond 8 samples");
+         if (reqU && reqU != 64 && reqU != 128) fail(FZ_E_INVALID, "FZ_VF_SM_LONG: unroll must be 64 or 128");
+      } else if (long_ok && !want_short && !reqU && n_samples >= 256) {
+         v.flags |= FZ_VF_SM_LONG;
+      }
+      if (v.flags & FZ_VF_SM_LONG) {
+         v.U = reqU ? reqU : 128;
+         // stage packing rides along when the block is long enough for the masked ends not to matter
+         if ((v.flags & FZ_VF_STAGE_PACK) && !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
+         auto lds_long = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (w.U + 12) * 4; };
+         while (lds_long(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
+         if (lds_long(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: the LDS patches do not fit this block size");
+         return v;
+      }
       auto lds = [&](const Variant& w) { return (uint64_t)w.block * w.P * (w.U * nw + 4) * 4 + (uint64_t)g.n_lds_slots * w.block * 4 * w.P; };
       if (!reqU) {
          // the longer the run of one stream inside a chunk the better it streams (measured: 128 B per
@@ -358,6 +377,8 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    const bool stream_major = uv && (uv->flags & FZ_VF_STREAM_MAJOR);
    if (stream_major) {
       if (tile_streams) fail(FZ_E_INVALID, "stream-major frames are not tiled");
+      if ((uint64_t)rows_total * std::max(p->g.n_in, p->g.n_out) >= (1ull << 24))
+         fail(FZ_E_UNSUPPORTED, "stream-major frames: more than 2^24 floats per stream buffer (a wave's 64 rows are addressed through one 4 GiB descriptor): use a window");
       if (((uint64_t)rows_total * p->g.n_in) % 4 || ((uint64_t)row0 * p->g.n_in) % 4 || ((uint64_t)rows_total * p->g.n_out) % 4 ||
           ((uint64_t)row0 * p->g.n_out) % 4)
          fail(FZ_E_INVALID, "stream-major frames: rows_total and row0 times the wires per frame must be multiples of 4 floats");
