@@ -288,6 +288,13 @@ uint32_t fz_recommended_tile_streams(const fz_program* p);
 int fz_program_tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
                     uint32_t n_samples, uint32_t tile_streams, void* hip_stream, fz_variant* chosen, float* chosen_ms);
 
+/* The winner is also PERSISTED: a line in <kernel cache dir>/plans.txt keyed by (graph structure -- coefficient values do
+ * not matter --, n_streams, tile_streams, the board's UUID); the first launch of that shape without a variant in a later
+ * process picks it up, so callers that tuned once never sit on the library default again.  FLOWZ_HIP_NO_PLAN_CACHE=1
+ * disables reading and writing.  fz_program_plan: the variant such a launch would use now on the current device
+ * ({0,0,0,0} = library default).                                                                                  */
+int fz_program_plan(fz_program* p, uint64_t n_streams, uint32_t tile_streams, fz_variant* out);
+
 /* the variants fz_program_tune would measure for this shape (the first entry is the library default {0,0,0,0});
  * writes min(n, cap) entries, returns n.  Pure host work: lets a build step pre-compile them (fz_program_build). */
 int fz_program_tune_candidates(fz_program* p, uint64_t n_streams, uint32_t n_samples, fz_variant* out, uint32_t cap);

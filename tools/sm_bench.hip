@@ -55,6 +55,48 @@ __global__ void __launch_bounds__(BLOCK) k_sm(const float* __restrict__ src, flo
    }
 }
 
+// k_sm with the occupancy of the long-run kernel body: a 140 KB LDS allocation lets ONE block (4 waves) live on a CU
+template <int R, int D, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_sm_occ(const float* __restrict__ src, float* __restrict__ dst, unsigned n_streams, unsigned T, int dshift)
+{
+   __shared__ float pad[35840];
+   if (T == 0xFFFFFFFFu) { pad[threadIdx.x] = 1.f; __syncthreads(); dst[threadIdx.x] = pad[(threadIdx.x * 7 + 1) % 35840]; }
+   dst += dshift;
+   constexpr int PP = R / 4, NP = 64 * PP / 64;
+   unsigned blk = blockIdx.x;
+   {
+      const unsigned nb = gridDim.x, xcd = blk & 7u, idx = blk >> 3, q = nb >> 3, r = nb & 7u;
+      blk = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+   }
+   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+   const size_t s_base = ((size_t)blk * (BLOCK / 64) + wave) * 64;
+   if (s_base >= n_streams) return;
+   const unsigned nch = T / R;
+   f4 buf[D][NP];
+   size_t off[NP];
+#pragma unroll
+   for (int i = 0; i < NP; ++i) {
+      const unsigned e = i * 64 + lane, sl = e / PP, q = e - sl * PP;
+      off[i] = (s_base + sl) * (size_t)T + q * 4;
+   }
+#pragma unroll
+   for (int d = 0; d < D - 1; ++d)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) buf[d][i] = __builtin_nontemporal_load((const f4*)(src + off[i] + (size_t)d * R));
+   for (unsigned c = 0; c < nch; c += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+         const unsigned cc = c + d;
+         if (cc + D - 1 < nch)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) buf[(d + D - 1) % D][i] = __builtin_nontemporal_load((const f4*)(src + off[i] + (size_t)(cc + D - 1) * R));
+         if (cc < nch)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) __builtin_nontemporal_store(buf[d][i], (f4*)(dst + off[i] + (size_t)cc * R));
+      }
+   }
+}
+
 // frames with the stream index fastest, tiled (the frame kernel's pattern): lane owns W floats
 template <int W, int U, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_walk(const float* __restrict__ s, float* __restrict__ d, size_t n_lanes,
@@ -232,6 +274,15 @@ int main(int argc, char** argv)
    cases.push_back({"128 B pieces + 512 B run touched one run ahead", [&] { k_sm_touch<256, true><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T); }, {}});
    cases.push_back({"stream-major R=128 (512 B runs), WRITE runs shifted by 32 B (T-128: rate shown is 3 % high)", [&] { k_sm<128, 2, 256, 64><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T - 128, 8); }, {}});
    cases.push_back({"stream-major R=128 (512 B runs), blk=64", [&] { k_sm<128, 2, 64, 64><<<dim3(ns / 64), dim3(64)>>>(s, d, ns, T); }, {}});
+   cases.push_back({"R=128 (512 B runs) D=2, ONE block of 4 waves per CU (140 KB LDS)", [&] { k_sm_occ<128, 2, 256><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T, 0); }, {}});
+   cases.push_back({"R=128 (512 B runs) D=2, ONE block per CU, write runs shifted by 128 B (whole line; T-128: 3 % high)", [&] { k_sm_occ<128, 2, 256><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T - 128, 32); }, {}});
+   cases.push_back({"R=32 (128 B runs) D=2, ONE block per CU", [&] { k_sm_occ<32, 2, 256><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T, 0); }, {}});
+   cases.push_back({"R=128 (512 B runs), write runs shifted by 128 B (whole line; T-128: 3 % high)", [&] { k_sm<128, 2, 256, 64><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T - 128, 32); }, {}});
+   cases.push_back({"R=128 (512 B runs), write runs shifted by 64 B (T-128: 3 % high)", [&] { k_sm<128, 2, 256, 64><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T - 128, 16); }, {}});
+   cases.push_back({"R=128 (512 B runs), READ runs shifted by 32 B, writes aligned (T-128: 3 % high)", [&] { k_sm<128, 2, 256, 64><<<dim3(ns / 256), dim3(256)>>>(s + 8, d, ns, T - 128, 0); }, {}});
+   cases.push_back({"R=128 (512 B runs), READ runs shifted by 16 B, writes aligned (T-128: 3 % high)", [&] { k_sm<128, 2, 256, 64><<<dim3(ns / 256), dim3(256)>>>(s + 4, d, ns, T - 128, 0); }, {}});
+   cases.push_back({"R=128, ONE block per CU, READ runs shifted by 32 B (T-128: 3 % high)", [&] { k_sm_occ<128, 2, 256><<<dim3(ns / 256), dim3(256)>>>(s + 8, d, ns, T - 128, 0); }, {}});
+   cases.push_back({"R=128 aligned, T-128 (reference for the shifted lines: 3 % high)", [&] { k_sm<128, 2, 256, 64><<<dim3(ns / 256), dim3(256)>>>(s, d, ns, T - 128, 0); }, {}});
    const size_t row = ns;
    cases.push_back({"frames tiled 8192 W=1 U=16", [&] { k_walk<1, 16, 256><<<dim3((row + 255) / 256), dim3(256)>>>(s, d, row, 8192, 8192, (size_t)8192 * T, T); }, {}});
    cases.push_back({"frames tiled 8192 W=2 U=16", [&] { k_walk<2, 16, 256><<<dim3((row / 2 + 255) / 256), dim3(256)>>>(s, d, row / 2, 4096, 8192, (size_t)8192 * T, T); }, {}});

@@ -105,6 +105,7 @@ def _load():
         "fz_bank_process_stream_major": (ctypes.c_int, [P, P, P, u32, u32, u32, ctypes.POINTER(Variant), P]),
         "fz_bank_process_blocks": (ctypes.c_int, [P, P, P, u32, u32, P, u32, ctypes.POINTER(Variant), P]),
         "fz_program_tune": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, P, ctypes.POINTER(Variant), ctypes.POINTER(f32)]),
+        "fz_program_plan": (ctypes.c_int, [P, u64, u32, ctypes.POINTER(Variant)]),
         "fz_program_tune_candidates": (ctypes.c_int, [P, u64, u32, ctypes.POINTER(Variant), u32]),
         "fz_recommended_tile_streams": (u32, [P]),
         "fz_bank_create": (ctypes.c_int, [P, u64, ctypes.POINTER(P)]),

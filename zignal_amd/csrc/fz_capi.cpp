@@ -22,6 +22,7 @@ int fz_compile(const fz_expr* e, fz_program** out)
       auto* p = new fz_program();
       try {
          p->g = lower(e);
+         p->graph_hash = graph_structure_hash(p->g);
       } catch (...) {
          delete p;
          throw;
@@ -44,6 +45,7 @@ int fz_compile_typed(const fz_expr* e, const uint32_t* in_dtypes, uint32_t n_in_
       }
       std::unique_ptr<fz_program> p(new fz_program());
       p->g = lower(e, opt);
+      p->graph_hash = graph_structure_hash(p->g);
       *out = p.release();
       return FZ_OK;)
 }
@@ -264,6 +266,15 @@ int fz_program_tune(fz_program* p, const float* in, float* out, float* state, co
    FZ_GUARD(
       if (!p) fail(FZ_E_INVALID, "null program");
       return tune(p, in, out, state, params, n_streams, n_samples, tile_streams, hip_stream, chosen, chosen_ms);)
+}
+
+int fz_program_plan(fz_program* p, uint64_t n_streams, uint32_t tile_streams, fz_variant* out)
+{
+   FZ_GUARD(
+      if (!p || !out || !n_streams) fail(FZ_E_INVALID, "fz_program_plan: bad arguments");
+      if (device_count() <= 0) fail(FZ_E_NO_DEVICE, "fz_program_plan: plans are per board; no HIP device visible");
+      *out = planned_variant(p, n_streams, tile_streams);
+      return FZ_OK;)
 }
 
 int fz_program_tune_candidates(fz_program* p, uint64_t n_streams, uint32_t n_samples, fz_variant* out, uint32_t cap)

@@ -170,6 +170,8 @@ struct fz_program {
    // caller passes none
    std::map<std::tuple<uint64_t, uint32_t, int>, fz_variant> plans;
    std::set<std::tuple<uint64_t, uint32_t, int>> tuned_default;   // shapes measured already (FLOWZ_HIP_AUTOTUNE)
+   std::set<std::tuple<uint64_t, uint32_t, int>> plan_looked_up;  // shapes whose persisted plan (plans.txt of the kernel cache) was consulted
+   uint64_t graph_hash = 0;                                        // structure of the lowered graph (no coefficient values)
 };
 
 namespace fz {
@@ -184,4 +186,7 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
          uint32_t n_samples, uint32_t tile_streams, void* stream, fz_variant* chosen, float* chosen_ms);
 std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint32_t n_samples);
 int device_count();
+uint64_t graph_structure_hash(const Graph& g);
+// the plan a launch without a variant would use for this shape on the current device: in memory, else persisted, else {0,0,0,0}
+fz_variant planned_variant(fz_program* p, uint64_t n_streams, uint32_t tile_streams);
 }  // namespace fz

@@ -354,6 +354,96 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    return v;
 }
 
+// ---- persisted plans ---------------------------------------------------------------------------------------------
+// fz_program_tune's winner is remembered across processes: <kernel cache>/plans.txt, one line per
+// (graph structure, n_streams, tile_streams, board) -- the board by its UUID, because the winner differs from board to
+// board.  A launch without a variant consults it once per shape.  FLOWZ_HIP_NO_PLAN_CACHE=1 turns it off.
+uint64_t graph_structure_hash(const Graph& g)
+{
+   std::ostringstream o;
+   o << g.n_in << ' ' << g.n_out << ' ' << g.n_param << ' ' << (g.typed ? 1 : 0) << '|';
+   for (const Node& n : g.nodes) o << n.kind << ',' << n.a << ',' << n.b << ',' << (n.f64 ? 1 : 0) << ';';
+   o << '|';
+   for (uint32_t v : g.outputs) o << v << ',';
+   o << '|';
+   for (const Line& l : g.lines) o << l.src << ':' << l.depth << ':' << (l.f64 ? 1 : 0) << ',';
+   return fnv1a(o.str());
+}
+
+static std::string board_id()
+{
+   int dev = 0;
+   if (hipGetDevice(&dev) != hipSuccess) return "";
+   hipUUID uuid;
+   if (hipDeviceGetUuid(&uuid, dev) == hipSuccess) {
+      char buf[40];
+      for (int i = 0; i < 16; ++i) std::snprintf(buf + 2 * i, 3, "%02x", (unsigned)(unsigned char)uuid.bytes[i]);
+      return buf;
+   }
+   (void)hipGetLastError();
+   return "dev" + std::to_string(dev);
+}
+
+static bool plan_cache_on() { return !std::getenv("FLOWZ_HIP_NO_PLAN_CACHE") && !std::getenv("FLOWZ_HIP_NO_CACHE"); }
+
+static void plan_store(const fz_program* p, uint64_t n_streams, uint32_t tile, const fz_variant& v, float ms)
+{
+   const std::string dir = cache_dir(), id = board_id();
+   if (!plan_cache_on() || dir.empty() || id.empty()) return;
+   ::mkdir(dir.c_str(), 0755);
+   char line[256];
+   const int n = std::snprintf(line, sizeof line, "%016llx %llu %u %s %u %u %u %u %.5f\n", (unsigned long long)p->graph_hash,
+                               (unsigned long long)n_streams, tile, id.c_str(), v.streams_per_lane, v.unroll, v.block_threads, v.flags, ms);
+   if (n <= 0 || n >= (int)sizeof line) return;
+   if (FILE* f = std::fopen((dir + "/plans.txt").c_str(), "a")) {     // one short append per tune: later lines win
+      std::fwrite(line, 1, (size_t)n, f);
+      std::fclose(f);
+   }
+}
+
+static bool plan_load(const fz_program* p, uint64_t n_streams, uint32_t tile, fz_variant* out)
+{
+   const std::string dir = cache_dir(), id = board_id();
+   if (!plan_cache_on() || dir.empty() || id.empty()) return false;
+   std::ifstream f(dir + "/plans.txt");
+   if (!f) return false;
+   bool found = false;
+   std::string ln;
+   while (std::getline(f, ln)) {
+      unsigned long long h = 0, ns = 0;
+      unsigned t = 0, P = 0, U = 0, B = 0, fl = 0;
+      char idbuf[64] = {0};
+      float ms = 0.f;
+      if (std::sscanf(ln.c_str(), "%llx %llu %u %63s %u %u %u %u %f", &h, &ns, &t, idbuf, &P, &U, &B, &fl, &ms) != 9) continue;
+      if (h != p->graph_hash || ns != n_streams || t != tile || id != idbuf) continue;
+      if ((P != 0 && P != 1 && P != 2 && P != 4) || U > 128 || B > 1024 || (B % 64)) continue;   // (a damaged line)
+      *out = fz_variant{P, U, B, fl};
+      found = true;
+   }
+   return found;
+}
+
+fz_variant planned_variant(fz_program* p, uint64_t n_streams, uint32_t tile_streams)
+{
+   int dev = 0;
+   FZ_HIP(hipGetDevice(&dev));
+   if (tile_streams >= n_streams) tile_streams = 0;
+   const auto key = std::make_tuple(n_streams, tile_streams, dev);
+   {
+      std::lock_guard<std::mutex> lock(p->mu);
+      auto it = p->plans.find(key);
+      if (it != p->plans.end()) return it->second;
+      if (!p->plan_looked_up.insert(key).second) return fz_variant{0, 0, 0, 0};
+   }
+   fz_variant v{0, 0, 0, 0};
+   if (plan_load(p, n_streams, tile_streams, &v) && (v.streams_per_lane || v.unroll || v.block_threads || v.flags)) {
+      std::lock_guard<std::mutex> lock(p->mu);
+      p->plans[key] = v;
+      return v;
+   }
+   return fz_variant{0, 0, 0, 0};
+}
+
 // ---- launch ------------------------------------------------------------------------------------------------
 struct ArgsHeader {
    const float* in;
@@ -406,6 +496,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       FZ_HIP(hipGetDevice(&dev));
       const auto key = std::make_tuple(n_streams, tile_streams, dev);
       bool known = false;
+      (void)planned_variant(p, n_streams, tile_streams);      // first launch of this shape: a plan persisted by an earlier process?
       {
          std::lock_guard<std::mutex> lock(p->mu);
          auto it = p->plans.find(key);
@@ -613,7 +704,9 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
       std::lock_guard<std::mutex> lock(p->mu);
       if (best == 0) p->plans.erase(std::make_tuple(n_streams, tile_streams, dev));
       else p->plans[std::make_tuple(n_streams, tile_streams, dev)] = cands[(size_t)best];
+      p->plan_looked_up.insert(std::make_tuple(n_streams, tile_streams, dev));
    }
+   plan_store(p, n_streams, tile_streams, cands[(size_t)best], best_ms);
    if (chosen) *chosen = cands[(size_t)best];
    if (chosen_ms) *chosen_ms = best_ms;
    return FZ_OK;

@@ -318,6 +318,13 @@ class Program:
         C.check(C.lib.fz_program_source(self._h, vp, buf, n + 1))
         return buf.value.decode()
 
+    def plan(self, n_streams: int, tile_streams: int = 0) -> Variant:
+        """The variant a launch of this shape WITHOUT a variant would use on the current device: tuned in this process,
+        else persisted by an earlier one (plans.txt in the kernel cache), else Variant(0,0,0,0) = the library default."""
+        v = Variant(0, 0, 0, 0)
+        C.check(C.lib.fz_program_plan(self._h, int(n_streams), int(tile_streams), ctypes.byref(v)))
+        return v
+
     def tune_candidates(self, n_streams: int, n_samples: int):
         """The variants Program.tune would measure for this shape (the first one is the library default)."""
         n = C.check(C.lib.fz_program_tune_candidates(self._h, int(n_streams), int(n_samples), None, 0))
