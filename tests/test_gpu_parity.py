@@ -1162,6 +1162,8 @@ def test_stream_major_kernel_rejects_what_it_cannot_do(torch_cuda, F):
         prog.run_block_stream_major(torch.zeros((8, 30, 1), device="cuda"))                 # rows % 4 != 0
     with pytest.raises(F.FlowzError):
         prog.run_block_stream_major(torch.zeros((8, 32, 1), device="cuda"), variant=F.make_variant(4, 8))
+    with pytest.raises(F.FlowzError):                          # 4-wire frames, two streams per lane, 32-sample chunks: one wave per CU
+        F.compile(F.from_sexpr(G.par4_sum())).run_block_stream_major(torch.zeros((128, 64, 4), device="cuda"), variant=F.make_variant(2, 32))
     far = F.compile(F.from_sexpr(("seq", ("in", 1), ("add", ("in", 1), ("del", 1, 300)))))
     with pytest.raises(F.FlowzError):
         far.run_block_stream_major(torch.zeros((8, 32, 1), device="cuda"))

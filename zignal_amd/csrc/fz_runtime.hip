@@ -273,6 +273,9 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    // (per-stream coefficients sit in VGPRs too: with 31 of them the deep prefetch costs 10 %)
    const uint32_t reg_values = (reg_state + g.n_param) * v.P;
    v.U = reqU ? reqU : ((v.P == 2 && n_streams >= (1u << 19) && g.n_in == 1 && g.n_out == 1 && reg_values <= 40) ? 32 : 16);
+   // wide frames, one stream per lane, chip oversubscribed: 32 rows in flight per lane (measured on three boards, 4-wire
+   // frames at 1 M streams: 13.4-14.1 ms against 14.4-14.6 ms with 16; profiles/r02/tune_logs.txt)
+   if (!reqU && v.P == 1 && g.n_in >= 3 && n_streams >= (1u << 19) && !(v.flags & FZ_VF_STAGE_PACK)) v.U = 32;
    if (!reqU && reg_state * v.P > 60) v.U = 8;
    if (!g.far_lines.empty()) {
       // far (HBM ring) reads are prefetched one chunk ahead: a read must be two chunks old, so the chunk
@@ -306,7 +309,10 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // stage packing (one stream per lane) carries over: the skew only shifts which output chunk a step completes.
       // It is what lifts deep serial graphs off the VALU floor here, whatever the stream count.
       if (v.P != 1 || !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
-      else if (!(uv && (uv->flags & FZ_VF_NO_STAGE_PACK)) && n_samples >= 32u * (g.split.K - 1)) v.flags |= FZ_VF_STAGE_PACK;
+      // (automatic only for graphs deep enough to be VALU-bound with one stream per lane: packing takes the in-runs of
+      //  the long-run body off the 512-byte grid, which costs ~10 % of the read rate -- measured: a 2-stage cascade runs
+      //  5.3-5.9 TB/s unpacked against 4.6-5.5 packed, a 6-stage one 4.6 against 5.3)
+      else if (!(uv && (uv->flags & FZ_VF_NO_STAGE_PACK)) && n_samples >= 32u * (g.split.K - 1) && g.n_ops > 27) v.flags |= FZ_VF_STAGE_PACK;
       const uint32_t nw = std::max<uint32_t>(std::max(g.n_in, g.n_out), 1);
       // long-run body (512-byte runs per stream): 1-in/1-out graphs with register-resident state, blocks of at least two phases
       const bool long_ok = g.n_in == 1 && g.n_out == 1 && v.P == 1 && g.n_lds_slots == 0 && (!g.split.ok || g.split.K <= 8);
@@ -340,6 +346,11 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       }
       while (lds(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
       if (lds(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "stream-major frames: the LDS patches do not fit (too many wires per frame)");
+      // two streams per lane with patches so large that a single wave fills the CU's LDS: measured 20 x slower than one
+      // stream per lane (4-wire frames, 32-sample chunks: 10.3 ms against 0.95 ms) -- refuse instead of crawling
+      if (v.P == 2 && v.block < 128 && !reqB)
+         fail(FZ_E_UNSUPPORTED, "stream-major frames: two streams per lane leave one wave per CU with this many wires per frame and this "
+                                "unroll; use one stream per lane or a shorter unroll");
       return v;
    }
    if (g.n_lds_slots) {
