@@ -32,6 +32,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# every run measures for itself: plans persisted by an earlier process on this board (plans.txt of the kernel cache) would
+# turn "library_default" into "whatever was tuned last time"
+os.environ.setdefault("FLOWZ_HIP_NO_PLAN_CACHE", "1")
 
 HBM_PEAK_GBS = 8000.0
 PARITY_STREAMS = 1024

@@ -30,6 +30,8 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstring>
+#include <initializer_list>
 #include <functional>
 #include <memory>
 #include <stdexcept>
@@ -87,6 +89,28 @@ inline uint32_t next_uniform_id()
 }
 
 constexpr int imax(int a, int b) { return a > b ? a : b; }
+
+// one argument of a typed call -> the float slots of its input wire
+template <class T>
+inline void put_typed(float*& w, uint32_t dtype, const T& v)
+{
+   if (dtype == FZ_DT_F32) {
+      *w++ = static_cast<float>(v);
+   } else if (dtype == FZ_DT_F64) {
+      const double d = static_cast<double>(v);
+      std::memcpy(w, &d, sizeof d);
+      w += 2;
+   } else {
+      *w++ = static_cast<float>(v);            // a real argument on a complex wire: (v, 0)
+      *w++ = 0.f;
+   }
+}
+inline void put_typed(float*& w, uint32_t dtype, const std::complex<float>& v)
+{
+   if (dtype != FZ_DT_CF32) throw std::invalid_argument("flowz: a std::complex<float> argument needs an input wire declared FZ_DT_CF32");
+   *w++ = v.real();
+   *w++ = v.imag();
+}
 
 struct expr_tag {};
 
@@ -384,6 +408,7 @@ class stateful_lambda {
    detail::program_ptr prog_;
    detail::ref_list refs_;
    std::unique_ptr<stream_bank> own_;     // lazily created 1-stream bank behind operator()
+   std::vector<uint32_t> in_dtypes_;      // compile_typed(): fz_dtype of every input wire
 
    stream_bank& own()
    {
@@ -427,14 +452,54 @@ public:
       detail::check(fz_compile(e.h.get(), &p));
       prog_ = detail::program_ptr(p, detail::program_deleter());
    }
-   stateful_lambda(const stateful_lambda& o) : prog_(o.prog_), refs_(o.refs_), own_(o.own_ ? new stream_bank(*o.own_) : nullptr) {}
+   // compile_typed(): the wire types of the reference's ResultType transform (flowz.hpp:585-644) carried through inputs,
+   // state and outputs (fz_compile_typed); in_dtypes: one fz_dtype per input wire, empty = all float
+   stateful_lambda(const expr<In, Out>& e, const std::vector<uint32_t>& in_dtypes) : refs_(e.refs), in_dtypes_(in_dtypes)
+   {
+      if (in_dtypes_.empty()) in_dtypes_.assign(In > 0 ? In : 0, static_cast<uint32_t>(FZ_DT_F32));
+      fz_program* p = nullptr;
+      detail::check(fz_compile_typed(e.h.get(), in_dtypes_.empty() ? nullptr : in_dtypes_.data(), static_cast<uint32_t>(in_dtypes_.size()), &p));
+      prog_ = detail::program_ptr(p, detail::program_deleter());
+   }
+   stateful_lambda(const stateful_lambda& o)
+      : prog_(o.prog_), refs_(o.refs_), own_(o.own_ ? new stream_bank(*o.own_) : nullptr), in_dtypes_(o.in_dtypes_)
+   {
+   }
    stateful_lambda(stateful_lambda&&) = default;
    stateful_lambda& operator=(stateful_lambda o)
    {
       std::swap(prog_, o.prog_);
       std::swap(refs_, o.refs_);
       std::swap(own_, o.own_);
+      std::swap(in_dtypes_, o.in_dtypes_);
       return *this;
+   }
+
+   // one sample of a compile_typed() closure: the arguments are converted to the declared type of their input wire
+   // (float / double / std::complex<float>), the result is the raw output frame -- 1 float slot per float wire, 2 per
+   // double wire (the 8 bytes of the double) and 2 per complex wire (re, im); read it with typed_f32/f64/c32 below and
+   // the wire types of output_dtypes()
+   template <class... Args, class = typename std::enable_if<(sizeof...(Args) == In)>::type>
+   std::vector<float> call_typed(const Args&... args)
+   {
+      if (!info().typed) throw error(FZ_E_INVALID, "call_typed needs a closure made by compile_typed()");
+      std::vector<float> in(info().n_in > 0 ? info().n_in : 1), out(info().n_out);
+      float* w = in.data();
+      size_t k = 0;
+      (void)std::initializer_list<int>{(detail::put_typed(w, in_dtypes_.at(k++), args), 0)...};
+      own().process_host(info().n_in ? in.data() : nullptr, out.data(), 1);
+      return out;
+   }
+   // wire types of the outputs (fz_dtype per wire), ResultType of the expression for compile_typed() closures
+   std::vector<uint32_t> output_dtypes() const
+   {
+      std::vector<uint32_t> slots(info().n_out), wires;
+      detail::check(fz_program_output_dtypes(prog_.get(), slots.data(), static_cast<uint32_t>(slots.size())));
+      for (uint32_t c : slots)
+         if (c == 0) wires.push_back(FZ_DT_F32);
+         else if (c == 1 || c == 4) wires.push_back(FZ_DT_F64);
+         else if (c == 2) wires.push_back(FZ_DT_CF32);
+      return wires;
    }
 
    // one sample of one stream; fewer arguments return a curried copy of the closure
@@ -484,6 +549,28 @@ struct compile_fn {
    }
 };
 static const compile_fn compile{};
+
+// compile() with ResultType semantics (flowz.hpp:585-644, test/tests.cpp:184-232): every wire keeps its C++ type through
+// inputs, delay lines and outputs.  in_dtypes: fz_dtype of each input wire (the reference's closure is a template over its
+// argument types); call the closure with call_typed(x...).
+struct compile_typed_fn {
+   template <int I, int O>
+   stateful_lambda<I, O> operator()(const expr<I, O>& e, const std::vector<uint32_t>& in_dtypes = {}) const
+   {
+      return stateful_lambda<I, O>(e, in_dtypes);
+   }
+};
+static const compile_typed_fn compile_typed{};
+
+// readers of a call_typed() frame: the value that starts at slot k
+inline float typed_f32(const std::vector<float>& frame, size_t k) { return frame.at(k); }
+inline double typed_f64(const std::vector<float>& frame, size_t k)
+{
+   double d;
+   std::memcpy(&d, &frame.at(k + 1) - 1, sizeof d);
+   return d;
+}
+inline std::complex<float> typed_c32(const std::vector<float>& frame, size_t k) { return {frame.at(k), frame.at(k + 1)}; }
 
 // layout adapter for callers that keep one contiguous buffer per stream ([stream][t][wire], what each
 // closure of the reference loops over): to / from the frames the block API takes (fz_transpose_frames)

@@ -2,6 +2,7 @@
 // include/flowz/flowz.hpp exactly like the reference writes them -- every call launches the
 // fused kernel on the GPU (1 stream x 1 sample).  Plus currying, closure copies and the block API.
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <vector>
 
@@ -156,6 +157,31 @@ int main()
       for (int t = 0; t < 40; ++t)
          for (int s = 0; s < ns; ++s) ok = ok && out[t * ns + s] == float((t + 1) * (s + 1));
       CHECK(ok);
+   }
+   {  // compile_typed(): ResultType through inputs, state and outputs -- against std::complex<float> / double computed right here
+      using cplx = std::complex<float>;
+      const cplx c{0.6f, 0.7f}, A{0.6f, 0.8f}, B{1.5f, -0.75f};
+      auto pole = compile_typed(~(c * _1[_1] + _2));                       // complex delay line
+      auto divs = compile_typed(A * _1 / (B + _1) + _1 / (B + _1));        // z / w and s / w (__divsc3)
+      auto acc = compile_typed(~(_1[_1] + 1.0 * _2));                      // tests.cpp:223: the accumulator is a double
+      auto dbl_in = compile_typed(_1[_1] * 0.5f + _1, {FZ_DT_F64});        // a double argument and a double delay line
+      cplx z{0.f, 0.f};
+      double a = 0.0, d1 = 0.0;
+      bool ok = true;
+      for (int t = 0; t < 50; ++t) {
+         const float x = 0.25f * float((t * 7) % 11) - 1.f;
+         z = c * z + x;
+         ok = ok && typed_c32(pole.call_typed(x), 0) == z;
+         const cplx w = B + x, r = A * x / w + x / w;
+         ok = ok && typed_c32(divs.call_typed(x), 0) == r;
+         a = a + 1.0 * x;
+         ok = ok && typed_f64(acc.call_typed(x), 0) == a;
+         const double xd = 1.0 / 3.0 + t, yd = d1 * 0.5f + xd;
+         ok = ok && typed_f64(dbl_in.call_typed(xd), 0) == yd;
+         d1 = xd;
+      }
+      CHECK(ok);
+      CHECK(pole.info().typed == 1 && pole.info().n_out == 2 && pole.info().n_out_wires == 1);
    }
    std::printf(failures ? "%d FAILURES\n" : "all GPU EDSL checks passed\n", failures);
    return failures ? 1 : 0;

@@ -1,5 +1,6 @@
 // Host-only checks of the C++ EDSL front end (no GPU): arities, delays, lowering, error paths.
 // Mirrors the analysis asserts of the reference's test/tests.cpp:63-102.
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 
@@ -58,6 +59,29 @@ int main()
    bool threw = false;
    try { compile(~(_1 + _2)); } catch (const flowz::error& e) { threw = e.code == FZ_E_GRAPH; }
    CHECK(threw);
+
+   {  // test_result_type_transform (tests.cpp:184-232) through compile_typed(): ResultType itself, no GPU needed
+      using cplx = std::complex<float>;
+      using T = std::vector<uint32_t>;
+      const uint32_t F = FZ_DT_F32, D = FZ_DT_F64, C = FZ_DT_CF32;
+      CHECK(compile_typed(_1).output_dtypes() == T{F});                                    // :200
+      CHECK(compile_typed(_1 * 1.0).output_dtypes() == T{D});                              // :201
+      CHECK(compile_typed(_1 * 1.0 |= _1).output_dtypes() == T{D});                        // :204
+      CHECK(compile_typed(_1 |= cplx{1, 0} * _1).output_dtypes() == T{C});                 // :206
+      CHECK(compile_typed((_1 * 1.0, _1) |= (_2, _1)).output_dtypes() == (T{F, D}));       // :214
+      CHECK(compile_typed(_1 |= _1[_1]).output_dtypes() == T{F});                          // :218
+      CHECK(compile_typed((_1[_1], 1.0 * _1) |= _2[_1]).output_dtypes() == T{D});          // :219  a double THROUGH a delay line
+      CHECK(compile((_1[_1], 1.0 * _1) |= _2[_1]).output_dtypes() == T{F});                //       compile(): float state (flowz.hpp:1245)
+      CHECK(compile_typed(~(_1[_1] + _2)).output_dtypes() == T{F});                        // :221
+      CHECK(compile_typed(~(1.0 * _1[_1] + _2)).output_dtypes() == T{D});                  // :222
+      CHECK(compile_typed(~(_1[_1] + 1.0 * _2)).output_dtypes() == T{D});                  // :223
+      CHECK(compile_typed(~(_1[_1] + 1.0)).output_dtypes() == T{D});                       // :224
+      CHECK(compile_typed(~(cplx{0.5f, 0.5f} * _1[_1] + _2)).output_dtypes() == T{C});     // complex state
+      CHECK(compile_typed(_1 * 2.f, {FZ_DT_F64}).output_dtypes() == T{D});                 // a double ARGUMENT: f(1.0)
+      bool threw2 = false;
+      try { (void)compile(~(cplx{0.5f, 0.5f} * _1[_1] + _2)); } catch (const flowz::error&) { threw2 = true; }
+      CHECK(threw2);                                                                       // compile() cannot store a complex
+   }
 
    // without a GPU the per-sample call must fail loudly (no CPU fallback)
    if (fz_device_count() == 0) {

@@ -1216,3 +1216,33 @@ print("autotune ok")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and "autotune ok" in out.stdout, out.stdout + out.stderr[-2000:]
     assert out.stderr.count("[flowz_hip] tune ") >= 5                   # the candidates were measured
+
+
+def test_tuned_plan_is_persisted_per_graph_shape_and_board(torch_cuda, F, tmp_path, monkeypatch):
+    """fz_program_tune's winner goes to <kernel cache>/plans.txt (graph structure, n_streams, tile, board UUID): a NEW
+    program of the same structure -- other coefficient values -- launched without a variant picks it up; other shapes and
+    FLOWZ_HIP_NO_PLAN_CACHE do not."""
+    torch = torch_cuda
+    monkeypatch.setenv("FLOWZ_HIP_CACHE", str(tmp_path))
+    monkeypatch.delenv("FLOWZ_HIP_NO_PLAN_CACHE", raising=False)
+    ns, T = 1 << 17, 256
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED)
+    p1 = F.compile(F.from_sexpr(G.df1_cascade(2)))
+    v0 = p1.plan(ns)
+    assert (v0.streams_per_lane, v0.unroll, v0.block_threads, v0.flags) == (0, 0, 0, 0)
+    chosen, _ = p1.tune(x)
+    lines = (tmp_path / "plans.txt").read_text().splitlines()
+    assert len(lines) == 1 and lines[0].split()[1:3] == [str(ns), "0"]
+    p2 = F.compile(F.from_sexpr(G.df1_cascade(2, [G.PAR4_SETS[0], G.PAR4_SETS[1]])))        # same structure, other coefficients
+    got = p2.plan(ns)
+    assert (got.streams_per_lane, got.unroll, got.block_threads, got.flags) == (chosen.streams_per_lane, chosen.unroll, chosen.block_threads, chosen.flags)
+    y2, _ = p2.run_block(x)
+    y1, _ = p2.run_block(x, variant=F.make_variant(1, 8))
+    assert torch.equal(y1, y2)
+    other = p2.plan(ns * 2)
+    assert (other.streams_per_lane, other.unroll, other.block_threads, other.flags) == (0, 0, 0, 0)
+    monkeypatch.setenv("FLOWZ_HIP_NO_PLAN_CACHE", "1")
+    p3 = F.compile(F.from_sexpr(G.df1_cascade(2)))
+    off = p3.plan(ns)
+    assert (off.streams_per_lane, off.unroll, off.block_threads, off.flags) == (0, 0, 0, 0)
