@@ -103,5 +103,10 @@ def make_typed(seed, max_in=3, depth=3):
         post = add(mul(mul(z, IN(1)), w), mul(_coef(rng), IN(1)))
         if rng.random() < 0.5:
             post = sub(lit(rng.uniform(-1, 1)), ("neg", post))
+        r = rng.random()
+        if r < 0.2:                                   # complex / complex (__divsc3), the divisor kept away from zero
+            post = ("div", post, add(("litc", float(rng.uniform(2, 3)), float(rng.uniform(-1, 1))), mul(lit(0.01), IN(1))))
+        elif r < 0.35:                                # scalar / complex
+            post = ("div", mul(lit(0.5), IN(1)), add(("litc", float(rng.uniform(2, 3)), float(rng.uniform(-1, 1))), mul(lit(0.01), post)))
         return seq(g, post), n_in, n_out, "complex"
     return _retype(rng, g, 0.35), n_in, n_out, "double"

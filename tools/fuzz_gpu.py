@@ -16,9 +16,9 @@ from zignal_amd import flowz as F  # noqa: E402
 
 
 def same(a, b, dt):
-    a, b = np.asarray(a, dt), np.asarray(b, dt)
+    a, b = np.ascontiguousarray(a, dt), np.ascontiguousarray(b, dt)
     nan = np.isnan(a) & np.isnan(b)
-    u = np.uint32 if dt == np.float32 else np.uint64
+    u = np.uint32 if np.dtype(dt) == np.float32 else np.uint64
     return np.array_equal(np.where(nan, 0, a).view(u), np.where(nan, 0, b).view(u))
 
 
@@ -57,6 +57,41 @@ for seed in range(first, first + count):
             U = int(rng.choice([4, 8, 16, 32]))
             ys, _ = p.run_block_stream_major(xs, variant=F.make_variant(P, U))
             res.append((f"stream-major P={P} U={U}", same(ys.permute(1, 0, 2).contiguous().cpu().numpy(), want[:60], np.float32)))
+        # the long-run body of the stream-major kernel (1-in/1-out graphs, >= 256 samples), automatic and 64-sample phases
+        if p.n_in == 1 and p.n_out == 1 and p.n_lds_slots == 0:
+            TL = 264 + 4 * int(rng.integers(0, 20))
+            xl = O.synth_input(seed + 1, np.arange(ns), TL, n_wires=1)
+            wl = O.compile(g, ns).run(xl)
+            xsl = torch.from_numpy(np.ascontiguousarray(np.transpose(xl, (1, 0, 2)))).cuda()
+            for v in (None, F.make_variant(1, 64, 0, F.C.FZ_VF_SM_LONG)):
+                ys, _ = p.run_block_stream_major(xsl, variant=v)
+                res.append((f"stream-major long {'auto' if v is None else 'U=64'} T={TL}", same(ys.permute(1, 0, 2).contiguous().cpu().numpy(), wl, np.float32)))
+        # fz_compile_typed: ResultType through inputs (random float / double wires), state and outputs
+        dts = [str(rng.choice(["f32", "f64"])) for _ in range(n_in)]
+        try:
+            ot = O.compile(g, ns, typed=True, in_dtypes=dts)
+        except O.GraphError:
+            ot = None
+        try:
+            pt = F.compile(F.from_sexpr(g), in_dtypes=dts)
+        except F.FlowzError:
+            pt = None
+        if (ot is None) != (pt is None):
+            res.append((f"typed compile accepted by one side only (oracle {ot is not None}, product {pt is not None}) {dts}", False))
+        elif pt is not None:
+            wires = [x[:, :, i].astype(np.float64 if dts[i] == "f64" else np.float32) * (1.0 + (1e-9 if dts[i] == "f64" else 0.0)) for i in range(n_in)]
+            wantt = O.run_typed(ot, wires, T=T)
+            yt, _ = pt.run_block(torch.from_numpy(F.pack_typed(wires, dts)).cuda(), variant=F.make_variant(int(rng.choice([1, 2, 4])), 8))
+            gott = F.unpack_typed(yt.cpu().numpy(), pt.output_dtypes())
+            okt = len(gott) == len(wantt)
+            for a, b in zip(gott, wantt):
+                if a.dtype != b.dtype:
+                    okt = False
+                elif a.dtype == np.complex64:
+                    okt = okt and same(a.real, b.real, np.float32) and same(a.imag, b.imag, np.float32)
+                else:
+                    okt = okt and same(a, b, a.dtype.type)
+            res.append((f"typed {dts}", okt))
         if all(r for _, r in res):
             ok += 1
         else:
