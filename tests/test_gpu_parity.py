@@ -1212,7 +1212,7 @@ r2, sr2 = prog.run_block(x, state=st_ref.clone(), variant=F.make_variant(1, 8))
 assert torch.equal(y, ref) and torch.equal(st, st_ref) and torch.equal(y2, r2) and torch.equal(st2, sr2)
 print("autotune ok")
 '''
-    env = dict(os.environ, FLOWZ_HIP_AUTOTUNE="1", FLOWZ_HIP_DEBUG="1")
+    env = dict(os.environ, FLOWZ_HIP_AUTOTUNE="1", FLOWZ_HIP_DEBUG="1", FLOWZ_HIP_NO_PLAN_CACHE="1")   # (a persisted plan would make the measurement unnecessary)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and "autotune ok" in out.stdout, out.stdout + out.stderr[-2000:]
     assert out.stderr.count("[flowz_hip] tune ") >= 5                   # the candidates were measured

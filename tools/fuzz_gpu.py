@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): a long randomized parity run -- random (typed) graphs, kernels vs the oracle.
-usage: tools/fuzz_gpu.py <first_seed> <count>"""
+usage: tools/fuzz_gpu.py <first_seed> <count> [time limit in seconds: stops early, still prints the summary]"""
+import time
 import os
 import sys
 
@@ -23,9 +24,16 @@ def same(a, b, dt):
 
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
+limit = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
+t_start, last = time.time(), first - 1
 ns, T = 200, 61
 ok = bad = skipped = 0
 for seed in range(first, first + count):
+    if time.time() - t_start > limit:
+        break
+    last = seed
+    if (seed - first) % 50 == 0:
+        print(f"... seed {seed}: {ok} identical, {bad} mismatching, {skipped} skipped so far ({time.time() - t_start:.0f} s)", flush=True)
     for typed in (False, True):
         g, n_in = (R.make_typed(seed)[:2] if typed else R.make(seed)[:2])
         try:
@@ -55,7 +63,12 @@ for seed in range(first, first + count):
         xs = torch.from_numpy(np.ascontiguousarray(np.transpose(x[:60], (1, 0, 2)))).cuda()
         for P in (1, 2):
             U = int(rng.choice([4, 8, 16, 32]))
-            ys, _ = p.run_block_stream_major(xs, variant=F.make_variant(P, U))
+            try:
+                ys, _ = p.run_block_stream_major(xs, variant=F.make_variant(P, U))
+            except F.FlowzError as e:                     # two streams per lane with patches too large for one wave per SIMD: refused
+                if P == 2 and e.code == F.C.FZ_E_UNSUPPORTED:
+                    continue
+                raise
             res.append((f"stream-major P={P} U={U}", same(ys.permute(1, 0, 2).contiguous().cpu().numpy(), want[:60], np.float32)))
         # the long-run body of the stream-major kernel (1-in/1-out graphs, >= 256 samples), automatic and 64-sample phases
         if p.n_in == 1 and p.n_out == 1 and p.n_lds_slots == 0:
@@ -97,5 +110,6 @@ for seed in range(first, first + count):
         else:
             bad += 1
             print("MISMATCH seed", seed, "typed" if typed else "plain", [n for n, r in res if not r], g, flush=True)
-print(f"fuzz seeds {first}..{first + count - 1}: {ok} graphs identical, {bad} mismatching, {skipped} skipped")
+print(f"fuzz seeds {first}..{last}: {ok} graphs identical, {bad} mismatching, {skipped} skipped "
+      f"(per graph: P = 1, 2, 4 with random unroll / flags, float64 frames, a split block, the stream-major kernel short and long, fz_compile_typed with random input types)")
 sys.exit(1 if bad else 0)

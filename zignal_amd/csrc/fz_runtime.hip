@@ -351,7 +351,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       if (lds(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "stream-major frames: the LDS patches do not fit (too many wires per frame)");
       // two streams per lane with patches so large that a single wave fills the CU's LDS: measured 20 x slower than one
       // stream per lane (4-wire frames, 32-sample chunks: 10.3 ms against 0.95 ms) -- refuse instead of crawling
-      if (v.P == 2 && lds(v) / (v.block / 64) > kMaxLdsBytes / 4)   // fewer than one wave per SIMD fit
+      if (v.P == 2 && (uint64_t)64 * v.P * (v.U * nw + 4) * 4 > kMaxLdsBytes / 4)   // the PATCH of one wave: fewer than one wave per SIMD fit
          fail(FZ_E_UNSUPPORTED, "stream-major frames: two streams per lane leave one wave per CU with this many wires per frame and this "
                                 "unroll; use one stream per lane or a shorter unroll");
       return v;
