@@ -1246,3 +1246,23 @@ def test_tuned_plan_is_persisted_per_graph_shape_and_board(torch_cuda, F, tmp_pa
     p3 = F.compile(F.from_sexpr(G.df1_cascade(2)))
     off = p3.plan(ns)
     assert (off.streams_per_lane, off.unroll, off.block_threads, off.flags) == (0, 0, 0, 0)
+
+
+def test_in_place_blocks_when_frame_widths_match(torch_cuda, F):
+    """`in == out` exactly is allowed when n_in == n_out (every kernel body reads a sample before
+    it writes the slot): frame kernel (lane-packed, stage-packed), stream-major short and long bodies."""
+    torch = torch_cuda
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    ns, T = 4096 + 64, 384
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED + 70)
+    want, st_want = prog.run_block(x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+    for v in (F.make_variant(2, 16), F.make_variant(4, 8), F.make_variant(1, 16, 256, STAGE_PACK), F.make_variant(1, 32, 256, NO_STAGE_PACK)):
+        buf = x.clone()
+        y, st = prog.run_block(buf, out=buf, variant=v)
+        assert torch.equal(buf, want) and torch.equal(st, st_want), (v.streams_per_lane, v.unroll, v.flags)
+    xs = x.permute(1, 0, 2).contiguous()
+    for v in (None, F.make_variant(0, 0, 0, SM_SHORT), F.make_variant(2, 16)):
+        buf = xs.clone()
+        y, st = prog.run_block_stream_major(buf, out=buf, variant=v)
+        assert torch.equal(buf.permute(1, 0, 2).contiguous(), want) and torch.equal(st, st_want)
