@@ -215,6 +215,9 @@ auto make_terminal(X x) -> decltype(detail::as_expr(x))
 
 // per-stream, block-constant coefficient k: one value per stream (array given to the bank)
 inline expr<0, 1> stream_param(uint32_t k) { return expr<0, 1>(detail::handle(fz_stream_param(k))); }
+// sample-rate modulator k: what a std::ref(x) terminal is when the caller changes x between CALLS (flowz/README.md:42-61),
+// for the block API -- one value per sample, the same for all streams (bank.set_modulation)
+inline expr<0, 1> modulator(uint32_t k) { return expr<0, 1>(detail::handle(fz_modulator(k))); }
 
 // ---- arithmetic (any C++ operator on evaluated children, proto::_default :769-772) --------------------------
 #define FLOWZ_BINARY_OP(SYM, OP)                                                                         \
@@ -341,6 +344,8 @@ public:
    uint64_t n_streams() const { return n_streams_; }
    void reset() { detail::check(fz_bank_reset(bank_)); }
    void set_stream_params(const float* host /* [n_param][n_streams] */) { detail::check(fz_bank_set_params_host(bank_, host)); }
+   // values of the sample-rate modulators for the following blocks: DEVICE array [n_mod][stride], stride >= the rows of a block
+   void set_modulation(const float* mod_dev, uint32_t stride) { detail::check(fz_program_set_modulation(prog_.get(), mod_dev, stride)); }
    float* state_device() { return fz_bank_state_device(bank_); }
 
    // frames are time-major: in [n_samples][n_streams][n_in], out [n_samples][n_streams][n_out]

@@ -73,6 +73,11 @@ fz_expr* fz_uniform(uint32_t k, float initial);      /* uniform run-time coeffic
                                                         std::ref(x) terminal is when the closure is called
                                                         (flowz/README.md:42-61); set with
                                                         fz_program_set_uniform between blocks             */
+fz_expr* fz_modulator(uint32_t k);                   /* the std::ref(x) terminal at SAMPLE rate (flowz/README.md:42-61: the
+                                                        reference re-reads the referenced variable on every call, i.e. every
+                                                        sample): modulator k has one value per sample of a block, the same
+                                                        for all streams, read from the array fz_program_set_modulation names --
+                                                        an input wire without the per-stream HBM traffic (scalar loads)       */
 fz_expr* fz_arith(fz_op op, fz_expr* a, fz_expr* b); /* any C++ arithmetic operator, _default :769-772;
                                                         b is ignored (may be NULL) for FZ_OP_NEG      */
 fz_expr* fz_channel (fz_expr* a, fz_expr* b);        /* a , b       channel_operator   :90           */
@@ -111,6 +116,7 @@ typedef struct fz_info {
    uint32_t n_out_wires; /* output wires (output_arity); < n_out when some wires are complex         */
    uint32_t n_in_wires;  /* input wires (input_arity); < n_in when a typed program has double / complex inputs */
    uint32_t typed;       /* 1 for fz_compile_typed programs                                           */
+   uint32_t n_mod;       /* sample-rate modulators (highest fz_modulator index + 1)                            */
 } fz_info;
 
 int  fz_compile(const fz_expr* e, fz_program** out);
@@ -149,8 +155,9 @@ typedef enum fz_ir_kind {
    FZ_IR_ADD = 5, FZ_IR_SUB = 6, FZ_IR_MUL = 7, FZ_IR_DIV = 8,   /* a (op) b                    */
    FZ_IR_NEG = 9,     /* -a                                                                    */
    FZ_IR_WIDEN = 10,  /* (double)a : float -> double, exact                                    */
-   FZ_IR_NARROW = 11  /* (float)a  : double -> float, one IEEE rounding (both only appear where C++ itself converts
+   FZ_IR_NARROW = 11, /* (float)a  : double -> float, one IEEE rounding (both only appear where C++ itself converts
                          inside an operator: the float complex division of libgcc's __divsc3, see fz_arith)           */
+   FZ_IR_MOD = 12     /* a = modulator index: value of sample-rate modulator a at this sample (fz_modulator)          */
 } fz_ir_kind;
 
 typedef struct fz_ir_node {
@@ -181,6 +188,12 @@ int fz_program_get_const(const fz_program* p, uint32_t slot, float* value);
 int fz_program_set_const(fz_program* p, uint32_t slot, float value);
 /* overwrite uniform run-time coefficient k (fz_uniform) between blocks */
 int fz_program_set_uniform(fz_program* p, uint32_t k, float value);
+/* Sample-rate modulators (fz_modulator): mod_dev is a DEVICE array [n_mod][stride] of floats, stride >= the rows the frame
+ * buffers of the following launches hold; sample t of a block (row row0 + t of a window) reads modulator k at
+ * mod_dev[k * stride + row0 + t].  The pointer is remembered by the program until it is set again (like fz_program_set_uniform:
+ * set it before the launch that needs it; a launch of a graph with modulators and no array fails with FZ_E_INVALID).
+ * Graphs with modulators are not stage-packed (their segments run at different times).                                   */
+int fz_program_set_modulation(fz_program* p, const float* mod_dev, uint32_t stride);
 
 /* ------------------------------------------------------------------------------------------
  * Kernel variants.  One fused HIP kernel per (graph, variant) is generated and built with

@@ -55,6 +55,9 @@ Graph notation ("s-expressions", plain nested tuples; a shared data format, no c
                          delay line (float state, :1245) nor meet a double operand (no such operator)
     ('param', k)         per-stream coefficient k (block-constant std::ref analogue,
                          flowz/README.md:42-61)
+    ('mod', k)           sample-rate modulator k: a std::ref(x) terminal whose variable the caller changes between calls
+                         (flowz/README.md:42-61: the reference re-reads it on every call); one value per sample, the same
+                         for all streams: step(..., mod=[...]) / run(x, mod=[n_mod, T])
     ('add'|'sub'|'mul'|'div', a, b), ('neg', a)             flowz.hpp:769-772
     ('chan', a, b)       a , b                              flowz.hpp:90
     ('par', a, b)        a | b                              flowz.hpp:91
@@ -82,7 +85,7 @@ def input_arity(e) -> int:
     k = e[0]
     if k in ("in", "del"):
         return int(e[1])                      # :163-170  arity of _i is i
-    if k in ("lit", "lit64", "litc", "param"):
+    if k in ("lit", "lit64", "litc", "param", "mod"):
         return 0                              # :171-174
     if k == "fb":                             # :175-181
         return max(0, input_arity(e[1]) - output_arity(e[1]))
@@ -126,7 +129,7 @@ def max_input_delays(e) -> tuple:
         return (0,) * (e[1] - 1) + (int(e[2]),)
     if k == "in":
         return (0,) * e[1]
-    if k in ("lit", "lit64", "litc", "param"):
+    if k in ("lit", "lit64", "litc", "param", "mod"):
         return ()
     if k == "fb":                             # :459-465
         return max_input_delays(e[1])[output_arity(e[1]):]
@@ -267,6 +270,7 @@ class FlowzOracle:
                 p = p[:, None]
             self._params = np.ascontiguousarray(np.broadcast_to(p, (p.shape[0], self.n_streams)))
         self._cur_in = [None] * self.n_in
+        self._mod_now = [F32(0)] * 256
         # add_front_panel (:261-277): one loose wire per external input
         self._inputs = [self._new(self._mk_input(i)) for i in range(self.n_in)]
         outs = self._elab(expr, self._inputs)
@@ -363,6 +367,9 @@ class FlowzOracle:
         if k == "param":
             idx = int(e[1])
             return [self._new(lambda idx=idx: self._params[idx])]
+        if k == "mod":                                          # the referenced variable as it is at this call
+            idx = int(e[1])
+            return [self._new(lambda idx=idx: np.full(self.n_streams, F32(self._mod_now[idx]), F32))]
         if k in _ARITH:                                         # _default<eval_it> :769-772
             a = self._one(e[1], ins)
             b = self._one(e[2], ins)
@@ -411,8 +418,11 @@ class FlowzOracle:
         return ws[0]
 
     # -- evaluation ----------------------------------------------------------------------
-    def step(self, *inputs):
-        """One sample for every stream.  inputs: n_in scalars or (n_streams,) arrays."""
+    def step(self, *inputs, mod=None):
+        """One sample for every stream.  inputs: n_in scalars or (n_streams,) arrays; mod: the values of the sample-rate
+        modulators at this call."""
+        if mod is not None:
+            self._mod_now = [F32(v) for v in mod] + [F32(0)] * 8
         if len(inputs) != self.n_in:
             raise GraphError(f"expected {self.n_in} inputs, got {len(inputs)}")
         self._t += 1
@@ -448,8 +458,8 @@ class FlowzOracle:
             w.fifo.append(v)
         return tuple(outs)
 
-    def run(self, x):
-        """x: float32 [T, n_streams, n_in] (time-major frames) -> [T, n_streams, n_slots]
+    def run(self, x, mod=None):
+        """x: float32 [T, n_streams, n_in] (time-major frames) -> [T, n_streams, n_slots]; mod: [n_mod, T] modulator values
         (n_slots == n_out unless some output wires are complex: those take two slots, re then im)."""
         x = np.asarray(x, dtype=F32)
         if x.ndim == 2 and self.n_in == 1:
@@ -458,7 +468,7 @@ class FlowzOracle:
         y = np.empty((T, self.n_streams, self.n_slots), self.out_dtype)
         with np.errstate(all="ignore"):
             for t in range(T):
-                o = self.step(*[x[t, :, i] for i in range(self.n_in)])
+                o = self.step(*[x[t, :, i] for i in range(self.n_in)], mod=None if mod is None else [m[t] for m in mod])
                 k = 0
                 for j in range(self.n_out):
                     if self.out_types[j] == "cf32":

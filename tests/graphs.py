@@ -90,3 +90,18 @@ def double_accumulator():
 def typed_delay_of_double():
     """test/tests.cpp:219  (_1[_1], 1.0*_1) |= _2[_1]: the delayed read of a double wire is double (ResultType)"""
     return seq(chan(DEL(1, 1), mul(lit64(1.0), IN(1))), DEL(2, 1))
+
+
+def mod(k):
+    return ("mod", k)
+
+
+def one_pole_modulated():
+    """flowz/README.md:42-61  ~( std::ref(a)*_1[_1] + _2 ) with `a` changed by the caller between calls: at block rate the
+    coefficient is a sample-rate modulator (one value per sample, the same for all streams)"""
+    return fb(add(mul(mod(0), DEL(1, 1)), IN(2)))
+
+
+def modulated_mix():
+    """two modulators in a non-recursive / recursive mix: (m0*_1 + m1*_1[_2]) |= ~(0.5*_1[_1] + m1*_2)"""
+    return seq(add(mul(mod(0), IN(1)), mul(mod(1), DEL(1, 2))), fb(add(mul(lit(0.5), DEL(1, 1)), mul(mod(1), IN(2)))))

@@ -20,7 +20,7 @@ def _split(d):
     return w[..., 0].copy(), w[..., 1].copy()
 
 
-def run_ir(prog, x, params=None, state=None):
+def run_ir(prog, x, params=None, state=None, mod=None):
     """x: [T, ns, n_in] float32 slots -> (y [T, ns, n_out] float32 slots, state [n_state, ns]) following the documented
     state layout: lines in fz_program_lines order, a float line takes `depth` rows (row+j = value at t-1-j), a double
     line (typed programs) 2*depth rows: slot j is ONE row of ns doubles = float rows (row+2j, row+2j+1)."""
@@ -58,6 +58,8 @@ def run_ir(prog, x, params=None, state=None):
                     v[i] = np.full(ns, val, np.float64) if dts[i] == "f64" else np.full(ns, F32(val), F32)
                 elif kind == "param":
                     v[i] = np.asarray(params[a], F32)
+                elif kind == "mod":
+                    v[i] = np.full(ns, F32(mod[a][t]), F32)
                 elif kind == "delay":
                     r0, depth, f64 = row0[a]
                     assert 1 <= b <= depth

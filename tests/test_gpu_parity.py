@@ -1266,3 +1266,62 @@ def test_in_place_blocks_when_frame_widths_match(torch_cuda, F):
         buf = xs.clone()
         y, st = prog.run_block_stream_major(buf, out=buf, variant=v)
         assert torch.equal(buf.permute(1, 0, 2).contiguous(), want) and torch.equal(st, st_want)
+
+
+@pytest.mark.parametrize("P", [0, 1, 2, 4])
+def test_sample_rate_modulators_on_gpu(torch_cuda, F, P):
+    """fz_modulator (the std::ref terminal of flowz/README.md:42-61 re-read at SAMPLE rate inside a block): one value per
+    sample for all streams, scalar loads in the kernel.  vs the oracle; every layout; windows (row0); equal to the reference's
+    own protocol -- one call per sample with the referenced variable changed between calls (fz_uniform + per-sample blocks)."""
+    torch = torch_cuda
+    ns, T = 512, 96
+    rng = np.random.default_rng(5)
+    m = rng.uniform(-0.9, 0.9, (2, T)).astype(np.float32)
+    md = torch.from_numpy(m).cuda()
+    x = O.synth_input(SEED + 80, np.arange(ns), T)
+    v = F.make_variant(P, 8) if P else None
+    for g in (G.one_pole_modulated(), G.modulated_mix()):
+        prog = F.compile(F.from_sexpr(g))
+        want = O.compile(g, ns).run(x, mod=m)
+        with pytest.raises(F.FlowzError):
+            prog.run_block(torch.from_numpy(x).cuda(), variant=v)                    # no modulation array yet
+        prog.set_modulation(md)
+        got, st = run_gpu(torch, F, prog, x, variant=v)
+        assert ndiff(got, want) == 0
+        if P in (0, 1):
+            yt, stt = prog.run_block(F.to_tiled(torch.from_numpy(x).cuda(), 256), variant=F.make_variant(1, 8, 64))
+            assert ndiff(F.from_tiled(yt).contiguous().cpu().numpy(), want) == 0 and torch.equal(stt, st)
+        # windows of the same buffers: the modulator array is indexed by the row of the buffer
+        xd = torch.from_numpy(x).cuda()
+        out = torch.zeros_like(xd)
+        st2 = torch.zeros_like(st)
+        prog.run_window(xd, out, st2, 0, 37, variant=v)
+        prog.run_window(xd, out, st2, 37, T - 37, variant=v)
+        assert ndiff(out.cpu().numpy(), want) == 0 and torch.equal(st2, st)
+        if P in (0, 1, 2):
+            ys, sts = prog.run_block_stream_major(xd.permute(1, 0, 2).contiguous(), variant=F.make_variant(P, 0) if P else None)
+            assert ndiff(ys.permute(1, 0, 2).contiguous().cpu().numpy(), want) == 0 and torch.equal(sts, st)
+    # the reference's protocol: per-sample calls, the referenced variable changed in between
+    if P == 0:
+        pu = F.compile(~(F.uniform(0, 0.0) * F._1[F._1] + F._2))
+        pm = F.compile(F.from_sexpr(G.one_pole_modulated()))
+        pm.set_modulation(md)
+        xd = torch.from_numpy(x).cuda()
+        ym, _ = pm.run_block(xd)
+        stu = torch.zeros((1, ns), device="cuda")
+        rows = []
+        for t in range(T):
+            pu.set_uniform(0, float(m[0, t]))
+            yt, stu = pu.run_block(xd[t:t + 1].contiguous(), state=stu)
+            rows.append(yt)
+        assert torch.equal(torch.cat(rows), ym)
+    # long blocks through the long-run stream-major body
+    if P == 0:
+        TL = 300
+        ml = rng.uniform(-0.9, 0.9, (2, TL)).astype(np.float32)
+        xl = O.synth_input(SEED + 81, np.arange(ns), TL)
+        g = G.modulated_mix()
+        prog = F.compile(F.from_sexpr(g))
+        prog.set_modulation(torch.from_numpy(ml).cuda())
+        ys, _ = prog.run_block_stream_major(torch.from_numpy(np.ascontiguousarray(np.transpose(xl, (1, 0, 2)))).cuda())
+        assert ndiff(ys.permute(1, 0, 2).contiguous().cpu().numpy(), O.compile(g, ns).run(xl, mod=ml)) == 0

@@ -310,3 +310,24 @@ def test_typed_programs_lowering_vs_oracle_and_std_complex():
             F.compile(F.from_sexpr(bad), typed=True, **kw)
     with pytest.raises(F.FlowzError):
         F.compile(F.from_sexpr(G.df1()), in_dtypes=["f32", "f32"])                   # one dtype per input wire
+
+
+def test_sample_rate_modulators_lower_like_the_oracle():
+    """fz_modulator: the std::ref terminal at sample rate (flowz/README.md:42-61).  Lowered IR == oracle; the graph is never
+    stage-packed; launching without a modulation array is refused."""
+    rng = np.random.default_rng(3)
+    x = O.synth_input(4, np.arange(5), 40)
+    m = rng.uniform(-0.9, 0.9, (2, 40)).astype(np.float32)
+    for g in (G.one_pole_modulated(), G.modulated_mix(), G.seq(G.df1_cascade(4), G.mul(G.mod(1), G.IN(1)))):
+        p = F.compile(F.from_sexpr(g))
+        assert p.n_mod == (1 if g == G.one_pole_modulated() else 2) and p.stage_packable == 0
+        want = O.compile(g, 5).run(x, mod=m)
+        got, _ = run_ir(p, x, mod=m)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # per-call semantics of the reference: the same as calling sample by sample with the variable changed in between
+    f = O.compile(G.one_pole_modulated(), 1)
+    ys = [f.step(1.0, mod=[a])[0][0] for a in (0.5, 0.25, -0.5)]
+    assert ys == [1.0, 1.25, 0.375]
+    with pytest.raises(F.FlowzError):                     # a graph without modulators takes no modulation array
+        plain = F.compile(F.from_sexpr(G.df1()))
+        _capi.check(_capi.lib.fz_program_set_modulation(plain._h, None, 16))

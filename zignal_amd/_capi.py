@@ -33,7 +33,7 @@ FZ_VF_SM_LONG, FZ_VF_SM_SHORT = 256, 512
 def FZ_VF_MAX_WG(n):
     """at most n workgroups per CU (flags bits 20..22)"""
     return (int(n) & 7) << 20
-IR_KINDS = {1: "input", 2: "const", 3: "param", 4: "delay", 5: "add", 6: "sub", 7: "mul", 8: "div", 9: "neg", 10: "widen", 11: "narrow"}
+IR_KINDS = {1: "input", 2: "const", 3: "param", 4: "delay", 5: "add", 6: "sub", 7: "mul", 8: "div", 9: "neg", 10: "widen", 11: "narrow", 12: "mod"}
 FZ_DT_F32, FZ_DT_F64, FZ_DT_CF32 = 0, 1, 2
 DTYPES = {"f32": 0, "f64": 1, "cf32": 2}
 
@@ -41,7 +41,7 @@ DTYPES = {"f32": 0, "f64": 1, "cf32": 2}
 class Info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in
                 ("n_in", "n_out", "n_nodes", "n_ops", "n_lines", "n_state", "n_const", "n_param", "max_delay", "n_lds_slots",
-                 "stage_packable", "n_const64", "n_out_wires", "n_in_wires", "typed")]
+                 "stage_packable", "n_const64", "n_out_wires", "n_in_wires", "typed", "n_mod")]
 
 
 class IrNode(ctypes.Structure):
@@ -70,6 +70,8 @@ def _load():
         "fz_literal_f64": (P, [ctypes.c_double]),
         "fz_literal_c32": (P, [ctypes.c_float, ctypes.c_float]),
         "fz_stream_param": (P, [u32]),
+        "fz_modulator": (P, [u32]),
+        "fz_program_set_modulation": (ctypes.c_int, [P, P, u32]),
         "fz_uniform": (P, [u32, f32]),
         "fz_program_set_uniform": (ctypes.c_int, [P, u32, f32]),
         "fz_arith": (P, [ctypes.c_int, P, P]),

@@ -87,6 +87,7 @@ int fz_program_info(const fz_program* p, fz_info* info)
       info->n_out_wires = g.n_out_wires;
       info->n_in_wires = (uint32_t)g.in_dtype.size();
       info->typed = g.typed ? 1u : 0u;
+      info->n_mod = g.n_mod;
       return FZ_OK;)
 }
 
@@ -157,6 +158,18 @@ int fz_program_set_uniform(fz_program* p, uint32_t k, float value)
       if (it == p->g.uniform_slot.end()) fail(FZ_E_INVALID, "graph has no uniform coefficient with this index");
       std::lock_guard<std::mutex> lock(p->mu);
       p->g.consts[it->second] = value;
+      return FZ_OK;)
+}
+
+int fz_program_set_modulation(fz_program* p, const float* mod_dev, uint32_t stride)
+{
+   FZ_GUARD(
+      if (!p) fail(FZ_E_INVALID, "null argument");
+      if (!p->g.n_mod) fail(FZ_E_INVALID, "the graph has no sample-rate modulators");
+      if (mod_dev && !stride) fail(FZ_E_INVALID, "fz_program_set_modulation: stride must be > 0");
+      std::lock_guard<std::mutex> lock(p->mu);
+      p->mod_dev = mod_dev;
+      p->mod_stride = stride;
       return FZ_OK;)
 }
 

@@ -64,6 +64,7 @@ std::vector<uint32_t> max_input_delays(const fz_expr* e)
       case EK::Placeholder: return std::vector<uint32_t>(e->i, 0u);
       case EK::Literal:
       case EK::Uniform:
+      case EK::Modulator:
       case EK::Param: return {};
       case EK::Feedback: return drop(max_input_delays(e->a), (size_t)e->a->out_arity);            // :459-465
       case EK::Parallel: return cat(max_input_delays(e->a), max_input_delays(e->b));              // :479-482
@@ -165,6 +166,16 @@ fz_expr* fz_uniform(uint32_t k, float initial)
       auto* e = mk(EK::Uniform);
       e->i = k;
       e->value = initial;
+      e->in_arity = 0;
+      return e;)
+}
+
+fz_expr* fz_modulator(uint32_t k)
+{
+   FZ_GUARD_PTR(
+      if (k >= 256) fail(FZ_E_INVALID, "modulator index too large");
+      auto* e = mk(EK::Modulator);
+      e->i = k;
       e->in_arity = 0;
       return e;)
 }

@@ -24,7 +24,7 @@ struct Error {
 [[noreturn]] void fail(int code, const std::string& msg);
 
 // ---- expression tree (the EDSL surface, flowz.hpp:68-93) ---------------------------------------
-enum class EK : uint8_t { Placeholder, Delayed, Literal, Uniform, Param, Arith, Neg, Channel, Parallel, Sequence, Feedback };
+enum class EK : uint8_t { Placeholder, Delayed, Literal, Uniform, Param, Arith, Neg, Channel, Parallel, Sequence, Feedback, Modulator };
 
 }  // namespace fz
 
@@ -97,6 +97,7 @@ struct FarRead {
 
 struct Graph {
    uint32_t n_in = 0, n_out = 0, n_param = 0;   // n_in / n_out: frame SLOTS (floats per frame)
+   uint32_t n_mod = 0;               // sample-rate modulators (fz_modulator)
    bool typed = false;               // fz_compile_typed: wire types carried through inputs, state and outputs
    std::vector<uint8_t> in_dtype;    // per input wire: fz_dtype
    std::vector<Node> nodes;          // topological order
@@ -172,6 +173,8 @@ struct fz_program {
    std::set<std::tuple<uint64_t, uint32_t, int>> tuned_default;   // shapes measured already (FLOWZ_HIP_AUTOTUNE)
    std::set<std::tuple<uint64_t, uint32_t, int>> plan_looked_up;  // shapes whose persisted plan (plans.txt of the kernel cache) was consulted
    uint64_t graph_hash = 0;                                        // structure of the lowered graph (no coefficient values)
+   const float* mod_dev = nullptr;                                 // fz_program_set_modulation
+   uint32_t mod_stride = 0;
 };
 
 namespace fz {

@@ -105,6 +105,7 @@ struct Elab {
          }
          case EK::Uniform: return {add(FZ_IR_CONST, -1, -1, e->value, e->i + 1)};   // n = id + 1: own slot
          case EK::Param: return {add(FZ_IR_PARAM, -1, -1, 0.f, e->i)};
+         case EK::Modulator: return {add(FZ_IR_MOD, -1, -1, 0.f, e->i)};
          case EK::Arith: {                                              // _default<eval_it> :769-772
             int a = one(e->a, ins), b = one(e->b, ins);
             uint32_t k = e->op == FZ_OP_ADD ? FZ_IR_ADD : e->op == FZ_OP_SUB ? FZ_IR_SUB
@@ -472,7 +473,7 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
                if (r.f64) key = {r.kind, -2, -1, bits_of64(r.value64)};
                else key = {r.kind, r.n ? (int)r.n : -1, -1, r.n ? 0u : bits_of(r.value)};
                break;
-            case FZ_IR_PARAM: key = {r.kind, -1, -1, r.n}; break;
+            case FZ_IR_PARAM: case FZ_IR_MOD: key = {r.kind, -1, -1, r.n}; break;
             case FZ_IR_DELAY: key = {r.kind, rep[(size_t)r.a], -1, r.n}; break;
             case FZ_IR_NEG: case FZ_IR_WIDEN: case FZ_IR_NARROW: key = {r.kind, rep[(size_t)r.a], -1, 0}; break;
             default: key = {r.kind, rep[(size_t)r.a], rep[(size_t)r.b], 0}; break;
@@ -505,6 +506,7 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
             else { n.a = slot_of(r.value, r.n); n.value = r.value; }
             break;
          case FZ_IR_PARAM: n.a = r.n; g.n_param = std::max(g.n_param, r.n + 1); break;
+         case FZ_IR_MOD: n.a = r.n; g.n_mod = std::max(g.n_mod, r.n + 1); break;
          case FZ_IR_DELAY: n.a = nid(r.a); n.b = r.n; break;
          case FZ_IR_NEG: case FZ_IR_WIDEN: case FZ_IR_NARROW: n.a = nid(r.a); ++g.n_ops; break;
          default: n.a = nid(r.a); n.b = nid(r.b); ++g.n_ops; break;

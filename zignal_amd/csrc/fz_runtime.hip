@@ -464,6 +464,7 @@ struct ArgsHeader {
    float* out;
    float* state;
    const float* params;
+   const float* mod;
    unsigned long long n_streams;
    unsigned int n_samples;
    unsigned int n_groups;
@@ -471,7 +472,10 @@ struct ArgsHeader {
    unsigned int tile_blocks;
    unsigned int rows_total;
    unsigned int row0;
+   unsigned int mod_stride;
+   unsigned int pad_;
 };
+static_assert(sizeof(ArgsHeader) % 8 == 0 && sizeof(ArgsHeader) == 5 * 8 + 8 + 8 * 4, "ArgsHeader must match the head of the kernel's fz_args without padding");
 
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
            uint32_t n_samples, const fz_variant* uv, void* stream, uint32_t tile_streams, uint32_t rows_total, uint32_t row0)
@@ -602,8 +606,17 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    alignas(8) char small[1024];
    std::vector<char> big;
    char* const kbuf = kbytes <= sizeof small ? small : (big.resize(kbytes), big.data());
-   ArgsHeader h{in, out, state, params, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
-                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0};
+   const float* mod_dev = nullptr;
+   uint32_t mod_stride = 0;
+   if (g.n_mod) {
+      std::lock_guard<std::mutex> lock(p->mu);
+      mod_dev = p->mod_dev;
+      mod_stride = p->mod_stride;
+      if (!mod_dev) fail(FZ_E_INVALID, "the graph has sample-rate modulators: call fz_program_set_modulation first");
+      if (mod_stride < rows_total) fail(FZ_E_INVALID, "fz_program_set_modulation: stride is shorter than the rows of this launch");
+   }
+   ArgsHeader h{in, out, state, params, mod_dev, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
+                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0, mod_stride, 0u};
    std::memcpy(kbuf, &h, sizeof h);
    {
       std::lock_guard<std::mutex> lock(p->mu);

@@ -94,7 +94,7 @@ StageSplit find_stage_split(const Graph& g)
    StageSplit none;
    if (g.n_in != 1 || g.n_out != 1 || g.n_lds_slots != 0 || !g.far_lines.empty() || g.n_ops < 2) return none;
    for (const Node& n : g.nodes)
-      if (n.f64) return none;                              // packed halves are float32 pairs
+      if (n.f64 || n.kind == FZ_IR_MOD) return none;       // packed halves are float32 pairs; a modulator has ONE value per time step
    const uint32_t N = (uint32_t)g.nodes.size();
    uint32_t in = N;
    for (uint32_t i = 0; i < N; ++i)

@@ -128,6 +128,12 @@ def param(k: int) -> Expr:
     return Expr(C.lib.fz_stream_param(int(k)))
 
 
+def modulator(k: int) -> Expr:
+    """Sample-rate modulator k: the std::ref(x) terminal whose variable changes between calls (flowz/README.md:42-61), for
+    block evaluation -- one value per sample, the same for all streams: Program.set_modulation(tensor [n_mod, rows])."""
+    return Expr(C.lib.fz_modulator(int(k)))
+
+
 def as_expr(x) -> Expr:
     if isinstance(x, Expr):
         return x
@@ -172,6 +178,7 @@ def from_sexpr(e) -> Expr:
     if k == "lit64": return lit64(e[1])
     if k == "litc": return litc(e[1], e[2])
     if k == "param": return param(e[1])
+    if k == "mod": return modulator(e[1])
     if k == "uniform": return uniform(e[1], e[2])
     if k == "neg": return -from_sexpr(e[1])
     if k == "fb": return ~from_sexpr(e[1])
@@ -299,6 +306,15 @@ class Program:
 
     def set_uniform(self, k: int, value: float):
         C.check(C.lib.fz_program_set_uniform(self._h, int(k), float(value)))
+
+    def set_modulation(self, mod):
+        """mod: CUDA float32 [n_mod, rows] (rows >= the samples the frame buffers of the next launches hold): sample t of a block
+        reads modulator k at mod[k, row0 + t].  The tensor must stay alive until those launches have run."""
+        import torch
+
+        assert mod.is_cuda and mod.dtype == torch.float32 and mod.is_contiguous() and mod.dim() == 2 and mod.shape[0] >= self.n_mod
+        self._mod_keepalive = mod
+        C.check(C.lib.fz_program_set_modulation(self._h, mod.data_ptr(), int(mod.shape[1])))
 
     def recommended_tile_streams(self) -> int:
         """Streams per frame tile that gives ~32 KiB row segments (see fz_run_block_tiled)."""
