@@ -134,7 +134,7 @@ int  fz_compile(const fz_expr* e, fz_program** out);
  *     frame is a double[] there), std::complex<float> = 2 slots (re, im).  n_in / n_out of fz_info count SLOTS,
  *     n_in_wires / n_out_wires count wires.  FZ_VF_OUT_F64 does not apply (rejected).
  * State rows: double lines come first and take two float rows per delay slot (one row of n_streams doubles);
- * a complex wire has one float line for each part.  Double lines are register-resident: depth <= 8.
+ * a complex wire has one float line for each part.  Double lines: registers up to 8 samples, LDS rings up to 256.
  * Not offered: std::complex<double>.                                                                             */
 typedef enum fz_dtype { FZ_DT_F32 = 0, FZ_DT_F64 = 1, FZ_DT_CF32 = 2 } fz_dtype;
 int  fz_compile_typed(const fz_expr* e, const uint32_t* in_dtypes, uint32_t n_in_wires, fz_program** out);

@@ -445,6 +445,17 @@ def test_typed_programs_complex_state_division_double_state(torch_cuda, F, P):
             assert np.array_equal(F.unpack_typed(got, ["f64"])[0], want[:92])
     with pytest.raises(F.FlowzError):
         prog.run_block(torch.zeros((4, 8, 1), device="cuda"), out_f64=True)    # FZ_VF_OUT_F64 does not apply to typed programs
+    # a double delay line of 12 samples: an LDS ring of (low word, high word) pairs, next to a float ring of 20
+    g = G.chan(G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 12)), G.mul(G.lit64(0.25), G.IN(2)))), G.add(G.IN(1), G.DEL(1, 20)))
+    prog = F.compile(F.from_sexpr(g), typed=True)
+    assert prog.line_dtypes() == ["f64", "f32"]
+    want = O.run_typed(O.compile(g, ns, typed=True), [x[:, :, 0]])
+    got, st = _typed_gpu(torch, F, prog, x, v)
+    for a_, b_ in zip(F.unpack_typed(got, prog.output_dtypes()), want):
+        assert a_.dtype == b_.dtype and np.array_equal(a_, b_)
+    a, st1 = _typed_gpu(torch, F, prog, x[:31], v)
+    b, st2 = _typed_gpu(torch, F, prog, x[31:], v, state=st1)
+    assert np.array_equal(np.concatenate([a, b]).view(np.uint32), got.view(np.uint32)) and torch.equal(st2.view(torch.int32), st.view(torch.int32))
 
 
 @pytest.mark.parametrize("P", [0, 1, 2, 4])

@@ -291,6 +291,13 @@ def test_typed_programs_lowering_vs_oracle_and_std_complex():
     got = F.unpack_typed(run_ir(p, x)[0], p.output_dtypes())
     want = O.run_typed(O.compile(g, 7, typed=True), [x[:, :, 0]])
     assert all(a.dtype == b.dtype and np.array_equal(a, b) for a, b in zip(got, want))
+    # a double line deeper than the register cap is an LDS ring of (low word, high word) pairs
+    g = G.chan(G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 12)), G.mul(G.lit64(0.25), G.IN(2)))), G.add(G.IN(1), G.DEL(1, 20)))
+    p = F.compile(F.from_sexpr(g), typed=True)
+    assert p.line_dtypes() == ["f64", "f32"] and p.n_state == 2 * 12 + 20 and p.n_lds_slots == 2 * 16 + 32
+    got = F.unpack_typed(run_ir(p, x)[0], p.output_dtypes())
+    want = O.run_typed(O.compile(g, 7, typed=True), [x[:, :, 0]])
+    assert all(a.dtype == b.dtype and np.array_equal(a, b) for a, b in zip(got, want))
     # typed INPUT wires (the reference's callable is a template over its argument types): double, complex, float
     g = G.chan(G.chan(G.mul(G.IN(1), G.lit(0.5)), G.add(G.IN(2), G.DEL(2, 1))), G.mul(G.IN(3), G.IN(3)))
     dts = ["f64", "cf32", "f32"]
@@ -305,7 +312,7 @@ def test_typed_programs_lowering_vs_oracle_and_std_complex():
     # what C++ would not compile / this build does not offer
     for bad, kw in ((("fb", ("add", ("mul", ("litc", 1.0, 0.0), ("del", 1, 1)), ("mul", ("lit64", 1.0), ("in", 2)))), {}),   # complex meets double
                     (("add", ("in", 1), ("lit64", 1.0)), {"in_dtypes": ["cf32"]}),
-                    (("fb", ("add", ("del", 1, 9), ("mul", ("lit64", 1.0), ("in", 2)))), {})):                               # double line deeper than 8
+                    (("fb", ("add", ("del", 1, 300), ("mul", ("lit64", 1.0), ("in", 2)))), {})):                             # double line beyond the LDS rings
         with pytest.raises(F.FlowzError):
             F.compile(F.from_sexpr(bad), typed=True, **kw)
     with pytest.raises(F.FlowzError):

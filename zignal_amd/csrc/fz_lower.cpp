@@ -557,14 +557,14 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
       l.part = part_of.count(kv.first) ? part_of[kv.first] : 0;
       l.far = l.depth > kLdsMaxDepth;
       l.in_lds = l.depth > kRegMaxDepth && !l.far;
-      if (f64 && l.depth > kRegMaxDepth)
-         fail(FZ_E_UNSUPPORTED, "a double delay line deeper than " + std::to_string(kRegMaxDepth) + " samples (double state is register-resident)");
+      if (f64 && l.far)
+         fail(FZ_E_UNSUPPORTED, "a double delay line deeper than " + std::to_string(kLdsMaxDepth) + " samples (the rings in HBM hold floats)");
       if (l.in_lds) {
          uint32_t sz = 1;
          while (sz < l.depth) sz <<= 1;
          l.lds_slot0 = lds;
          l.lds_size = sz;
-         lds += sz;
+         lds += f64 ? 2 * sz : sz;                 // a double ring: the low words in [slot0, slot0 + sz), the high words behind them
       }
       row += l.depth * (f64 ? 2u : 1u);
       g.max_delay = std::max(g.max_delay, l.depth);
