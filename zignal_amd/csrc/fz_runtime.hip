@@ -276,9 +276,8 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    // wide frames, one stream per lane, chip oversubscribed: 32 rows in flight per lane (measured on three boards, 4-wire
    // frames at 1 M streams: 13.4-14.1 ms against 14.4-14.6 ms with 16; profiles/r02/tune_logs.txt)
    if (!reqU && v.P == 1 && g.n_in >= 3 && n_streams >= (1u << 19) && !(v.flags & FZ_VF_STAGE_PACK)) v.U = 32;
-   // few streams (one wave per SIMD or less), one stream per lane, no stage packing: the lone wave hides the HBM latency
-   // with its own prefetch depth only (measured: fan-out 4-biquad sum at 65 536 streams 0.65 -> 0.74 of peak with 32 rows)
-   if (!reqU && v.P == 1 && n_streams < (1u << 18) && g.n_in <= 2 && !g.split.ok) v.U = 32;
+   // (few streams, one stream per lane, no stage packing: 16 against 32 rows is board-dependent -- the fan-out 4-biquad sum at
+   //  65 536 streams measured 0.65 / 0.74 of peak on one board and 0.79 / 0.69 on the next; fz_program_tune tries both)
    if (!reqU && reg_state * v.P > 60) v.U = 8;
    if (!g.far_lines.empty()) {
       // far (HBM ring) reads are prefetched one chunk ahead: a read must be two chunks old, so the chunk
