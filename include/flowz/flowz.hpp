@@ -100,10 +100,21 @@ inline void put_typed(float*& w, uint32_t dtype, const T& v)
       const double d = static_cast<double>(v);
       std::memcpy(w, &d, sizeof d);
       w += 2;
+   } else if (dtype == FZ_DT_CF64) {           // a real argument on a complex<double> wire: (v, 0.0)
+      const double d[2] = {static_cast<double>(v), 0.0};
+      std::memcpy(w, d, sizeof d);
+      w += 4;
    } else {
       *w++ = static_cast<float>(v);            // a real argument on a complex wire: (v, 0)
       *w++ = 0.f;
    }
+}
+inline void put_typed(float*& w, uint32_t dtype, const std::complex<double>& v)
+{
+   if (dtype != FZ_DT_CF64) throw std::invalid_argument("flowz: a std::complex<double> argument needs an input wire declared FZ_DT_CF64");
+   const double d[2] = {v.real(), v.imag()};
+   std::memcpy(w, d, sizeof d);
+   w += 4;
 }
 inline void put_typed(float*& w, uint32_t dtype, const std::complex<float>& v)
 {
@@ -151,6 +162,8 @@ expr<0, 1> as_expr(T v)
 }
 // a std::complex<float> terminal (test/tests.cpp:206-207): the wire above it is complex
 inline expr<0, 1> as_expr(const std::complex<float>& z) { return expr<0, 1>(handle(fz_literal_c32(z.real(), z.imag()))); }
+// a std::complex<double> terminal: double parts; it meets double operands only, as in C++
+inline expr<0, 1> as_expr(const std::complex<double>& z) { return expr<0, 1>(handle(fz_literal_c64(z.real(), z.imag()))); }
 inline expr<0, 1> as_expr(std::reference_wrapper<float> r)
 {
    const uint32_t id = next_uniform_id();
@@ -170,6 +183,7 @@ const expr<I, O>& as_expr(const expr<I, O>& e)
 template <class T>
 struct is_operand : std::integral_constant<bool, std::is_arithmetic<typename std::decay<T>::type>::value ||
                                                     std::is_same<typename std::decay<T>::type, std::complex<float>>::value ||
+                                                    std::is_same<typename std::decay<T>::type, std::complex<double>>::value ||
                                                     std::is_same<typename std::decay<T>::type, std::reference_wrapper<float>>::value ||
                                                     std::is_same<typename std::decay<T>::type, std::reference_wrapper<const float>>::value> {};
 
@@ -481,8 +495,9 @@ public:
    }
 
    // one sample of a compile_typed() closure: the arguments are converted to the declared type of their input wire
-   // (float / double / std::complex<float>), the result is the raw output frame -- 1 float slot per float wire, 2 per
-   // double wire (the 8 bytes of the double) and 2 per complex wire (re, im); read it with typed_f32/f64/c32 below and
+   // (float / double / std::complex<float> / std::complex<double>), the result is the raw output frame -- 1 float slot per
+   // float wire, 2 per double wire (the 8 bytes of the double), 2 per complex<float> wire (re, im), 4 per complex<double>
+   // wire (the double of re, then of im); read it with typed_f32/f64/c32/c64 below and
    // the wire types of output_dtypes()
    template <class... Args, class = typename std::enable_if<(sizeof...(Args) == In)>::type>
    std::vector<float> call_typed(const Args&... args)
@@ -504,6 +519,7 @@ public:
          if (c == 0) wires.push_back(FZ_DT_F32);
          else if (c == 1 || c == 4) wires.push_back(FZ_DT_F64);
          else if (c == 2) wires.push_back(FZ_DT_CF32);
+         else if (c == 6 || c == 10) wires.push_back(FZ_DT_CF64);
       return wires;
    }
 
@@ -576,6 +592,7 @@ inline double typed_f64(const std::vector<float>& frame, size_t k)
    return d;
 }
 inline std::complex<float> typed_c32(const std::vector<float>& frame, size_t k) { return {frame.at(k), frame.at(k + 1)}; }
+inline std::complex<double> typed_c64(const std::vector<float>& frame, size_t k) { return {typed_f64(frame, k), typed_f64(frame, k + 2)}; }
 
 // layout adapter for callers that keep one contiguous buffer per stream ([stream][t][wire], what each
 // closure of the reference loops over): to / from the frames the block API takes (fz_transpose_frames)

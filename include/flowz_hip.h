@@ -65,6 +65,12 @@ fz_expr* fz_literal_c32(float re, float im);         /* a std::complex<float> te
                                                         (they are float, :1245; fz_compile_typed stores it)
                                                         nor meet a double operand (no such operator in C++):
                                                         FZ_E_GRAPH                                        */
+fz_expr* fz_literal_c64(double re, double im);       /* a std::complex<double> terminal: as fz_literal_c32 with double parts.  Operators
+                                                        follow std::complex<double>: z*w is the (ac-bd, ad+bc) of __muldc3, z/w and
+                                                        s/w are libgcc's __divdc3 = Smith's method (|c| < |d| ? ratio c/d : ratio d/c;
+                                                        both sides are evaluated and selected: FZ_IR_ABSLT / FZ_IR_SELECT); it mixes
+                                                        with double scalars only (as in C++: no operator for complex<double> with
+                                                        float or complex<float>)                                              */
 fz_expr* fz_stream_param(uint32_t k);                /* per-stream, block-constant coefficient k:
                                                         the std::ref terminal of flowz/README.md:42-61,
                                                         one value per stream                          */
@@ -135,13 +141,15 @@ int  fz_compile(const fz_expr* e, fz_program** out);
  *     n_in_wires / n_out_wires count wires.  FZ_VF_OUT_F64 does not apply (rejected).
  * State rows: double lines come first and take two float rows per delay slot (one row of n_streams doubles);
  * a complex wire has one float line for each part.  Double lines: registers up to 8 samples, LDS rings up to 256.
- * Not offered: std::complex<double>.                                                                             */
-typedef enum fz_dtype { FZ_DT_F32 = 0, FZ_DT_F64 = 1, FZ_DT_CF32 = 2 } fz_dtype;
+ * std::complex<double> wires (fz_literal_c64, FZ_DT_CF64 inputs) take four slots: the double of the real part, then
+ * the double of the imaginary part; their delay lines are two double lines.                                         */
+typedef enum fz_dtype { FZ_DT_F32 = 0, FZ_DT_F64 = 1, FZ_DT_CF32 = 2, FZ_DT_CF64 = 3 } fz_dtype;   /* CF64: 4 slots (re, im doubles) */
 int  fz_compile_typed(const fz_expr* e, const uint32_t* in_dtypes, uint32_t n_in_wires, fz_program** out);
 /* type of every input wire (fz_dtype); writes min(n, cap), returns n = n_in_wires */
 int  fz_program_input_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap);
 /* storage type of every delay line, in fz_program_lines order: 0 float, 1 double (two state rows per slot),
- * 2 / 3 the real / imaginary part of a std::complex<float> wire (float rows); writes min(n, cap), returns n */
+ * 2 / 3 the real / imaginary part of a std::complex<float> wire (float rows), 4 / 5 the real / imaginary part of a
+ * std::complex<double> wire (double lines: two state rows per slot); writes min(n, cap), returns n */
 int  fz_program_line_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap);
 void fz_program_destroy(fz_program* p);
 int  fz_program_info(const fz_program* p, fz_info* info);
@@ -157,7 +165,9 @@ typedef enum fz_ir_kind {
    FZ_IR_WIDEN = 10,  /* (double)a : float -> double, exact                                    */
    FZ_IR_NARROW = 11, /* (float)a  : double -> float, one IEEE rounding (both only appear where C++ itself converts
                          inside an operator: the float complex division of libgcc's __divsc3, see fz_arith)           */
-   FZ_IR_MOD = 12     /* a = modulator index: value of sample-rate modulator a at this sample (fz_modulator)          */
+   FZ_IR_MOD = 12,    /* a = modulator index: value of sample-rate modulator a at this sample (fz_modulator)          */
+   FZ_IR_ABSLT = 13,  /* |a| < |b| ? 1 : 0  (in the operands' type)                                                    */
+   FZ_IR_SELECT = 14  /* a != 0 ? b : c   (the data-dependent branch of __divdc3; both sides are evaluated)            */
 } fz_ir_kind;
 
 typedef struct fz_ir_node {
@@ -165,6 +175,7 @@ typedef struct fz_ir_node {
    float value;        /* FZ_IR_CONST, dtype 0 */
    uint32_t dtype;     /* 0 = float32, 1 = float64 (the node's C++ arithmetic type) */
    double value64;     /* FZ_IR_CONST, dtype 1 */
+   uint32_t c;         /* third operand (FZ_IR_SELECT) */
 } fz_ir_node;
 
 /* nodes are in evaluation (topological) order; writes min(n, cap), returns n */
@@ -173,7 +184,9 @@ int fz_program_ir(const fz_program* p, fz_ir_node* nodes, uint32_t cap);
 int fz_program_outputs(const fz_program* p, uint32_t* node_ids, uint32_t cap);
 /* arithmetic type of each output frame slot before it is narrowed to the float32 frame: 0 = float, 1 = double,
  * 2 / 3 = real / imaginary part of a std::complex<float> wire; fz_compile_typed programs: 4 / 5 = low / high word
- * of a double wire (never 1: nothing is narrowed)
+ * of a double wire (never 1: nothing is narrowed), 6 / 7 / 8 / 9 = low / high word of the real, low / high word of
+ * the imaginary part of a std::complex<double> wire; fz_compile programs: 10 / 11 = real / imaginary part of a
+ * std::complex<double> wire (narrowed to the float frame like code 1)
  * (the ResultType inference of flowz.hpp:585-644 / test/tests.cpp:200-231, with compile()'s float delay
  * lines: a delayed read is float whatever was pushed, flowz.hpp:1245); writes min(n_out, cap), returns n_out */
 int fz_program_output_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap);

@@ -69,3 +69,23 @@ extern "C" void fzo_complex_div_mix_std(float are, float aim, float bre, float b
          o[1] = r.imag();
       }
 }
+
+// std::complex<double>: complex state, complex / complex and scalar / complex (tests/graphs.py cdouble_resonator)
+extern "C" void fzo_cdouble_resonator_std(double cre, double cim, double bre, double bim, const double* x, double* y, long n_streams,
+                                          long T)
+{
+   using cplx = std::complex<double>;
+   const cplx C{cre, cim}, B{bre, bim};
+   for (long s = 0; s < n_streams; ++s) {
+      cplx z1{0.0, 0.0};
+      for (long t = 0; t < T; ++t) {
+         const double x0 = x[t * n_streams + s];
+         const cplx z = C * z1 + x0;
+         const cplx w = B + x0;
+         const cplx r = z / w + x0 / w;
+         y[(t * n_streams + s) * 2 + 0] = r.real();
+         y[(t * n_streams + s) * 2 + 1] = r.imag();
+         z1 = z;
+      }
+   }
+}

@@ -183,6 +183,20 @@ def complex_div_mix(x, A=(0.6, 0.8), B=(1.5, -0.75), stream_major=False, std=Fal
     return _run("fzo_complex_div_mix", pre, x, 1, 2, stream_major)
 
 
+def cdouble_resonator(x, C=(0.6, 0.7), B=(1.5, -0.75), std=False):
+    """x: float64 [T, n_streams] -> complex128 [T, n_streams]: tests/graphs.py cdouble_resonator (std::complex<double> state
+    and both spellings of __divdc3).  std=True: the std::complex<double> spelling (oracle/complex_std.cpp)."""
+    x = np.ascontiguousarray(x, np.float64)
+    T, ns = x.shape
+    y = np.empty((T, ns, 2), np.float64)
+    L = lib_std() if std else lib()
+    fn = getattr(L, "fzo_cdouble_resonator_std" if std else "fzo_cdouble_resonator")
+    fn.restype = None
+    fn(*(ctypes.c_double(float(v)) for v in (*C, *B)), x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p),
+       ctypes.c_long(ns), ctypes.c_long(T))
+    return y.view(np.complex128)[..., 0]
+
+
 def double_accumulator(x, stream_major=False):
     """-> float64 frames: tests/graphs.py double_accumulator with double state"""
     return _run("fzo_double_accumulator", (), x, 1, 1, stream_major, np.float64)

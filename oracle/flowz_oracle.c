@@ -25,6 +25,7 @@
  * so the same code walks time-major device-style frames (ss = n_wires, ts = n_streams*n_wires)
  * and per-stream contiguous arrays (ss = T*n_wires, ts = n_wires).
  */
+#include <math.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -415,12 +416,49 @@ void fzo_double_accumulator(const float* x, ptrdiff_t xss, ptrdiff_t xts, double
    }
 }
 
+/* std::complex<double> division = __divdc3 (libgcc2.c): Smith's method.  The scaling branches newer libgcc adds for
+ * extreme magnitudes (|d| >= DBL_MAX/2, tiny operands, subnormal ratio) and the NaN recovery are not restated;
+ * oracle/complex_std.cpp (std::complex<double> compiled by g++) is the pin.                                       */
+static void cdiv_smith(double a, double b, double c, double d, double* x, double* y)
+{
+   if (fabs(c) < fabs(d)) {
+      const double ratio = c / d, denom = (c * ratio) + d;
+      *x = ((a * ratio) + b) / denom;
+      *y = ((b * ratio) - a) / denom;
+   } else {
+      const double ratio = d / c, denom = (d * ratio) + c;
+      *x = ((b * ratio) + a) / denom;
+      *y = (b - (a * ratio)) / denom;
+   }
+}
+
+/* tests/graphs.py: cdouble_resonator (typed, double input x)
+ *    z = C*z[-1] + x  (std::complex<double> state) ;  w = B + x ;  out = z/w + x/w   (both are __divdc3)
+ * x: [T][n_streams] doubles, y: [T][n_streams][2] doubles (re, im)                                                */
+void fzo_cdouble_resonator(double cre, double cim, double bre, double bim, const double* x, double* y, long n_streams, long T)
+{
+   for (long s = 0; s < n_streams; ++s) {
+      double zr = 0.0, zi = 0.0;
+      for (long t = 0; t < T; ++t) {
+         const double x0 = x[t * n_streams + s];
+         const double ac = cre * zr, bd = cim * zi, ad = cre * zi, bc = cim * zr;   /* __muldc3, finite values */
+         zr = (ac - bd) + x0;                                                          /* z += s: real part only */
+         zi = ad + bc;
+         const double wr = bre + x0, wi = bim;
+         double q1r, q1i, q2r, q2i;
+         cdiv_smith(zr, zi, wr, wi, &q1r, &q1i);
+         cdiv_smith(x0, 0.0, wr, wi, &q2r, &q2i);                                      /* r = s; r /= w */
+         y[(t * n_streams + s) * 2 + 0] = q1r + q2r;
+         y[(t * n_streams + s) * 2 + 1] = q1i + q2i;
+      }
+   }
+}
+
 /* ---- RBJ low-pass coefficients, reactive_equations/reactive_filter_coeff.cpp:38-58, with the
  * reference's types: every PARAMETER is float, `1.` `2.` are double literals; std::cos/std::sin of a
  * float.  sin/cos are taken in double and rounded to float, which is within 1 ULP of (and almost
  * always equal to) the float libm result the reference gets.
  * raw6: [6][n] a0 a1 a2 b0 b1 b2;  df1: [5][n] b0/a0 b1/a0 b2/a0 -a1/a0 -a2/a0 (either may be NULL) */
-#include <math.h>
 void fzo_rbj_lowpass(const float* freq, const float* q, float sr, long n, float* raw6, float* df1)
 {
    const float two_pi = 8. * atan(1.);

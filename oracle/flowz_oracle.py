@@ -53,6 +53,8 @@ Graph notation ("s-expressions", plain nested tuples; a shared data format, no c
                          complex; operators as <complex> defines them for complex<float> (class _Cplx
                          below); it takes two slots (re, im) of the output frame; it cannot enter a
                          delay line (float state, :1245) nor meet a double operand (no such operator)
+    ('litc64', re, im)   a std::complex<double> terminal: as 'litc' with double parts (division: __divdc3, Smith's method);
+                         typed programs carry it through delay lines and frames un-narrowed
     ('param', k)         per-stream coefficient k (block-constant std::ref analogue,
                          flowz/README.md:42-61)
     ('mod', k)           sample-rate modulator k: a std::ref(x) terminal whose variable the caller changes between calls
@@ -85,7 +87,7 @@ def input_arity(e) -> int:
     k = e[0]
     if k in ("in", "del"):
         return int(e[1])                      # :163-170  arity of _i is i
-    if k in ("lit", "lit64", "litc", "param", "mod"):
+    if k in ("lit", "lit64", "litc", "litc64", "param", "mod"):
         return 0                              # :171-174
     if k == "fb":                             # :175-181
         return max(0, input_arity(e[1]) - output_arity(e[1]))
@@ -129,7 +131,7 @@ def max_input_delays(e) -> tuple:
         return (0,) * (e[1] - 1) + (int(e[2]),)
     if k == "in":
         return (0,) * e[1]
-    if k in ("lit", "lit64", "litc", "param", "mod"):
+    if k in ("lit", "lit64", "litc", "litc64", "param", "mod"):
         return ()
     if k == "fb":                             # :459-465
         return max_input_delays(e[1])[output_arity(e[1]):]
@@ -149,35 +151,53 @@ def max_input_delays(e) -> tuple:
 # ----------------------------------------------------------------------------------------
 
 class _Cplx:
-    """std::complex<float>, one per stream.  libstdc++/libc++ <complex>, complex<float>:
+    """std::complex<float> / std::complex<double>, one per stream (dt = the part type).  libstdc++/libc++ <complex>:
          z *= s, z /= s        scale both parts          z += s, z -= s     real part only
          s - z                 complex r = -z; r += s    -z                 both parts
-         z * w                 _Complex float multiply = __mulsc3: ac = a*c, bd = b*d, ad = a*d,
-                               bc = b*c, (ac - bd, ad + bc), every operation rounded to float (its
+         z * w                 _Complex multiply = __mulsc3 / __muldc3: ac = a*c, bd = b*d, ad = a*d,
+                               bc = b*c, (ac - bd, ad + bc), every operation rounded to the part type (its
                                inf/nan recovery branch is not restated: finite values only)
+       complex<float>:
        z / w, s / w          _Complex float divide = libgcc's __divsc3 as g++ links it here ("float is handled with
                              double precision", libgcc2.c): aa..dd = the four parts widened to double,
                              denom = cc*cc + dd*dd, x = (float)((aa*cc + bb*dd)/denom), y = (float)((bb*cc - aa*dd)/denom);
                              s / w is complex<float>(s) /= w (<complex>), i.e. b = +0.f.  Its NaN-recovery branch is not
-                             restated (finite values, nonzero divisor).  tests/test_oracle_c.py pins this against
-                             std::complex<float> compiled by g++ (oracle/complex_std.cpp)."""
+                             restated (finite values, nonzero divisor).
+       complex<double>:
+       z / w, s / w          __divdc3 = Smith's method: |c| < |d| ? (ratio = c/d, denom = c*ratio + d, x = (a*ratio + b)/denom,
+                             y = (b*ratio - a)/denom) : (ratio = d/c, denom = d*ratio + c, x = (b*ratio + a)/denom,
+                             y = (b - a*ratio)/denom).  The scaling branches of newer libgcc for extreme magnitudes
+                             (|d| >= DBL_MAX/2, tiny operands, subnormal ratio) and the NaN recovery are not restated.
+       tests/test_oracle_c.py pins both against std::complex compiled by g++ (oracle/complex_std.cpp).
+       The operand types must agree as C++ demands (operator(complex<T>, T), operator(complex<T>, complex<T>)): nothing
+       converts between complex<float> / double or complex<double> / float / complex<float>."""
 
     __array_ufunc__ = None            # numpy arrays defer to the reflected operators below
-    __slots__ = ("re", "im")
+    __slots__ = ("re", "im", "dt")
+    lenient = False                   # while the typed-state fixpoint still raises line types: see FlowzOracle.__init__
 
     def __init__(self, re, im):
-        self.re = np.asarray(re, F32)
-        self.im = np.asarray(im, F32)
+        re, im = np.asarray(re), np.asarray(im)
+        self.dt = np.float64 if (re.dtype == np.float64 or im.dtype == np.float64) else F32
+        self.re = re.astype(self.dt, copy=False)
+        self.im = im.astype(self.dt, copy=False)
 
-    @staticmethod
-    def _scalar(o):
+    def _scalar(self, o):
         o = np.asarray(o)
-        if o.dtype != F32:
-            raise GraphError("std::complex<float> and double operands do not mix (no such operator in C++)")
+        if o.dtype != self.dt:
+            if _Cplx.lenient:
+                return o.astype(np.float64)
+            raise GraphError("std::complex<float> and double operands (std::complex<double> and float ones) do not mix: no such operator in C++")
+        return o
+
+    def _peer(self, o):
+        if o.dt != self.dt and not _Cplx.lenient:
+            raise GraphError("std::complex<float> and std::complex<double> operands do not mix (no such operator in C++)")
         return o
 
     def __add__(self, o):
         if isinstance(o, _Cplx):
+            self._peer(o)
             return _Cplx(self.re + o.re, self.im + o.im)
         return _Cplx(self.re + self._scalar(o), self.im)
 
@@ -186,6 +206,7 @@ class _Cplx:
 
     def __sub__(self, o):
         if isinstance(o, _Cplx):
+            self._peer(o)
             return _Cplx(self.re - o.re, self.im - o.im)
         return _Cplx(self.re - self._scalar(o), self.im)
 
@@ -194,6 +215,7 @@ class _Cplx:
 
     def __mul__(self, o):
         if isinstance(o, _Cplx):
+            self._peer(o)
             ac, bd = self.re * o.re, self.im * o.im
             ad, bc = self.re * o.im, self.im * o.re
             return _Cplx(ac - bd, ad + bc)
@@ -212,15 +234,31 @@ class _Cplx:
         y = ((bb * cc) - (aa * dd)) / denom
         return _Cplx(x.astype(F32), y.astype(F32))
 
+    @staticmethod
+    def _smith_div(a, b, c, d):
+        a, b, c, d = (np.asarray(v, np.float64) for v in (a, b, c, d))
+        r1 = c / d
+        den1 = (c * r1) + d
+        x1, y1 = ((a * r1) + b) / den1, ((b * r1) - a) / den1
+        r2 = d / c
+        den2 = (d * r2) + c
+        x2, y2 = ((b * r2) + a) / den2, (b - (a * r2)) / den2
+        m = np.abs(c) < np.abs(d)
+        return _Cplx(np.where(m, x1, x2), np.where(m, y1, y2))
+
+    def _div(self, a, b, c, d):
+        return self._smith_div(a, b, c, d) if self.dt == np.float64 else self._wide_div(a, b, c, d)
+
     def __truediv__(self, o):
         if isinstance(o, _Cplx):
-            return self._wide_div(self.re, self.im, o.re, o.im)
+            self._peer(o)
+            return self._div(self.re, self.im, o.re, o.im)
         o = self._scalar(o)
         return _Cplx(self.re / o, self.im / o)
 
     def __rtruediv__(self, o):
         o = self._scalar(o)
-        return self._wide_div(o, np.zeros_like(self.re), self.re, self.im)
+        return self._div(o, np.zeros_like(self.re), self.re, self.im)
 
     def __neg__(self):
         return _Cplx(-self.re, -self.im)
@@ -229,6 +267,12 @@ class _Cplx:
 # ----------------------------------------------------------------------------------------
 # lazy wires
 # ----------------------------------------------------------------------------------------
+
+def _kind_of(v):
+    if isinstance(v, _Cplx):
+        return "cf64" if v.dt == np.float64 else "cf32"
+    return "f64" if np.asarray(v).dtype == np.float64 else "f32"
+
 
 class _Wire:
     """One signal wire.  `fn()` computes the value of the current sample on demand."""
@@ -286,34 +330,47 @@ class FlowzOracle:
             raise GraphError("one input dtype per input wire")
 
         def zero_of(kind):
-            if kind == "cf32":
-                return _Cplx(np.zeros(self.n_streams, F32), np.zeros(self.n_streams, F32))
+            if kind in ("cf32", "cf64"):
+                dt = np.float64 if kind == "cf64" else F32
+                return _Cplx(np.zeros(self.n_streams, dt), np.zeros(self.n_streams, dt))
             return np.zeros(self.n_streams, np.float64 if kind == "f64" else F32)
 
-        def kind_of(v):
-            return "cf32" if isinstance(v, _Cplx) else ("f64" if np.asarray(v).dtype == np.float64 else "f32")
+        kind_of = _kind_of
 
         # output frame slots: a complex wire takes two (re, im).  Types are static: probe them once.
         for i in range(self.n_in):
             self._cur_in[i] = zero_of(self.in_dtypes[i])
+        rank = {"f32": 0, "f64": 1, "cf32": 2, "cf64": 3}
         with np.errstate(all="ignore"):
-            for _ in range(8):                       # typed state: raise the lines' types until they settle (least fixpoint from float)
-                self._t += 1
-                changed = False
-                for w in self._delayed:
-                    k = kind_of(self._value(w))
-                    if k == "cf32" and not self.typed:
-                        raise GraphError("a std::complex wire cannot enter a delay line: compile() stores float state")
-                    if self.typed and k != kind_of(w.fifo[0]):
-                        if {k, kind_of(w.fifo[0])} == {"f64", "cf32"}:
-                            raise GraphError("a delayed wire is both double and std::complex<float>")
-                        w.fifo = [zero_of(k) for _ in range(w.depth)]
-                        changed = True
-                if not changed:
-                    break
+            # typed state: raise the lines' types until they settle (least fixpoint from float).  While a line's type is
+            # still an assumption an operator may meet a pair C++ has no operator for (a float recursion variable times a
+            # complex<double>): the verdict waits for the settled types (the strict pass below).
+            _Cplx.lenient = self.typed
+            try:
+                for _ in range(8):
+                    self._t += 1
+                    changed = False
+                    for w in self._delayed:
+                        k = kind_of(self._value(w))
+                        if k in ("cf32", "cf64") and not self.typed:
+                            raise GraphError("a std::complex wire cannot enter a delay line: compile() stores float state")
+                        had = kind_of(w.fifo[0])
+                        if self.typed and k != had:
+                            lo, hi = sorted((k, had), key=rank.get)
+                            if lo != "f32" and (lo, hi) != ("f64", "cf64"):
+                                raise GraphError("a delayed wire has two types C++ does not convert into each other (double / std::complex<float> / std::complex<double>)")
+                            w.fifo = [zero_of(hi) for _ in range(w.depth)]
+                            changed = True
+                    if not changed:
+                        break
+            finally:
+                _Cplx.lenient = False
+            self._t += 1
+            for w in self._delayed:
+                self._value(w)
             probe = [self._value(w) for w in self._outs]
-        self.out_types = ["cf32" if isinstance(v, _Cplx) else ("f64" if np.asarray(v).dtype == np.float64 else "f32") for v in probe]
-        self.n_slots = sum(2 if k == "cf32" else 1 for k in self.out_types)
+        self.out_types = [kind_of(v) for v in probe]
+        self.n_slots = sum(2 if k in ("cf32", "cf64") else 1 for k in self.out_types)
 
     # -- construction ------------------------------------------------------------------
     def _new(self, fn=None):
@@ -364,6 +421,9 @@ class FlowzOracle:
         if k == "litc":
             cr, ci = F32(e[1]), F32(e[2])
             return [self._new(lambda cr=cr, ci=ci: _Cplx(np.full(self.n_streams, cr, F32), np.full(self.n_streams, ci, F32)))]
+        if k == "litc64":
+            zr, zi = np.float64(e[1]), np.float64(e[2])
+            return [self._new(lambda zr=zr, zi=zi: _Cplx(np.full(self.n_streams, zr, np.float64), np.full(self.n_streams, zi, np.float64)))]
         if k == "param":
             idx = int(e[1])
             return [self._new(lambda idx=idx: self._params[idx])]
@@ -428,8 +488,8 @@ class FlowzOracle:
         self._t += 1
         for i, x in enumerate(inputs):
             dt = self.in_dtypes[i]
-            if dt == "cf32":
-                z = np.broadcast_to(np.asarray(x, dtype=np.complex64), (self.n_streams,))
+            if dt in ("cf32", "cf64"):
+                z = np.broadcast_to(np.asarray(x, dtype=np.complex128 if dt == "cf64" else np.complex64), (self.n_streams,))
                 self._cur_in[i] = _Cplx(np.ascontiguousarray(z.real), np.ascontiguousarray(z.imag))
             else:
                 self._cur_in[i] = np.ascontiguousarray(
@@ -438,7 +498,8 @@ class FlowzOracle:
         for w in self._outs:                       # complex wires come out as numpy complex (exact pair)
             v = self._value(w)
             if isinstance(v, _Cplx):
-                c = np.empty(self.n_streams, np.complex128 if self.out_dtype == np.float64 else np.complex64)
+                wide = self.out_dtype == np.float64 or (self.typed and v.dt == np.float64)
+                c = np.empty(self.n_streams, np.complex128 if wide else np.complex64)
                 c.real, c.imag = v.re, v.im
                 outs.append(c)
             elif self.typed:
@@ -471,7 +532,7 @@ class FlowzOracle:
                 o = self.step(*[x[t, :, i] for i in range(self.n_in)], mod=None if mod is None else [m[t] for m in mod])
                 k = 0
                 for j in range(self.n_out):
-                    if self.out_types[j] == "cf32":
+                    if self.out_types[j] in ("cf32", "cf64"):
                         y[t, :, k] = o[j].real
                         y[t, :, k + 1] = o[j].imag
                         k += 2

@@ -183,6 +183,25 @@ int main()
       CHECK(ok);
       CHECK(pole.info().typed == 1 && pole.info().n_out == 2 && pole.info().n_out_wires == 1);
    }
+   {  // std::complex<double>: complex<double> state (two double delay lines), z / w and s / w (__divdc3: a data-dependent
+      // branch), a complex<double> ARGUMENT -- against std::complex<double> computed right here
+      using cd = std::complex<double>;
+      const cd c{0.6, 0.7}, B{1.5, -0.75};
+      auto pole = compile_typed(~(c * _1[_1] + _2), {FZ_DT_F64});
+      auto divs = compile_typed(_1 / (B + _2) + _2 / (B + _2), {FZ_DT_CF64, FZ_DT_F64});
+      cd z{0.0, 0.0};
+      bool ok = true;
+      for (int t = 0; t < 60; ++t) {
+         const double x = 0.37 * double((t * 7) % 11) - 2.3;          // B.real() + x changes sides of |c| < |d|
+         z = c * z + x;
+         ok = ok && typed_c64(pole.call_typed(x), 0) == z;
+         const cd w = B + x, r = z / w + x / w;
+         ok = ok && typed_c64(divs.call_typed(z, x), 0) == r;
+      }
+      CHECK(ok);
+      CHECK(pole.info().typed == 1 && pole.info().n_out == 4 && pole.info().n_out_wires == 1 && pole.info().n_in == 2);
+      CHECK(pole.output_dtypes() == std::vector<uint32_t>{FZ_DT_CF64});
+   }
    std::printf(failures ? "%d FAILURES\n" : "all GPU EDSL checks passed\n", failures);
    return failures ? 1 : 0;
 }

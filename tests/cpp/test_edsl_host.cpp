@@ -78,6 +78,17 @@ int main()
       CHECK(compile_typed(~(_1[_1] + 1.0)).output_dtypes() == T{D});                       // :224
       CHECK(compile_typed(~(cplx{0.5f, 0.5f} * _1[_1] + _2)).output_dtypes() == T{C});     // complex state
       CHECK(compile_typed(_1 * 2.f, {FZ_DT_F64}).output_dtypes() == T{D});                 // a double ARGUMENT: f(1.0)
+      using cd = std::complex<double>;
+      const uint32_t Z = FZ_DT_CF64;
+      CHECK(compile_typed(_1 |= cd{1, 0} * _1, {FZ_DT_F64}).output_dtypes() == T{Z});      // complex<double> * double
+      CHECK(compile_typed(~(cd{0.5, 0.5} * _1[_1] + 1.0 * _2)).output_dtypes() == T{Z});   // complex<double> state; float*1.0 is double
+      CHECK(compile_typed(_1 / cd{2, 1}, {Z}).output_dtypes() == T{Z});                    // a complex<double> argument
+      bool threw3 = false;
+      try { (void)compile_typed(cd{1, 0} * _1); } catch (const flowz::error& e) { threw3 = e.code == FZ_E_GRAPH; }
+      CHECK(threw3);                                                                       // complex<double> * float: no such operator
+      threw3 = false;
+      try { (void)compile_typed((cd{1, 0} * _1) * cplx{1, 0}, {FZ_DT_F64}); } catch (const flowz::error& e) { threw3 = e.code == FZ_E_GRAPH; }
+      CHECK(threw3);                                                                       // complex<double> * complex<float>: neither
       bool threw2 = false;
       try { (void)compile(~(cplx{0.5f, 0.5f} * _1[_1] + _2)); } catch (const flowz::error&) { threw2 = true; }
       CHECK(threw2);                                                                       // compile() cannot store a complex

@@ -81,6 +81,19 @@ def complex_div_mix(A=(0.6, 0.8), B=(1.5, -0.75)):
     return add(("div", z1, w), ("div", x, w))
 
 
+def litc64(re, im):
+    return ("litc64", float(re), float(im))
+
+
+def cdouble_resonator(C=(0.6, 0.7), B=(1.5, -0.75)):
+    """typed, one DOUBLE input x:  z = ~( C*_1[_1] + _2 ) with a std::complex<double> coefficient (two double delay lines),
+    w = B + x,  out = z / w + x / w  -- complex state and both spellings of __divdc3 (Smith's method: a data-dependent
+    branch).  oracle: fzo_cdouble_resonator[_std]"""
+    z = fb(add(mul(litc64(*C), DEL(1, 1)), IN(2)))
+    w = add(litc64(*B), IN(2))
+    return seq(chan(z, IN(1)), add(("div", IN(1), w), ("div", IN(2), w)))
+
+
 def double_accumulator():
     """test/tests.cpp:223  ~( _1[_1] + 1.0*_2 ): ResultType says the loop is double (tuple<double>); with typed state the
     accumulator itself is a double.  oracle: fzo_double_accumulator"""

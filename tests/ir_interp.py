@@ -36,8 +36,9 @@ def run_ir(prog, x, params=None, state=None, mod=None):
     ldt = prog.line_dtypes()
     row0, r = {}, 0
     for (src, depth), dt in zip(lines, ldt):
-        row0[src] = (r, depth, dt == "f64")
-        r += depth * (2 if dt == "f64" else 1)
+        f64 = dt in ("f64", "re64", "im64")
+        row0[src] = (r, depth, f64)
+        r += depth * (2 if f64 else 1)
     if state is None:
         state = np.zeros((max(r, 1), ns), F32)
     else:
@@ -75,6 +76,10 @@ def run_ir(prog, x, params=None, state=None, mod=None):
                     v[i] = v[a] / v[b]
                 elif kind == "neg":
                     v[i] = -v[a]
+                elif kind == "abslt":
+                    v[i] = (np.abs(v[a]) < np.abs(v[b])).astype(v[a].dtype)
+                elif kind == "select":
+                    v[i] = np.where(v[a] != 0, v[b], v[val])
                 elif kind == "widen":
                     v[i] = np.asarray(v[a], F32).astype(np.float64)
                 elif kind == "narrow":
@@ -83,9 +88,9 @@ def run_ir(prog, x, params=None, state=None, mod=None):
                     raise AssertionError(kind)
                 assert np.asarray(v[i]).dtype == (np.float64 if dts[i] == "f64" else F32), (i, kind, dts[i])
             for j, o in enumerate(outs):
-                if codes[j] == 4:
+                if codes[j] in (4, 6, 8):
                     y[t, :, j] = _split(v[o])[0]
-                elif codes[j] == 5:
+                elif codes[j] in (5, 7, 9):
                     y[t, :, j] = _split(v[o])[1]
                 else:
                     y[t, :, j] = v[o]                       # (a double narrows to the float frame, code 1)

@@ -94,9 +94,27 @@ def _retype(rng, e, p64):
 def make_typed(seed, max_in=3, depth=3):
     """as make(), with mixed wire types: some coefficients are double literals (float64 sub-expressions,
     narrowed when they enter a delay line), or -- float-only graphs -- a feed-forward
-    std::complex<float> stage behind the first output wire.  Returns (sexpr, n_in, n_out_wires, kind)."""
+    std::complex<float> stage behind the first output wire, or a std::complex<double> stage there.
+    Returns (sexpr, n_in, n_out_wires, kind)."""
     rng = np.random.default_rng(seed + 77000)
     g, n_in, n_out = make(seed, max_in, depth)
+    r2 = np.random.default_rng(seed + 99000)          # (its own stream: the graphs of the other kinds stay what they were)
+    if r2.random() < 0.2:
+        # a feed-forward std::complex<double> stage behind the first output wire: the wire is widened by a double
+        # literal first (complex<double> meets double operands only); z*w, z+s, s-z, -z, z/w and s/w (__divdc3: Smith's
+        # method, both sides of its branch are reached: the divisor's real part runs through |c| = |d|)
+        c64 = lambda lo, hi: ("litc64", float(r2.uniform(lo, hi)), float(r2.uniform(-1, 1)))   # noqa: E731
+        xd = mul(("lit64", float(r2.uniform(0.5, 1.5))), IN(1))
+        post = add(mul(mul(c64(-1, 1), xd), c64(-1, 1)), mul(("lit64", float(r2.uniform(-1, 1))), xd))
+        if r2.random() < 0.5:
+            post = sub(("lit64", float(r2.uniform(-1, 1))), ("neg", post))
+        div = add(("litc64", float(r2.uniform(-0.5, 0.5)), float(r2.choice([-1, 1]) * r2.uniform(0.4, 1.0))), xd)
+        r = r2.random()
+        if r < 0.4:
+            post = ("div", post, div)
+        elif r < 0.7:
+            post = ("div", xd, add(div, mul(("lit64", 0.01), post)))
+        return seq(g, post), n_in, n_out, "cdouble"
     if rng.random() < 0.45:                           # the stage reads wire 1, the other outputs pass around it
         z = ("litc", float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)))
         w = ("litc", float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)))

@@ -84,7 +84,7 @@ def test_lowering_matches_oracle_on_random_typed_graphs(chunk):
         x = O.synth_input(seed, np.arange(2), 40, n_wires=n_in)
         got, _ = run_ir(p, x)
         assert same_or_both_nan(got, f.run(x)), f"seed {seed}: {g}"
-        kinds.add(kind if kind == "complex" else ("double" if p.n_const64 else "float"))
+        kinds.add(kind if kind in ("complex", "cdouble") else ("double" if p.n_const64 else "float"))
         n += 1
     assert n >= 12 and {"complex", "double"} <= kinds
 

@@ -487,6 +487,43 @@ def test_typed_programs_double_and_complex_input_frames(torch_cuda, F, P):
     assert np.array_equal(np.concatenate([a, b]).view(np.uint32), got.view(np.uint32)) and torch.equal(st2.view(torch.int32), st.view(torch.int32))
 
 
+@pytest.mark.parametrize("P", [0, 1, 2, 4])
+def test_typed_programs_complex_double_state_and_smith_division(torch_cuda, F, P):
+    """std::complex<double> wires on the GPU: complex<double> state (two double lines), z / w and s / w (__divdc3: Smith's
+    method, both sides evaluated and selected per stream) vs std::complex<double> compiled by g++; complex<double> input
+    frames (four slots) vs the typed oracle; time-major, stream-tiled, stream-major, chained blocks."""
+    from test_oracle_c import _cdouble_input
+    torch = torch_cuda
+    ns, T = 1024, 64
+    x = _cdouble_input(T, ns)
+    want = C.cdouble_resonator(x, std=True)
+    g = G.cdouble_resonator()
+    prog = F.compile(F.from_sexpr(g), in_dtypes=["f64"])
+    fr = F.pack_typed([x], ["f64"])
+    v = F.make_variant(P, 4) if P else None
+    got, st = _typed_gpu(torch, F, prog, fr, v)
+    assert np.array_equal(F.unpack_typed(got, ["cf64"])[0].view(np.int64), want.view(np.int64))
+    a, st1 = _typed_gpu(torch, F, prog, fr[:23], v)
+    b, st2 = _typed_gpu(torch, F, prog, fr[23:], v, state=st1)
+    assert np.array_equal(np.concatenate([a, b]).view(np.uint32), got.view(np.uint32)) and torch.equal(st2.view(torch.int32), st.view(torch.int32))
+    got_t, st_t = _typed_gpu(torch, F, prog, fr, F.make_variant(P, 4, 64) if P else None, tile=256)
+    assert np.array_equal(got_t.view(np.uint32), got.view(np.uint32)) and torch.equal(st.view(torch.int32), st_t.view(torch.int32))
+    if P in (0, 1):
+        got_s, st_s = _typed_gpu(torch, F, prog, fr, None, stream_major=True)
+        assert np.array_equal(got_s.view(np.uint32), got.view(np.uint32)) and torch.equal(st.view(torch.int32), st_s.view(torch.int32))
+    # complex<double> input wires with the other three types, a complex<double> wire through a depth-3 line
+    g = G.chan(G.chan(("div", G.IN(1), G.add(G.IN(2), G.DEL(1, 3))), G.mul(G.IN(3), G.IN(4))), G.sub(G.IN(2), G.IN(1)))
+    dts = ["cf64", "f64", "cf32", "f32"]
+    prog = F.compile(F.from_sexpr(g), in_dtypes=dts)
+    rng = np.random.default_rng(13)
+    cplx = lambda dt: (rng.standard_normal((T, ns)) + 1j * rng.standard_normal((T, ns))).astype(dt)   # noqa: E731
+    w = [cplx(np.complex128), rng.standard_normal((T, ns)), cplx(np.complex64), rng.standard_normal((T, ns)).astype(np.float32)]
+    want = O.run_typed(O.compile(g, ns, typed=True, in_dtypes=dts), w)
+    got, _ = _typed_gpu(torch, F, prog, F.pack_typed(w, dts), v)
+    for a, b in zip(F.unpack_typed(got, prog.output_dtypes()), want):
+        assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
 @pytest.mark.parametrize("case", KA["result_types"], ids=lambda c: "tests.cpp:" + c["lines"])
 def test_typed_programs_tests_cpp_result_types_on_gpu(torch_cuda, F, case):
     """test_result_type_transform (tests.cpp:184-232) evaluated on the GPU under fz_compile_typed: the output frames carry

@@ -319,6 +319,47 @@ def test_typed_programs_lowering_vs_oracle_and_std_complex():
         F.compile(F.from_sexpr(G.df1()), in_dtypes=["f32", "f32"])                   # one dtype per input wire
 
 
+def test_complex_double_programs_lowering_vs_oracle_and_std_complex():
+    """std::complex<double> (fz_literal_c64, FZ_DT_CF64): two double lines per delayed wire, four frame slots per wire,
+    __divdc3 as FZ_IR_ABSLT / FZ_IR_SELECT over both sides of Smith's branch -- lowered IR (test interpreter) == typed Python
+    oracle == std::complex<double> compiled by g++."""
+    from test_oracle_c import _cdouble_input
+    x = _cdouble_input(90, 5)
+    g = G.cdouble_resonator()
+    p = F.compile(F.from_sexpr(g), in_dtypes=["f64"])
+    assert (p.n_in, p.n_in_wires, p.n_out, p.n_out_wires) == (2, 1, 4, 1) and p.output_dtypes() == ["cf64"]
+    assert p.line_dtypes() == ["re64", "im64"] and p.output_slot_codes() == [6, 7, 8, 9] and p.n_state == 4
+    kinds = [n[0] for n in p.ir()]
+    assert kinds.count("abslt") == 1 and kinds.count("select") == 4 and set(p.ir_dtypes()) == {"f64"}   # |c| < |d| is shared by z/w and x/w
+    got = F.unpack_typed(run_ir(p, F.pack_typed([x], ["f64"]))[0], ["cf64"])[0]
+    assert got.dtype == np.complex128 and np.array_equal(got.view(np.int64), C.cdouble_resonator(x, std=True).view(np.int64))
+    # complex<double> INPUT wires next to the other three types; a complex<double> wire through a depth-3 line
+    g = G.chan(G.chan(("div", G.IN(1), G.add(G.IN(2), G.DEL(1, 3))), G.mul(G.IN(3), G.IN(4))), G.sub(G.IN(2), G.IN(1)))
+    dts = ["cf64", "f64", "cf32", "f32"]
+    p = F.compile(F.from_sexpr(g), in_dtypes=dts)
+    assert (p.n_in, p.n_in_wires, p.input_dtypes(), p.output_dtypes()) == (9, 4, dts, ["cf64", "cf32", "cf64"])
+    rng = np.random.default_rng(11)
+    cplx = lambda dt: (rng.standard_normal((24, 3)) + 1j * rng.standard_normal((24, 3))).astype(dt)   # noqa: E731
+    w = [cplx(np.complex128), rng.standard_normal((24, 3)), cplx(np.complex64), rng.standard_normal((24, 3)).astype(np.float32)]
+    got = F.unpack_typed(run_ir(p, F.pack_typed(w, dts))[0], p.output_dtypes())
+    want = O.run_typed(O.compile(g, 3, typed=True, in_dtypes=dts), w)
+    assert all(a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(got, want))
+    # untyped compile(): the wire computes in complex<double> and narrows to the float frame (re, im)
+    g = ("div", G.mul(G.litc64(0.3, 0.4), G.mul(G.lit64(1.0), G.IN(1))), G.litc64(2.0, -1.0))
+    p = F.compile(F.from_sexpr(g))
+    xf = O.synth_input(3, np.arange(4), 16)
+    assert np.array_equal(run_ir(p, xf)[0], O.compile(g, 4).run(xf)) and p.n_out == 2
+    # the absorber: a float recursion variable that meets a complex<double> becomes one; a wire that stays float does not compile
+    p = F.compile(F.from_sexpr(G.fb(G.add(G.mul(G.litc64(0.5, 0.5), G.DEL(1, 1)), G.mul(G.lit64(1.0), G.IN(2))))), typed=True)
+    assert p.output_dtypes() == ["cf64"] and p.line_dtypes() == ["re64", "im64"]
+    for bad, dts in ((G.mul(G.litc64(1, 0), G.IN(1)), ["f32"]), (G.mul(G.litc64(1, 0), G.litc(1, 0)), None),
+                     (G.add(G.IN(1), G.IN(2)), ["cf64", "cf32"]), (G.add(G.IN(1), G.IN(2)), ["cf32", "f64"]),
+                     (G.fb(G.chan(G.add(G.DEL(1, 1), G.IN(3)), G.mul(G.litc64(1, 0), G.DEL(1, 1)))), None),
+                     (G.fb(G.add(G.mul(G.litc64(1, 0), G.DEL(1, 1)), G.mul(G.litc(1, 0), G.IN(2)))), None)):
+        with pytest.raises(F.FlowzError):
+            F.compile(F.from_sexpr(bad), typed=True, in_dtypes=dts)
+
+
 def test_sample_rate_modulators_lower_like_the_oracle():
     """fz_modulator: the std::ref terminal at sample rate (flowz/README.md:42-61).  Lowered IR == oracle; the graph is never
     stage-packed; launching without a modulation array is refused."""

@@ -143,6 +143,39 @@ def test_typed_state_and_complex_division_three_spellings_agree():
         O.compile(G.complex_one_pole())                                           # compile(): float state (flowz.hpp:1245)
 
 
+def _cdouble_input(T, ns, seed=5):
+    """double input whose sum with B.real() = 1.5 crosses |c| < |d| (|1.5 + x| < 0.75) about one time in seven"""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1.0, 1.0, (T, ns))
+    x[::3] *= 3.0
+    return x
+
+
+def test_complex_double_state_and_smith_division_three_spellings_agree():
+    """std::complex<double> wires: complex<double> state and both spellings of the division (__divdc3 = Smith's method with
+    its data-dependent branch) -- the typed Python oracle, the C restatement and std::complex<double> compiled by g++ are
+    bit-identical, and both sides of the branch are taken."""
+    x = _cdouble_input(240, 33)
+    want = C.cdouble_resonator(x, std=True)
+    took = np.abs(1.5 + x) < 0.75
+    assert 0.05 < took.mean() < 0.5 and np.isfinite(want.view(np.float64)).all()
+    assert np.array_equal(C.cdouble_resonator(x).view(np.int64), want.view(np.int64))
+    g = G.cdouble_resonator()
+    assert O.output_dtypes_typed(g, ["f64"]) == ["cf64"]
+    y = O.run_typed(O.compile(g, 33, in_dtypes=["f64"]), [x])[0]
+    assert y.dtype == np.complex128 and np.array_equal(y.view(np.int64), want.view(np.int64))
+    # what C++ has no operator for: complex<double> with float / complex<float>; double with complex<float>
+    for bad, dts in ((G.mul(G.litc64(1, 0), G.IN(1)), ["f32"]), (G.mul(G.litc64(1, 0), G.litc(1, 0)), None),
+                     (G.add(G.IN(1), G.IN(2)), ["cf64", "cf32"]), (G.add(G.IN(1), G.IN(2)), ["cf32", "f64"])):
+        with pytest.raises(O.GraphError):
+            O.compile(bad, 1, typed=True, in_dtypes=dts)
+    # a float recursion variable is absorbed by the complex<double> it meets (ResultType's absorber, flowz.hpp:602-620)
+    assert O.output_dtypes_typed(G.fb(G.add(G.mul(G.litc64(0.5, 0.5), G.DEL(1, 1)), G.mul(G.lit64(1.0), G.IN(2))))) == ["cf64"]
+    # ... but a float wire that STAYS float and meets a complex<double> is the compile error it is in C++
+    with pytest.raises(O.GraphError):
+        O.compile(G.fb(G.chan(G.add(G.DEL(1, 1), G.IN(3)), G.mul(G.litc64(1, 0), G.DEL(1, 1)))), 1, typed=True)
+
+
 def test_rbj_lowpass_oracle_matches_reference_spelling_within_1ulp():
     """reactive_filter_coeff.cpp:38-58: the oracle takes sin/cos in double and rounds to float; the
     reference calls std::sin/std::cos on float.  Coefficients agree within 1 ULP (mostly exactly)."""

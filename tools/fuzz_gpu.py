@@ -100,8 +100,9 @@ for seed in range(first, first + count):
             for a, b in zip(gott, wantt):
                 if a.dtype != b.dtype:
                     okt = False
-                elif a.dtype == np.complex64:
-                    okt = okt and same(a.real, b.real, np.float32) and same(a.imag, b.imag, np.float32)
+                elif a.dtype in (np.complex64, np.complex128):
+                    part = np.float32 if a.dtype == np.complex64 else np.float64
+                    okt = okt and same(a.real, b.real, part) and same(a.imag, b.imag, part)
                 else:
                     okt = okt and same(a, b, a.dtype.type)
             res.append((f"typed {dts}", okt))

@@ -33,9 +33,9 @@ FZ_VF_SM_LONG, FZ_VF_SM_SHORT = 256, 512
 def FZ_VF_MAX_WG(n):
     """at most n workgroups per CU (flags bits 20..22)"""
     return (int(n) & 7) << 20
-IR_KINDS = {1: "input", 2: "const", 3: "param", 4: "delay", 5: "add", 6: "sub", 7: "mul", 8: "div", 9: "neg", 10: "widen", 11: "narrow", 12: "mod"}
-FZ_DT_F32, FZ_DT_F64, FZ_DT_CF32 = 0, 1, 2
-DTYPES = {"f32": 0, "f64": 1, "cf32": 2}
+IR_KINDS = {1: "input", 2: "const", 3: "param", 4: "delay", 5: "add", 6: "sub", 7: "mul", 8: "div", 9: "neg", 10: "widen", 11: "narrow", 12: "mod", 13: "abslt", 14: "select"}
+FZ_DT_F32, FZ_DT_F64, FZ_DT_CF32, FZ_DT_CF64 = 0, 1, 2, 3
+DTYPES = {"f32": 0, "f64": 1, "cf32": 2, "cf64": 3}
 
 
 class Info(ctypes.Structure):
@@ -46,7 +46,7 @@ class Info(ctypes.Structure):
 
 class IrNode(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_uint32), ("a", ctypes.c_uint32), ("b", ctypes.c_uint32), ("value", ctypes.c_float),
-                ("dtype", ctypes.c_uint32), ("value64", ctypes.c_double)]
+                ("dtype", ctypes.c_uint32), ("value64", ctypes.c_double), ("c", ctypes.c_uint32)]
 
 
 class Variant(ctypes.Structure):
@@ -69,6 +69,7 @@ def _load():
         "fz_literal": (P, [f32]),
         "fz_literal_f64": (P, [ctypes.c_double]),
         "fz_literal_c32": (P, [ctypes.c_float, ctypes.c_float]),
+        "fz_literal_c64": (P, [ctypes.c_double, ctypes.c_double]),
         "fz_stream_param": (P, [u32]),
         "fz_modulator": (P, [u32]),
         "fz_program_set_modulation": (ctypes.c_int, [P, P, u32]),

@@ -40,7 +40,7 @@ int fz_compile_typed(const fz_expr* e, const uint32_t* in_dtypes, uint32_t n_in_
       LowerOptions opt;
       opt.typed = true;
       for (uint32_t i = 0; in_dtypes && i < n_in_wires; ++i) {
-         if (in_dtypes[i] > FZ_DT_CF32) fail(FZ_E_INVALID, "fz_compile_typed: unknown fz_dtype");
+         if (in_dtypes[i] > FZ_DT_CF64) fail(FZ_E_INVALID, "fz_compile_typed: unknown fz_dtype");
          opt.in_dtype.push_back((uint8_t)in_dtypes[i]);
       }
       std::unique_ptr<fz_program> p(new fz_program());
@@ -61,7 +61,7 @@ int fz_program_line_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap)
 {
    if (!p) { set_error("null program"); return FZ_E_INVALID; }
    for (size_t k = 0; k < p->g.lines.size() && k < cap && dtypes; ++k)
-      dtypes[k] = p->g.lines[k].f64 ? 1u : (p->g.lines[k].part ? 1u + p->g.lines[k].part : 0u);
+      dtypes[k] = p->g.lines[k].part ? (p->g.lines[k].f64 ? 3u : 1u) + p->g.lines[k].part : (p->g.lines[k].f64 ? 1u : 0u);
    return (int)p->g.lines.size();
 }
 
@@ -99,6 +99,7 @@ int fz_program_ir(const fz_program* p, fz_ir_node* nodes, uint32_t cap)
       nodes[k].kind = g.nodes[k].kind;
       nodes[k].a = g.nodes[k].a;
       nodes[k].b = g.nodes[k].b;
+      nodes[k].c = g.nodes[k].c;
       const bool c = g.nodes[k].kind == FZ_IR_CONST;
       nodes[k].dtype = g.nodes[k].f64 ? 1u : 0u;
       nodes[k].value = (c && !g.nodes[k].f64) ? g.consts[g.nodes[k].a] : 0.f;
@@ -117,7 +118,12 @@ int fz_program_outputs(const fz_program* p, uint32_t* ids, uint32_t cap)
 int fz_program_output_dtypes(const fz_program* p, uint32_t* dtypes, uint32_t cap)
 {
    if (!p) { set_error("null program"); return FZ_E_INVALID; }
-   for (size_t k = 0; k < p->g.outputs.size() && k < cap; ++k) dtypes[k] = p->g.out_part[k] ? 1u + p->g.out_part[k] : (p->g.nodes[p->g.outputs[k]].f64 ? 1u : 0u);
+   for (size_t k = 0; k < p->g.outputs.size() && k < cap; ++k) {
+      const uint8_t part = p->g.out_part[k];
+      const bool f64 = p->g.nodes[p->g.outputs[k]].f64;
+      dtypes[k] = (part == 1 || part == 2) && f64 ? 9u + part         // a complex<double> part narrowed to the float frame
+                  : part ? 1u + part : (f64 ? 1u : 0u);
+   }
    return (int)p->g.outputs.size();
 }
 

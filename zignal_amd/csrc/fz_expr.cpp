@@ -159,6 +159,19 @@ fz_expr* fz_literal_c32(float re, float im)
    return e;
 }
 
+fz_expr* fz_literal_c64(double re, double im)
+{
+   auto* e = mk(EK::Literal);
+   e->value = (float)re;
+   e->value_im = (float)im;
+   e->value64 = re;
+   e->value64_im = im;
+   e->cplx = true;
+   e->f64 = true;
+   e->in_arity = 0;
+   return e;
+}
+
 fz_expr* fz_uniform(uint32_t k, float initial)
 {
    FZ_GUARD_PTR(

@@ -38,6 +38,7 @@ struct fz_expr {
    bool f64 = false;      // literal is a C++ double
    bool cplx = false;     // literal is a std::complex<float> (value, value_im)
    float value_im = 0.f;
+   double value64_im = 0.0; // imaginary part of a std::complex<double> literal (cplx && f64)
    fz_op op = FZ_OP_ADD;  // arith
    fz_expr* a = nullptr;
    fz_expr* b = nullptr;
@@ -68,7 +69,7 @@ struct StageSplit {
 // ---- lowered DAG ---------------------------------------------------------------------------------
 struct Node {
    uint32_t kind;   // fz_ir_kind
-   uint32_t a = 0, b = 0;
+   uint32_t a = 0, b = 0, c = 0;
    float value = 0.f;
    bool f64 = false;   // the node's arithmetic type is double (a double literal is among its ancestors)
    double value64 = 0.0;

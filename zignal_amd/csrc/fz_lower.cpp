@@ -49,6 +49,8 @@ struct Elab {
    //   z*w = (ac-bd, ad+bc): the arithmetic of __mulsc3 (_Complex float) for finite values; its
    //         inf/nan recovery branch is not reproduced.   s/z, z/w: __divsc3, see wide_div below.
    std::map<int, int> imag_of;
+   std::string mix_error;   // a complex / scalar type mismatch seen while feedback wire types were still assumptions
+   int fixpoint_depth = 0;
 
    int add(uint32_t kind, int a = -1, int b = -1, float value = 0.f, uint32_t n = 0)
    {
@@ -85,6 +87,8 @@ struct Elab {
                // one float line per part
                const int src = ins[e->i - 1];
                const int re = add(FZ_IR_DELAY, src, -1, 0.f, e->n), im = add(FZ_IR_DELAY, imag_of[src], -1, 0.f, e->n);
+               raw[(size_t)re].f64 = raw[(size_t)src].f64;      // std::complex<double>: two double lines
+               raw[(size_t)im].f64 = raw[(size_t)imag_of[src]].f64;
                imag_of[re] = im;
                return {re};
             } else {
@@ -95,6 +99,11 @@ struct Elab {
          case EK::Literal: {
             if (e->cplx) {
                int re = add(FZ_IR_CONST, -1, -1, e->value), im = add(FZ_IR_CONST, -1, -1, e->value_im);
+               if (e->f64) {                                  // std::complex<double>: both parts are double terminals
+                  raw[(size_t)re].f64 = raw[(size_t)im].f64 = true;
+                  raw[(size_t)re].value64 = e->value64;
+                  raw[(size_t)im].value64 = e->value64_im;
+               }
                imag_of[re] = im;
                return {re};
             }
@@ -165,12 +174,15 @@ struct Elab {
                if (round > 4) fail(FZ_E_GRAPH, "internal: feedback wire types do not settle");
                const size_t mark = raw.size();
                const std::map<int, int> imag_mark = imag_of;
+               const std::string error_mark = mix_error;
+               struct Depth { int& d; Depth(int& x) : d(x) { ++d; } ~Depth() { --d; } } depth(fixpoint_depth);
                std::vector<int> in2, fwd_re(k), fwd_im(k, -1);
                for (size_t j = 0; j < k; ++j) {
                   fwd_re[j] = add(K_FWD);
-                  if (assume[j] == 1) raw[(size_t)fwd_re[j]].f64 = true;
-                  if (assume[j] == 2) {
+                  if (assume[j] == 1 || assume[j] == 3) raw[(size_t)fwd_re[j]].f64 = true;
+                  if (assume[j] >= 2) {
                      fwd_im[j] = add(K_FWD);
+                     raw[(size_t)fwd_im[j]].f64 = assume[j] == 3;
                      imag_of[fwd_re[j]] = fwd_im[j];
                   }
                   in2.push_back(fwd_re[j]);
@@ -180,12 +192,14 @@ struct Elab {
                if (ao.size() != k) fail(FZ_E_GRAPH, "feedback body arity mismatch");
                bool same = true;
                for (size_t j = 0; j < k; ++j) {
-                  const uint8_t act = imag_of.count(ao[j]) ? 2 : (raw[(size_t)ao[j]].f64 ? 1 : 0);
+                  const uint8_t act = (imag_of.count(ao[j]) ? 2 : 0) + (raw[(size_t)ao[j]].f64 ? 1 : 0);   // 0 float, 1 double, 2 complex<float>, 3 complex<double>
                   if (act == assume[j]) continue;
                   same = false;
-                  if ((act == 1 && assume[j] == 2) || (act == 2 && assume[j] == 1))
-                     fail(FZ_E_GRAPH, "a fed-back wire is both double and std::complex<float> (no such conversion in C++)");
-                  assume[j] = std::max(assume[j], act);
+                  // float is absorbed by everything, double by complex<double>; complex<float> meets neither double nor complex<double>
+                  const uint8_t lo = std::min(act, assume[j]), hi = std::max(act, assume[j]);
+                  if (lo != 0 && !(lo == 1 && hi == 3))
+                     fail(FZ_E_GRAPH, "a fed-back wire has two types that C++ does not convert into each other (double / std::complex<float> / std::complex<double>)");
+                  assume[j] = hi;
                }
                if (same) {
                   for (size_t j = 0; j < k; ++j) {
@@ -196,6 +210,7 @@ struct Elab {
                }
                raw.resize(mark);                                  // forget this attempt
                imag_of = imag_mark;
+               mix_error = error_mark;
             }
          }
       }
@@ -214,8 +229,17 @@ struct Elab {
    int complex_arith(uint32_t k, int a, int b)
    {
       const bool ca = imag_of.count(a) != 0, cb = imag_of.count(b) != 0;
-      if ((!ca && raw[(size_t)a].f64) || (!cb && raw[(size_t)b].f64))
-         fail(FZ_E_GRAPH, "std::complex<float> and double operands do not mix (C++ has no such operator)");
+      // operator(complex<T>, T) / (complex<T>, complex<T>) only: the part type of the complex operand(s) must be the
+      // type of the other operand
+      const bool za = raw[(size_t)a].f64, zb = raw[(size_t)b].f64;
+      if (za != zb) {
+         // inside a typed feedback body the operand may be a recursion variable whose type is still being raised: the
+         // verdict waits until the types around the loop have settled (lower() checks mix_error at the end)
+         const char* msg = "std::complex<float> does not mix with double operands nor std::complex<double> with float ones (C++ has no such operator)";
+         if (!typed || !fixpoint_depth) fail(FZ_E_GRAPH, msg);
+         mix_error = msg;
+      }
+      const bool dbl = za || zb;
       int re = -1, im = -1;
       if (ca && cb) {
          const int ar = a, ai = imag_of[a], br = b, bi = imag_of[b];
@@ -228,7 +252,7 @@ struct Elab {
                im = arith(FZ_IR_ADD, ad, bc);
                break;
             }
-            default: return wide_div(ar, ai, br, bi);
+            default: return dbl ? smith_div(ar, ai, br, bi) : wide_div(ar, ai, br, bi);
          }
       } else if (ca) {                                      // complex (op) scalar
          const int ar = a, ai = imag_of[a];
@@ -244,6 +268,11 @@ struct Elab {
             case FZ_IR_MUL: re = arith(FZ_IR_MUL, br, a); im = arith(FZ_IR_MUL, bi, a); break;
             default: {                                      // s / w: complex<float> r = s; r /= w  (<complex>), b = +0.f
                const int zero = add(FZ_IR_CONST, -1, -1, 0.f);
+               if (dbl) {
+                  raw[(size_t)zero].f64 = true;
+                  raw[(size_t)zero].value64 = 0.0;
+                  return smith_div(a, zero, br, bi);
+               }
                return wide_div(a, zero, br, bi);
             }
          }
@@ -270,6 +299,30 @@ struct Elab {
       const int xn = arith(FZ_IR_ADD, arith(FZ_IR_MUL, aa, cc), arith(FZ_IR_MUL, bb, dd));
       const int yn = arith(FZ_IR_SUB, arith(FZ_IR_MUL, bb, cc), arith(FZ_IR_MUL, aa, dd));
       const int re = add(FZ_IR_NARROW, arith(FZ_IR_DIV, xn, denom)), im = add(FZ_IR_NARROW, arith(FZ_IR_DIV, yn, denom));
+      imag_of[re] = im;
+      return re;
+   }
+
+   // (a + ib) / (c + id) for std::complex<double>: libgcc's __divdc3 = Smith's method,
+   //    |c| < |d| :  ratio = c/d, denom = c*ratio + d, x = (a*ratio + b)/denom, y = (b*ratio - a)/denom
+   //    else      :  ratio = d/c, denom = d*ratio + c, x = (b*ratio + a)/denom, y = (b - a*ratio)/denom
+   // (its scaling branches for extreme magnitudes and its NaN recovery are not restated; 200 000 random quotients of
+   // std::complex<double> compiled by g++ here agree bit for bit).  Both sides are evaluated, the result is selected.
+   int smith_div(int a, int b, int c, int d)
+   {
+      auto sel = [&](int m, int x, int y) {
+         const int id = add(FZ_IR_SELECT, m, x, 0.f, (uint32_t)y);
+         raw[(size_t)id].f64 = true;
+         return id;
+      };
+      const int m = arith(FZ_IR_ABSLT, c, d);
+      const int r1 = arith(FZ_IR_DIV, c, d), den1 = arith(FZ_IR_ADD, arith(FZ_IR_MUL, c, r1), d);
+      const int x1 = arith(FZ_IR_DIV, arith(FZ_IR_ADD, arith(FZ_IR_MUL, a, r1), b), den1);
+      const int y1 = arith(FZ_IR_DIV, arith(FZ_IR_SUB, arith(FZ_IR_MUL, b, r1), a), den1);
+      const int r2 = arith(FZ_IR_DIV, d, c), den2 = arith(FZ_IR_ADD, arith(FZ_IR_MUL, d, r2), c);
+      const int x2 = arith(FZ_IR_DIV, arith(FZ_IR_ADD, arith(FZ_IR_MUL, b, r2), a), den2);
+      const int y2 = arith(FZ_IR_DIV, arith(FZ_IR_SUB, b, arith(FZ_IR_MUL, a, r2)), den2);
+      const int re = sel(m, x1, x2), im = sel(m, y1, y2);
       imag_of[re] = im;
       return re;
    }
@@ -315,17 +368,23 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
    uint32_t n_in = 0;                                        // frame slots
    for (uint32_t i = 0; i < n_in_wires; ++i) {
       const uint8_t dt = (opt.typed && i < opt.in_dtype.size()) ? opt.in_dtype[i] : 0;
-      if (dt > 2) fail(FZ_E_INVALID, "unknown input wire type");
+      if (dt > 3) fail(FZ_E_INVALID, "unknown input wire type");
       in_dtype[i] = dt;
       const int id = el.add(FZ_IR_INPUT, -1, -1, 0.f, n_in);
-      if (dt == 1) el.raw[(size_t)id].f64 = true;
+      if (dt == 1 || dt == 3) el.raw[(size_t)id].f64 = true;
       if (dt == 2) el.imag_of[id] = el.add(FZ_IR_INPUT, -1, -1, 0.f, n_in + 1);
-      n_in += dt ? 2 : 1;
+      if (dt == 3) {                                           // complex<double>: (re double, im double) = 4 slots
+         const int im = el.add(FZ_IR_INPUT, -1, -1, 0.f, n_in + 2);
+         el.raw[(size_t)im].f64 = true;
+         el.imag_of[id] = im;
+      }
+      n_in += dt == 3 ? 4 : dt ? 2 : 1;
       ins.push_back(id);
    }
    std::vector<int> input_nodes;                             // every INPUT node (kept alive even when unused)
    for (size_t i = 0; i < el.raw.size(); ++i) input_nodes.push_back((int)i);
    std::vector<int> out_wires = el.run(e, ins);
+   if (!el.mix_error.empty()) fail(FZ_E_GRAPH, el.mix_error);
    if ((int)out_wires.size() != e->out_arity) fail(FZ_E_GRAPH, "output arity mismatch between arity table and routing");
    if (out_wires.empty()) fail(FZ_E_GRAPH, "graph has no output wire");
    // output frame slots: a complex wire takes two (re, im); typed programs: a double wire two (low, high word)
@@ -348,6 +407,7 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
       if (raw[i].kind == K_FWD) continue;
       if (raw[i].a >= 0) raw[i].a = el.resolve(raw[i].a);
       if (raw[i].b >= 0) raw[i].b = el.resolve(raw[i].b);
+      if (raw[i].kind == FZ_IR_SELECT) raw[i].n = (uint32_t)el.resolve((int)raw[i].n);
    }
    for (auto& o : outs) o = el.resolve(o);
 
@@ -363,6 +423,7 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
          live[(size_t)v] = 1;
          if (raw[(size_t)v].a >= 0) work.push_back(raw[(size_t)v].a);
          if (raw[(size_t)v].b >= 0) work.push_back(raw[(size_t)v].b);
+         if (raw[(size_t)v].kind == FZ_IR_SELECT) work.push_back((int)raw[(size_t)v].n);
       }
    }
 
@@ -383,8 +444,10 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
             if (r.kind != FZ_IR_DELAY) {
                if (f.stage == 0) { dep = r.a; f.stage = 1; }
                else if (f.stage == 1) { dep = r.b; f.stage = 2; }
+               else if (f.stage == 2 && r.kind == FZ_IR_SELECT) { dep = (int)r.n; f.stage = 4; }
                else f.stage = 3;
             } else f.stage = 3;
+            if (f.stage == 4 && dep < 0) f.stage = 3;
             if (f.stage == 3) {
                color[(size_t)f.v] = 2;
                order.push_back(f.v);
@@ -418,6 +481,8 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
             r.f64 = raw[(size_t)r.a].f64 || raw[(size_t)r.b].f64;
             break;
          case FZ_IR_NEG: r.f64 = raw[(size_t)r.a].f64; break;
+         case FZ_IR_ABSLT: r.f64 = raw[(size_t)r.a].f64 || raw[(size_t)r.b].f64; break;
+         case FZ_IR_SELECT: r.f64 = raw[(size_t)r.b].f64 || raw[(size_t)r.n].f64; break;
          case FZ_IR_CONST: break;
          case FZ_IR_WIDEN: r.f64 = true; break;
          case FZ_IR_NARROW: r.f64 = false; break;
@@ -463,20 +528,21 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
    for (size_t i = 0; i < N; ++i) rep[i] = (int)i;
    for (bool changed = true; changed;) {
       changed = false;
-      std::map<std::tuple<uint32_t, int, int, uint64_t>, int> seen;
+      std::map<std::tuple<uint32_t, int, int, int, uint64_t>, int> seen;
       for (int v : order) {
          const Raw& r = raw[(size_t)v];
-         std::tuple<uint32_t, int, int, uint64_t> key;
+         std::tuple<uint32_t, int, int, int, uint64_t> key;
          switch (r.kind) {
-            case FZ_IR_INPUT: key = {r.kind, -1, -1, r.n}; break;
+            case FZ_IR_INPUT: key = {r.kind, -1, -1, -1, r.n}; break;
             case FZ_IR_CONST:
-               if (r.f64) key = {r.kind, -2, -1, bits_of64(r.value64)};
-               else key = {r.kind, r.n ? (int)r.n : -1, -1, r.n ? 0u : bits_of(r.value)};
+               if (r.f64) key = {r.kind, -2, -1, -1, bits_of64(r.value64)};
+               else key = {r.kind, r.n ? (int)r.n : -1, -1, -1, r.n ? 0u : bits_of(r.value)};
                break;
-            case FZ_IR_PARAM: case FZ_IR_MOD: key = {r.kind, -1, -1, r.n}; break;
-            case FZ_IR_DELAY: key = {r.kind, rep[(size_t)r.a], -1, r.n}; break;
-            case FZ_IR_NEG: case FZ_IR_WIDEN: case FZ_IR_NARROW: key = {r.kind, rep[(size_t)r.a], -1, 0}; break;
-            default: key = {r.kind, rep[(size_t)r.a], rep[(size_t)r.b], 0}; break;
+            case FZ_IR_PARAM: case FZ_IR_MOD: key = {r.kind, -1, -1, -1, r.n}; break;
+            case FZ_IR_DELAY: key = {r.kind, rep[(size_t)r.a], -1, -1, r.n}; break;
+            case FZ_IR_NEG: case FZ_IR_WIDEN: case FZ_IR_NARROW: key = {r.kind, rep[(size_t)r.a], -1, -1, 0}; break;
+            case FZ_IR_SELECT: key = {r.kind, rep[(size_t)r.a], rep[(size_t)r.b], rep[(size_t)r.n], 0}; break;
+            default: key = {r.kind, rep[(size_t)r.a], rep[(size_t)r.b], -1, 0}; break;
          }
          auto it = seen.find(key);
          int nv = v;
@@ -509,6 +575,7 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
          case FZ_IR_MOD: n.a = r.n; g.n_mod = std::max(g.n_mod, r.n + 1); break;
          case FZ_IR_DELAY: n.a = nid(r.a); n.b = r.n; break;
          case FZ_IR_NEG: case FZ_IR_WIDEN: case FZ_IR_NARROW: n.a = nid(r.a); ++g.n_ops; break;
+         case FZ_IR_SELECT: n.a = nid(r.a); n.b = nid(r.b); n.c = nid((int)r.n); ++g.n_ops; break;
          default: n.a = nid(r.a); n.b = nid(r.b); ++g.n_ops; break;
       }
    }
@@ -518,11 +585,12 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
    g.n_out_wires = (uint32_t)out_wires.size();
    for (size_t k = 0; k < outs.size(); ++k) {
       const uint32_t id = nid(outs[k]);
-      if (opt.typed && out_part[k] == 0 && g.nodes[id].f64) {   // a double wire leaves un-narrowed: two slots
+      if (opt.typed && g.nodes[id].f64) {   // a double (part) leaves un-narrowed: two slots (low word, high word)
+         const uint8_t base = out_part[k] == 0 ? 3 : out_part[k] == 1 ? 5 : 7;   // real wire / re / im of a complex<double>
          g.outputs.push_back(id);
-         g.out_part.push_back(3);
+         g.out_part.push_back(base);
          g.outputs.push_back(id);
-         g.out_part.push_back(4);
+         g.out_part.push_back((uint8_t)(base + 1));
       } else {
          g.outputs.push_back(id);
          g.out_part.push_back(out_part[k]);

@@ -375,7 +375,7 @@ uint64_t graph_structure_hash(const Graph& g)
 {
    std::ostringstream o;
    o << g.n_in << ' ' << g.n_out << ' ' << g.n_param << ' ' << (g.typed ? 1 : 0) << '|';
-   for (const Node& n : g.nodes) o << n.kind << ',' << n.a << ',' << n.b << ',' << (n.f64 ? 1 : 0) << ';';
+   for (const Node& n : g.nodes) o << n.kind << ',' << n.a << ',' << n.b << ',' << n.c << ',' << (n.f64 ? 1 : 0) << ';';
    o << '|';
    for (uint32_t v : g.outputs) o << v << ',';
    o << '|';

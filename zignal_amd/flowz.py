@@ -119,6 +119,12 @@ def litc(re: float, im: float = 0.0) -> Expr:
     return Expr(C.lib.fz_literal_c32(float(re), float(im)))
 
 
+def litc64(re: float, im: float = 0.0) -> Expr:
+    """A std::complex<double> terminal: as litc with double parts (z / w is libgcc's __divdc3, Smith's method).  In a
+    typed program the wire takes four float32 slots: the double of the real part, then that of the imaginary part."""
+    return Expr(C.lib.fz_literal_c64(float(re), float(im)))
+
+
 def uniform(k: int, initial: float = 0.0) -> Expr:
     """Uniform run-time coefficient k (the std::ref(x) terminal): Program.set_uniform(k, v)."""
     return Expr(C.lib.fz_uniform(int(k), float(initial)))
@@ -177,6 +183,7 @@ def from_sexpr(e) -> Expr:
     if k == "lit": return lit(e[1])
     if k == "lit64": return lit64(e[1])
     if k == "litc": return litc(e[1], e[2])
+    if k == "litc64": return litc64(e[1], e[2])
     if k == "param": return param(e[1])
     if k == "mod": return modulator(e[1])
     if k == "uniform": return uniform(e[1], e[2])
@@ -243,7 +250,9 @@ class Program:
         n = C.check(C.lib.fz_program_ir(self._h, None, 0))
         buf = (C.IrNode * max(n, 1))()
         C.check(C.lib.fz_program_ir(self._h, buf, n))
-        return [(C.IR_KINDS[buf[i].kind], buf[i].a, buf[i].b, buf[i].value64 if buf[i].dtype else buf[i].value)
+        # 4th field: the literal of a 'const' node; the third operand of a 'select' node (a != 0 ? b : c)
+        return [(C.IR_KINDS[buf[i].kind], buf[i].a, buf[i].b,
+                 buf[i].c if buf[i].kind == 14 else (buf[i].value64 if buf[i].dtype else buf[i].value))
                 for i in range(n)]
 
     def ir_dtypes(self):
@@ -263,11 +272,14 @@ class Program:
         (a 'cf32' wire, std::complex<float>, takes two frame slots: re, im)."""
         buf = (ctypes.c_uint32 * max(self.n_out, 1))()
         C.check(C.lib.fz_program_output_dtypes(self._h, buf, self.n_out))
-        return [("f32", "f64", "cf32", None, "f64")[buf[i]] for i in range(self.n_out) if buf[i] not in (3, 5)]
+        names = {0: "f32", 1: "f64", 2: "cf32", 4: "f64", 6: "cf64", 10: "cf64"}   # the first slot of a wire names it
+        return [names[buf[i]] for i in range(self.n_out) if buf[i] in names]
 
     def output_slot_codes(self):
         """raw per-slot codes of fz_program_output_dtypes: 0 float, 1 double (narrowed to the float frame), 2 / 3 re / im
-        of a complex wire, 4 / 5 low / high word of a double wire (typed programs)"""
+        of a complex wire, 4 / 5 low / high word of a double wire (typed programs), 6 / 7 / 8 / 9 low / high word of the
+        real, low / high word of the imaginary part of a std::complex<double> wire (typed programs), 10 / 11 re / im of a
+        std::complex<double> wire narrowed to the float frame (compile())"""
         buf = (ctypes.c_uint32 * max(self.n_out, 1))()
         C.check(C.lib.fz_program_output_dtypes(self._h, buf, self.n_out))
         return [buf[i] for i in range(self.n_out)]
@@ -277,7 +289,7 @@ class Program:
         n = max(self.n_in_wires, 1)
         buf = (ctypes.c_uint32 * n)()
         k = C.check(C.lib.fz_program_input_dtypes(self._h, buf, n))
-        return [("f32", "f64", "cf32")[buf[i]] for i in range(k)]
+        return [("f32", "f64", "cf32", "cf64")[buf[i]] for i in range(k)]
 
     def line_dtypes(self):
         """storage type per delay line (in lines() order): 'f32', 'f64' (two state rows per slot), 're' / 'im' (the
@@ -285,7 +297,7 @@ class Program:
         n = max(self.n_lines, 1)
         buf = (ctypes.c_uint32 * n)()
         k = C.check(C.lib.fz_program_line_dtypes(self._h, buf, n))
-        return [("f32", "f64", "re", "im")[buf[i]] for i in range(k)]
+        return [("f32", "f64", "re", "im", "re64", "im64")[buf[i]] for i in range(k)]
 
     def lines(self):
         n = self.n_lines
@@ -617,7 +629,7 @@ def compile(expr, typed: bool = False, in_dtypes: Optional[Sequence[str]] = None
 
 
 def pack_typed(wires, dtypes):
-    """numpy helper: per-wire arrays [T, n_streams] (float32 / float64 / complex64) -> float32 frames [T, n_streams, slots]
+    """numpy helper: per-wire arrays [T, n_streams] (float32 / float64 / complex64 / complex128) -> float32 frames [T, n_streams, slots]
     as a typed program reads them."""
     import numpy as np
 
@@ -627,6 +639,8 @@ def pack_typed(wires, dtypes):
             cols.append(np.asarray(w, np.float32)[..., None])
         elif dt == "f64":
             cols.append(np.ascontiguousarray(np.asarray(w, np.float64)).view(np.float32).reshape(np.shape(w) + (2,)))
+        elif dt == "cf64":
+            cols.append(np.ascontiguousarray(np.asarray(w, np.complex128)).view(np.float32).reshape(np.shape(w) + (4,)))
         else:
             cols.append(np.ascontiguousarray(np.asarray(w, np.complex64)).view(np.float32).reshape(np.shape(w) + (2,)))
     return np.ascontiguousarray(np.concatenate(cols, axis=-1))
@@ -642,6 +656,10 @@ def unpack_typed(frames, dtypes):
         if dt == "f32":
             out.append(frames[..., k].copy())
             k += 1
+        elif dt == "cf64":
+            quad = np.ascontiguousarray(frames[..., k:k + 4])
+            out.append(quad.view(np.complex128)[..., 0])
+            k += 4
         else:
             pair = np.ascontiguousarray(frames[..., k:k + 2])
             out.append(pair.view(np.float64 if dt == "f64" else np.complex64)[..., 0])
