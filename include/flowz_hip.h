@@ -248,8 +248,22 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
 int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */
 /* the same with the variant's automatic fields resolved as fz_run_block would for this block shape */
 int fz_program_build_for(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples);
+/* Registers, LDS and scratch memory of a variant's kernel, from the code object's metadata (JITs it; no device needed).
+ * The unroll of a variant is an UPPER bound for time-major / tiled frames: a kernel whose prefetch buffers and delay lines
+ * do not fit the register file would keep some of them in scratch memory, so fz_run_block halves the unroll until nothing
+ * spills (stream-major frames keep theirs: it is also the length of a stream's run in memory).  as_launched = 1: the kernel that
+ * fz_run_block launches (`unroll` = what is left of the variant's); 0: the variant exactly as given.                   */
+typedef struct fz_kernel_resources {
+   uint32_t vgprs, agprs, sgprs;
+   uint32_t scratch_bytes;      /* per lane; 0 = nothing spills */
+   uint32_t lds_bytes;          /* static LDS of a workgroup */
+   uint32_t vgpr_spills, sgpr_spills;
+   uint32_t unroll;
+} fz_kernel_resources;
+int fz_program_kernel_resources(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, int as_launched,
+                                fz_kernel_resources* out);
 /* symbol of the variant's kernel as profilers show it, e.g. "fz_block_kernel_p2u32b256f0"; the
- * variant is resolved as fz_run_block would for (n_streams, n_samples); returns length          */
+ * variant is resolved as fz_run_block would for (n_streams, n_samples) -- unroll lowered as above; returns length */
 long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples,
                             char* buf, size_t cap);
 /* generated HIP source of a variant (skeleton + graph body); returns length, writes <= cap    */

@@ -2,6 +2,8 @@
 
 Graphs are built from the reference's combinators with their arity rules; all
 feedback paths go through small coefficients so that responses stay bounded."""
+import os
+
 import numpy as np
 
 from graphs import DEL, IN, add, chan, fb, lit, mul, par, seq, sub
@@ -99,7 +101,7 @@ def make_typed(seed, max_in=3, depth=3):
     rng = np.random.default_rng(seed + 77000)
     g, n_in, n_out = make(seed, max_in, depth)
     r2 = np.random.default_rng(seed + 99000)          # (its own stream: the graphs of the other kinds stay what they were)
-    if r2.random() < 0.2:
+    if r2.random() < 0.2 and not os.environ.get("RANDGRAPHS_NO_CDOUBLE"):   # (the switch: to re-create graphs of runs before this kind existed)
         # a feed-forward std::complex<double> stage behind the first output wire: the wire is widened by a double
         # literal first (complex<double> meets double operands only); z*w, z+s, s-z, -z, z/w and s/w (__divdc3: Smith's
         # method, both sides of its branch are reached: the divisor's real part runs through |c| = |d|)

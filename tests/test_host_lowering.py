@@ -360,6 +360,28 @@ def test_complex_double_programs_lowering_vs_oracle_and_std_complex():
             F.compile(F.from_sexpr(bad), typed=True, in_dtypes=dts)
 
 
+def test_no_headline_kernel_uses_scratch_memory_and_unroll_is_lowered_until_nothing_spills():
+    """fz_program_kernel_resources (the code object's metadata): every kernel fz_program_tune would try for the BASELINE
+    graphs at the BASELINE shapes, and their stream-major kernels, keep everything in registers; a frame kernel whose
+    prefetch buffers do not fit (3-wire frames, 4 streams per lane, 16 rows in flight) gets its unroll halved."""
+    from zignal_amd.workloads import BASELINE_GRAPHS
+    for name, mk in BASELINE_GRAPHS.items():
+        p = F.compile(F.from_sexpr(mk()))
+        for ns in (65536, 1 << 20):
+            for v in p.tune_candidates(ns, 4096):
+                r = p.kernel_resources(v, ns, 4096, as_launched=False)
+                assert r["scratch_bytes"] == 0 and r["vgpr_spills"] == 0 and 0 < r["vgprs"] <= 512, (name, ns, r)
+        r = p.kernel_resources(F.make_variant(0, 0, 0, F.C.FZ_VF_STREAM_MAJOR), 1 << 20, 4096, as_launched=False)
+        assert r["scratch_bytes"] == 0 and r["lds_bytes"] > 0, (name, r)
+    import randgraphs as R
+    p = F.compile(F.from_sexpr(R.make(1339)[0]))                 # 3 inputs, 2 outputs, 13 state rows
+    v = F.make_variant(4, 16, 256)
+    given, run = p.kernel_resources(v, 200, 61, as_launched=False), p.kernel_resources(v, 200, 61)
+    assert given["scratch_bytes"] > 0 and given["unroll"] == 16
+    assert run["scratch_bytes"] == 0 and run["unroll"] == 8 and run["vgprs"] < 512
+    assert p.kernel_name(v, 200, 61).startswith("fz_block_kernel_p4u8b256")
+
+
 def test_sample_rate_modulators_lower_like_the_oracle():
     """fz_modulator: the std::ref terminal at sample rate (flowz/README.md:42-61).  Lowered IR == oracle; the graph is never
     stage-packed; launching without a modulation array is refused."""

@@ -23,6 +23,15 @@ def same(a, b, dt):
     return np.array_equal(np.where(nan, 0, a).view(u), np.where(nan, 0, b).view(u))
 
 
+TRACE = bool(os.environ.get("FUZZ_TRACE"))      # print every launch before it runs and synchronise after it: pins a faulting kernel
+
+
+def trace(*what):
+    if TRACE:
+        torch.cuda.synchronize()
+        print("   ", *what, flush=True)
+
+
 first, count = int(sys.argv[1]), int(sys.argv[2])
 limit = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
 t_start, last = time.time(), first - 1
@@ -36,6 +45,7 @@ for seed in range(first, first + count):
         print(f"... seed {seed}: {ok} identical, {bad} mismatching, {skipped} skipped so far ({time.time() - t_start:.0f} s)", flush=True)
     for typed in (False, True):
         g, n_in = (R.make_typed(seed)[:2] if typed else R.make(seed)[:2])
+        trace("seed", seed, "typed" if typed else "plain", g)
         try:
             f = O.compile(g, ns)
             f64 = O.compile(g, ns, out_f64=True)
@@ -51,11 +61,14 @@ for seed in range(first, first + count):
         for P in (1, 2, 4):
             U = int(rng.choice([1, 3, 8, 16]))
             fl = int(rng.choice([0, F.C.FZ_VF_PREFETCH3, F.C.FZ_VF_MAX_WG(2), F.C.FZ_VF_NO_STAGE_PACK]))
+            trace("P", P, "U", U, "flags", fl)
             y, _ = p.run_block(xd, variant=F.make_variant(P, U, 256, fl))
             res.append((f"P={P} U={U} flags={fl}", same(y.cpu().numpy(), want, np.float32)))
+        trace("f64 frames")
         y64, _ = p.run_block(xd, out_f64=True)
         res.append(("f64 frames", same(y64.cpu().numpy(), want64, np.float64)))
         cut = int(rng.integers(1, T))
+        trace("chained at", cut)
         ya, st = p.run_block(xd[:cut].contiguous())
         yb, _ = p.run_block(xd[cut:].contiguous(), state=st)
         res.append((f"chained at {cut}", same(torch.cat([ya, yb]).cpu().numpy(), want, np.float32)))
@@ -63,6 +76,7 @@ for seed in range(first, first + count):
         xs = torch.from_numpy(np.ascontiguousarray(np.transpose(x[:60], (1, 0, 2)))).cuda()
         for P in (1, 2):
             U = int(rng.choice([4, 8, 16, 32]))
+            trace("stream-major P", P, "U", U)
             try:
                 ys, _ = p.run_block_stream_major(xs, variant=F.make_variant(P, U))
             except F.FlowzError as e:                     # two streams per lane with patches too large for one wave per SIMD: refused
@@ -77,6 +91,7 @@ for seed in range(first, first + count):
             wl = O.compile(g, ns).run(xl)
             xsl = torch.from_numpy(np.ascontiguousarray(np.transpose(xl, (1, 0, 2)))).cuda()
             for v in (None, F.make_variant(1, 64, 0, F.C.FZ_VF_SM_LONG)):
+                trace("stream-major long", "auto" if v is None else "U=64", "T", TL)
                 ys, _ = p.run_block_stream_major(xsl, variant=v)
                 res.append((f"stream-major long {'auto' if v is None else 'U=64'} T={TL}", same(ys.permute(1, 0, 2).contiguous().cpu().numpy(), wl, np.float32)))
         # fz_compile_typed: ResultType through inputs (random float / double wires), state and outputs
@@ -94,6 +109,7 @@ for seed in range(first, first + count):
         elif pt is not None:
             wires = [x[:, :, i].astype(np.float64 if dts[i] == "f64" else np.float32) * (1.0 + (1e-9 if dts[i] == "f64" else 0.0)) for i in range(n_in)]
             wantt = O.run_typed(ot, wires, T=T)
+            trace("typed", dts)
             yt, _ = pt.run_block(torch.from_numpy(F.pack_typed(wires, dts)).cuda(), variant=F.make_variant(int(rng.choice([1, 2, 4])), 8))
             gott = F.unpack_typed(yt.cpu().numpy(), pt.output_dtypes())
             okt = len(gott) == len(wantt)
@@ -106,6 +122,7 @@ for seed in range(first, first + count):
                 else:
                     okt = okt and same(a, b, a.dtype.type)
             res.append((f"typed {dts}", okt))
+        trace("done")
         if all(r for _, r in res):
             ok += 1
         else:

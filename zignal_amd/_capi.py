@@ -49,6 +49,10 @@ class IrNode(ctypes.Structure):
                 ("dtype", ctypes.c_uint32), ("value64", ctypes.c_double), ("c", ctypes.c_uint32)]
 
 
+class KernelResources(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in ("vgprs", "agprs", "sgprs", "scratch_bytes", "lds_bytes", "vgpr_spills", "sgpr_spills", "unroll")]
+
+
 class Variant(ctypes.Structure):
     _fields_ = [("streams_per_lane", ctypes.c_uint32), ("unroll", ctypes.c_uint32),
                 ("block_threads", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
@@ -99,6 +103,7 @@ def _load():
         "fz_program_set_const": (ctypes.c_int, [P, u32, f32]),
         "fz_program_build": (ctypes.c_int, [P, ctypes.POINTER(Variant)]),
         "fz_program_build_for": (ctypes.c_int, [P, ctypes.POINTER(Variant), u64, u32]),
+        "fz_program_kernel_resources": (ctypes.c_int, [P, ctypes.POINTER(Variant), u64, u32, ctypes.c_int, ctypes.POINTER(KernelResources)]),
         "fz_program_kernel_name": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, ctypes.c_char_p, ctypes.c_size_t]),
         "fz_program_source": (ctypes.c_long, [P, ctypes.POINTER(Variant), ctypes.c_char_p, ctypes.c_size_t]),
         "fz_run_block": (ctypes.c_int, [P, P, P, P, P, u64, u32, ctypes.POINTER(Variant), P]),

@@ -192,7 +192,20 @@ int fz_program_build_for(fz_program* p, const fz_variant* v, uint64_t n_streams,
 {
    FZ_GUARD(
       if (!p || !n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_build_for: bad arguments");
-      (void)get_kernel(p, resolve_variant(p->g, v, n_streams, n_samples), nullptr);
+      (void)get_kernel(p, settle_variant(p, resolve_variant(p->g, v, n_streams, n_samples)), nullptr);
+      return FZ_OK;)
+}
+
+int fz_program_kernel_resources(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, int as_launched,
+                                fz_kernel_resources* out)
+{
+   FZ_GUARD(
+      if (!p || !out || !n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_kernel_resources: bad arguments");
+      Variant rv = resolve_variant(p->g, v, n_streams, n_samples);
+      if (as_launched) rv = settle_variant(p, rv);
+      const auto k = get_kernel(p, rv, nullptr);
+      *out = fz_kernel_resources{k->res.vgprs, k->res.agprs, k->res.sgprs, k->res.scratch_bytes, k->res.lds_bytes, k->res.vgpr_spills,
+                                 k->res.sgpr_spills, rv.U};
       return FZ_OK;)
 }
 
@@ -200,7 +213,7 @@ long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_strea
 {
    try {
       if (!p) fail(FZ_E_INVALID, "null program");
-      const std::string s = kernel_name(p->g, resolve_variant(p->g, v, n_streams ? n_streams : (1ull << 20), n_samples ? n_samples : (1u << 20)));
+      const std::string s = kernel_name(p->g, settle_variant(p, resolve_variant(p->g, v, n_streams ? n_streams : (1ull << 20), n_samples ? n_samples : (1u << 20))));
       if (buf && cap) {
          const size_t n = std::min(cap - 1, s.size());
          std::memcpy(buf, s.data(), n);

@@ -149,7 +149,16 @@ const char* skeleton_source();                            // hand-written kernel
 std::string full_source(const Graph& g, const Variant& v);
 
 // ---- runtime ---------------------------------------------------------------------------------------------
+// what the code object's metadata says the kernel needs (AMDGPU msgpack notes)
+struct KernelResources {
+   uint32_t vgprs = 0, agprs = 0, sgprs = 0;
+   uint32_t scratch_bytes = 0;      // .private_segment_fixed_size: bytes of scratch memory per lane (register spills)
+   uint32_t lds_bytes = 0;
+   uint32_t vgpr_spills = 0, sgpr_spills = 0;
+};
+
 struct Kernel {
+   KernelResources res;
    struct Loaded {
       int device;
       void* module;     // hipModule_t
@@ -183,6 +192,8 @@ Variant resolve_variant(const Graph& g, const fz_variant* v, uint64_t n_streams,
 // builds (or fetches from the caches) the kernel of variant v; fn_out != null: also load it on the
 // current device and return its hipFunction_t
 std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out);
+// the variant that runs: `v` with its unroll lowered until the kernel keeps its values in registers (no scratch memory)
+Variant settle_variant(fz_program* p, Variant v);
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params,
            uint64_t n_streams, uint32_t n_samples, const fz_variant* v, void* stream, uint32_t tile_streams = 0,
            uint32_t rows_total = 0, uint32_t row0 = 0);

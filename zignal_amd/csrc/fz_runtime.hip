@@ -78,6 +78,16 @@ static std::vector<const char*> build_options(const Variant& v)
    std::vector<const char*> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                  "-fhip-fp32-correctly-rounded-divide-sqrt"};
    if (!(v.flags & FZ_VF_SLP)) o.push_back("-fno-slp-vectorize");
+   // developer hook (kernel experiments: -DFZ_DBG_NOLOAD ... and compiler flags); part of the cache key like every option
+   static const std::vector<std::string> extra = [] {
+      std::vector<std::string> e;
+      if (const char* env = std::getenv("FLOWZ_HIP_EXTRA_OPTS")) {
+         std::istringstream is(env);
+         for (std::string t; is >> t;) e.push_back(t);
+      }
+      return e;
+   }();
+   for (const std::string& e : extra) o.push_back(e.c_str());
    return o;
 }
 
@@ -201,6 +211,56 @@ static std::vector<char> jit_compile(const Graph& g, const Variant& v)
    return code;
 }
 
+// One field of the kernel's metadata map (code object v3+: an ELF note holding msgpack; one kernel per code object here).
+// The key is a msgpack string, the value the msgpack unsigned integer right behind it.
+static uint32_t note_uint(const std::vector<char>& code, const char* key)
+{
+   const size_t kl = std::strlen(key);
+   const unsigned char* b = reinterpret_cast<const unsigned char*>(code.data());
+   for (size_t i = 1; i + kl + 1 <= code.size(); ++i) {
+      if (std::memcmp(b + i, key, kl) != 0) continue;
+      const bool fixstr = b[i - 1] == (0xa0u | kl), str8 = i >= 2 && b[i - 2] == 0xd9 && b[i - 1] == kl;
+      if (!fixstr && !str8) continue;                         // (the text inside a longer key or a value)
+      const unsigned char* v = b + i + kl;
+      const size_t left = code.size() - (i + kl);
+      if (v[0] <= 0x7f) return v[0];
+      if (v[0] == 0xcc && left >= 2) return v[1];
+      if (v[0] == 0xcd && left >= 3) return (uint32_t)v[1] << 8 | v[2];
+      if (v[0] == 0xce && left >= 5) return (uint32_t)v[1] << 24 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 8 | v[4];
+      return 0xFFFFFFFFu;
+   }
+   return 0;
+}
+
+static KernelResources read_resources(const std::vector<char>& code)
+{
+   KernelResources r;
+   r.vgprs = note_uint(code, ".vgpr_count");
+   r.agprs = note_uint(code, ".agpr_count");
+   r.sgprs = note_uint(code, ".sgpr_count");
+   r.scratch_bytes = note_uint(code, ".private_segment_fixed_size");
+   r.lds_bytes = note_uint(code, ".group_segment_fixed_size");
+   r.vgpr_spills = note_uint(code, ".vgpr_spill_count");
+   r.sgpr_spills = note_uint(code, ".sgpr_spill_count");
+   return r;
+}
+
+// A frame kernel that spills keeps part of its prefetch buffers / delay lines in scratch memory.  There the unroll is only
+// the prefetch depth, so it is an UPPER bound: halved until nothing spills.  A graph that spills even at unroll 1 runs as it
+// is.  Stream-major kernels are left alone: their unroll is also the length of a stream's run in memory, and the 4-wire sum
+// measured 0.98 ms with 32-sample chunks and 64 spilled registers against 1.33 ms with 16-sample chunks and none.
+Variant settle_variant(fz_program* p, Variant v)
+{
+   static const bool off = std::getenv("FLOWZ_HIP_KEEP_SPILLS") != nullptr;   // (developer switch: measure the spilling kernel itself)
+   if (off) return v;
+   for (;;) {
+      const auto k = get_kernel(p, v, nullptr);
+      if (k->res.scratch_bytes == 0) return v;
+      if ((v.flags & FZ_VF_STREAM_MAJOR) || v.U <= 1) return v;
+      v.U /= 2;
+   }
+}
+
 std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out)
 {
    std::lock_guard<std::mutex> lock(p->mu);
@@ -221,6 +281,7 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
          k->code = jit_compile(p->g, v);
          if (use_cache) cache_store(dir, path, k->code);
       }
+      k->res = read_resources(k->code);
       slot = k;
    }
    if (fn_out) {
@@ -595,6 +656,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
          v.U /= 2;
       }
    }
+   v = settle_variant(p, v);
    void* fn = nullptr;
    auto k = get_kernel(p, v, &fn);
 
@@ -629,8 +691,8 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    static const bool debug = std::getenv("FLOWZ_HIP_DEBUG") != nullptr;
    if (debug) {
       FZ_HIP(hipStreamSynchronize((hipStream_t)stream));
-      std::fprintf(stderr, "[flowz_hip] launched grid=%u block=%u P=%u U=%u flags=%u n_streams=%llu n_samples=%u kernarg=%zu B\n",
-                   grid, v.block, v.P, v.U, v.flags, (unsigned long long)n_streams, n_samples, size);
+      std::fprintf(stderr, "[flowz_hip] launched grid=%u block=%u P=%u U=%u flags=%u n_streams=%llu n_samples=%u kernarg=%zu B vgprs=%u scratch=%u B/lane\n",
+                   grid, v.block, v.P, v.U, v.flags, (unsigned long long)n_streams, n_samples, size, k->res.vgprs + k->res.agprs, k->res.scratch_bytes);
    }
    return FZ_OK;
 }

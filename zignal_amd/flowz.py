@@ -370,6 +370,15 @@ class Program:
             C.check(C.lib.fz_program_build(self._h, vp))
         return self
 
+    def kernel_resources(self, variant: Optional[Variant] = None, n_streams: int = 1 << 20, n_samples: int = 4096,
+                         as_launched: bool = True) -> dict:
+        """registers / LDS / scratch bytes per lane of a variant's kernel (JITs it; needs no GPU).  as_launched: with the
+        unroll lowered until nothing spills, as run_block does ('unroll' = what runs); False: the variant exactly as given."""
+        vp = ctypes.byref(variant) if variant is not None else None
+        r = C.KernelResources()
+        C.check(C.lib.fz_program_kernel_resources(self._h, vp, int(n_streams), int(n_samples), int(as_launched), ctypes.byref(r)))
+        return {n: getattr(r, n) for n, _ in C.KernelResources._fields_}
+
     # -- the hot path ----------------------------------------------------------------------
     def run_block_ptr(self, in_ptr, out_ptr, state_ptr, params_ptr, n_streams, n_samples,
                       variant: Optional[Variant] = None, stream=None, tile_streams: int = 0):
