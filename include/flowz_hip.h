@@ -237,8 +237,6 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
        FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
                                    float*): the results of graphs with double literals leave un-narrowed, float
                                    wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */
-/* bits 8..11 of flags: minimum waves per SIMD requested from the register allocator (0 = none) */
-#define FZ_VF_MIN_WAVES(n) (((uint32_t)(n) & 15u) << 8)
 /* bits 20..22 of flags: at most n workgroups per CU (the kernel pads its LDS); 0 = as many as fit.
  * Fewer, fatter waves keep fewer frame tiles in flight: which occupancy streams fastest from HBM depends
  * on the board -- let fz_program_tune measure it                                                   */
