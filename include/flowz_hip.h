@@ -234,6 +234,10 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
                                    64 selectable), one in-place LDS patch per wave, one wave per SIMD; chosen automatically for
                                    blocks of >= 256 samples; FZ_VF_SM_SHORT keeps the 32-sample chunks                          */
        FZ_VF_SM_SHORT = 512u,
+       FZ_VF_WAVE_SPLIT = 1024u, /* fewer streams than lanes: a serial graph of K isomorphic segments (K even) is cut in the middle,
+                                   two waves of a workgroup evaluate the halves for the same 64 streams (the cut wire
+                                   travels through LDS, the second wave one chunk behind); one stream per lane, block_threads
+                                   counts the streams of a workgroup (64 or 128 = one or two wave pairs; default 128)     */
        FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
                                    float*): the results of graphs with double literals leave un-narrowed, float
                                    wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */

@@ -654,6 +654,65 @@ def test_stage_pack_is_automatic_for_few_streams_and_rejected_when_impossible(to
         prog.run_block(x, variant=F.make_variant(2, 8, 256, STAGE_PACK))
 
 
+# ---- wave split: two waves per 64 streams, each one half of the serial graph (fewer streams than lanes) ---------------
+WAVE_SPLIT = 1024
+SPLITTABLE = {
+    "cascade4": lambda: G.df1_cascade(4),                                          # halves: one packed pair each
+    "cascade6": lambda: G.df1_cascade(6),                                          # halves: a packed pair and a scalar stage
+    "cascade8": lambda: G.df1_cascade(8),                                          # halves: two packed pairs, lag 3
+    "cascade16": lambda: G.df1_cascade(16),                                        # halves: four packed pairs, lag 7 (hand-off distance 8)
+    "cascade4_distinct_coeffs": lambda: G.df1_cascade(4, [G.STABLE, G.PAR4_SETS[0], G.PAR4_SETS[1], G.PAR4_SETS[2]]),
+    "cascade6_distinct_coeffs": lambda: G.df1_cascade(6, [G.STABLE, G.PAR4_SETS[0], G.PAR4_SETS[1], G.PAR4_SETS[2], G.PAR4_SETS[3], G.STABLE]),
+    "df2_x4": lambda: G.seq(G.seq(G.df2(*G.STABLE), G.df2(*G.PAR4_SETS[3])), G.seq(G.df2(*G.PAR4_SETS[1]), G.df2(*G.STABLE))),
+}
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 5, 13, 16, 17, 40, 64, 101, 300])
+@pytest.mark.parametrize("name", sorted(SPLITTABLE))
+def test_wave_split_kernel_vs_oracle(torch_cuda, F, name, T):
+    """FZ_VF_WAVE_SPLIT: the cut wire goes through LDS, the second wave runs a round behind; every block length (all-masked
+    blocks, blocks that end inside a round, many rounds), ragged stream counts, unroll 8 / 16 / 32 -- outputs and the
+    canonical state against the oracle / the plain kernel."""
+    g = SPLITTABLE[name]()
+    prog = F.compile(F.from_sexpr(g))
+    ns = 133
+    x = O.synth_input(SEED + 5, np.arange(ns), T)
+    want = O.compile(g, ns).run(x)
+    ref, st_ref = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+    assert ndiff(ref, want) == 0
+    for U, B in ((8, 64), (16, 128), (32, 0), (16, 64)):
+        got, st = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, U, B, WAVE_SPLIT))
+        assert ndiff(got, want) == 0, (name, T, U, B)
+        assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0, (name, T, U, B)
+
+
+def test_wave_split_blocks_chain_tiles_and_refusals(torch_cuda, F):
+    """blocks of a wave-split kernel chain with every other variant through the canonical state; stream-tiled frames;
+    graphs that are not two isomorphic halves are refused."""
+    torch = torch_cuda
+    g = G.df1_cascade(6)
+    prog = F.compile(F.from_sexpr(g))
+    ws = F.make_variant(1, 16, 0, WAVE_SPLIT)
+    assert prog.kernel_name(ws, 4096, 256).startswith("fz_block_kernel_p1u16b128w2f")
+    ns = 4096 + 64 * 3
+    x = O.synth_input(11, np.arange(ns), 230)
+    want = C.df1_cascade([G.STABLE] * 6, x)
+    a, st = run_gpu(torch, F, prog, x[:33], variant=ws)
+    b, st = run_gpu(torch, F, prog, x[33:34], variant=ws, state=st)                  # a 1-sample block
+    c, st = run_gpu(torch, F, prog, x[34:70], variant=F.make_variant(1, 8, 256, STAGE_PACK), state=st)
+    d, st = run_gpu(torch, F, prog, x[70:199], variant=ws, state=st)
+    e, st = run_gpu(torch, F, prog, x[199:], variant=F.make_variant(2, 8), state=st)
+    assert ndiff(np.concatenate([a, b, c, d, e]), want) == 0
+    xt = torch.from_numpy(x[:, :4096]).cuda()
+    yt, _ = prog.run_block(F.to_tiled(xt, 1024), variant=ws)                          # tiles of 1024 streams
+    assert ndiff(F.from_tiled(yt).contiguous().cpu().numpy(), want[:, :4096]) == 0
+    for bad in (G.df1_cascade(2), G.par4_sum_fanout(), G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1)))):
+        with pytest.raises(F.FlowzError):
+            F.compile(F.from_sexpr(bad)).run_block(torch.zeros((4, 64, 1), device="cuda"), variant=ws)
+    with pytest.raises(F.FlowzError):
+        prog.run_block(torch.zeros((4, 64, 1), device="cuda"), variant=F.make_variant(2, 16, 64, WAVE_SPLIT))
+
+
 # ---- empty blocks, maximum sizes -------------------------------------------------------------------------
 def test_empty_block_is_a_noop(torch_cuda, F):
     torch = torch_cuda

@@ -382,6 +382,32 @@ def test_no_headline_kernel_uses_scratch_memory_and_unroll_is_lowered_until_noth
     assert p.kernel_name(v, 200, 61).startswith("fz_block_kernel_p4u8b256")
 
 
+def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorphic_halves():
+    """FZ_VF_WAVE_SPLIT (host side): the serial graph is cut at the middle wire of its stage split, each half is a stage-packed
+    body of its own; automatic up to 32 768 streams for blocks of >= 256 samples; never for graphs with a scalar prefix /
+    suffix, per-stream coefficients, several wires, an odd or a single pair of segments."""
+    from zignal_amd.workloads import BASELINE_GRAPHS
+    p = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    assert p.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u16b128w2f1024"
+    assert p.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u16b128w2f1024"
+    assert p.kernel_name(None, 65536, 4096).startswith("fz_block_kernel_p1u16b256s6f")       # one wave per SIMD already
+    assert p.kernel_name(None, 32768, 200).startswith("fz_block_kernel_p1u16b256s6f")        # short blocks: the ends would dominate
+    assert p.kernel_name(F.make_variant(0, 0, 0, 16), 32768, 4096) == "fz_block_kernel_p1u16b256f0"   # FZ_VF_NO_STAGE_PACK: the plain kernel
+    src = p.source(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT))
+    assert "namespace fz_r0 {" in src and "namespace fz_r1 {" in src and "#define FZ_WS_K0 2" in src and "#define FZ_WS_K1 2" in src
+    r = p.kernel_resources(None, 32768, 4096)
+    assert r["scratch_bytes"] == 0 and r["lds_bytes"] == 2 * 8 * 64 * 16 and r["vgprs"] < 128   # two pairs x ring of 8 groups x 64 lanes x 16 B
+    assert [v.flags & F.C.FZ_VF_WAVE_SPLIT for v in p.tune_candidates(32768, 4096)][1:3] == [1024, 1024]
+    for name in ("par4_sum", "par4_sum_fanout", "osc_chain6"):
+        q = F.compile(F.from_sexpr(BASELINE_GRAPHS[name]()))
+        assert "w2" not in q.kernel_name(None, 32768, 4096)
+        with pytest.raises(F.FlowzError):
+            q.kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT), 32768, 4096)
+    for bad in (G.df1_cascade(2), G.df1_cascade(3), G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1)))):
+        with pytest.raises(F.FlowzError):
+            F.compile(F.from_sexpr(bad)).kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT), 4096, 4096)
+
+
 def test_sample_rate_modulators_lower_like_the_oracle():
     """fz_modulator: the std::ref terminal at sample rate (flowz/README.md:42-61).  Lowered IR == oracle; the graph is never
     stage-packed; launching without a modulation array is refused."""

@@ -115,9 +115,14 @@ struct Graph {
    std::vector<FarRead> far_reads;   // distinct (far line, delay) pairs, in first-use order
    std::vector<uint32_t> far_lines;  // indices of far lines
    uint32_t far_min_read = 0;        // smallest delay read from a far line's HBM ring (> kRegMaxDepth); 0: none
+   // Wave split (FZ_VF_WAVE_SPLIT): the two halves of a serial graph cut at the middle wire of its stage split, each a
+   // graph of its own (1 in, 1 out; constants and state rows are the parent's) that one wave of a pair evaluates.
+   // Empty when the graph does not allow it.
+   std::vector<Graph> wave_roles;
 };
 
 StageSplit find_stage_split(const Graph& g);
+std::vector<Graph> find_wave_roles(const Graph& g);   // fz_split.cpp; {} or two graphs
 
 // register-resident delay lines up to this depth; deeper ones become LDS rings
 constexpr uint32_t kRegMaxDepth = 8;

@@ -660,6 +660,7 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
    g.n_state = row;
    g.n_lds_slots = lds;
    g.split = find_stage_split(g);
+   g.wave_roles = find_wave_roles(g);
    return g;
 }
 

@@ -265,4 +265,130 @@ StageSplit find_stage_split(const Graph& g)
    return none;
 }
 
+// ---- wave split ---------------------------------------------------------------------------------------------------
+// Fewer streams than the chip has lanes: half the SIMDs idle while every wave carries the whole serial graph.  A graph that
+// is a series of K isomorphic segments (K even, no scalar prefix or suffix) is cut at its middle wire m = cuts[K/2]:
+//    in -> [ role 0: segments 0 .. K/2-1 ] -> m -> [ role 1: segments K/2 .. K-1 ] -> out
+// Two waves of a workgroup evaluate the two halves for the same 64 streams; m travels through LDS, role 1 one chunk of
+// samples behind role 0 (fz_block_kernel.hip.inc, FZ_VF_WAVE_SPLIT).  Each half is a graph of its own here -- node ids
+// renumbered, constant slots and state rows the parent's -- so that the ordinary generators (and the stage packing of each
+// half: a 3-biquad half is one packed pair and a scalar stage) apply to it unchanged.  Delay lines of the cut wire are kept
+// by both halves (role 0 reads them as its own output's past, role 1 as its input's past): the same values in both.
+static bool extract_role(const Graph& g, const std::vector<char>& in_a, uint32_t cut, bool second, Graph& r)
+{
+   const uint32_t N = (uint32_t)g.nodes.size();
+   std::vector<int> nid(N, -1);
+   r = Graph();
+   r.n_in = r.n_out = r.n_out_wires = 1;
+   r.consts = g.consts;                                   // same slots: the kernarg image is the parent's
+   r.uniform_slot = g.uniform_slot;
+   r.in_dtype = {0};
+   auto add = [&](uint32_t v, const Node& n) {
+      nid[v] = (int)r.nodes.size();
+      r.nodes.push_back(n);
+   };
+   if (second) {
+      Node in{};
+      in.kind = FZ_IR_INPUT;
+      add(cut, in);                                       // the cut wire is this half's input
+   }
+   for (uint32_t v = 0; v < N; ++v) {
+      if ((in_a[v] != 0) == second || (second && v == cut)) continue;   // the other half's node
+      Node n = g.nodes[v];
+      auto op = [&](uint32_t o) -> int { return o < N ? nid[o] : -1; };
+      switch (n.kind) {
+         case FZ_IR_INPUT: if (second) return false; break;
+         case FZ_IR_CONST: break;
+         case FZ_IR_DELAY: break;                          // source patched below (it may come later in the order)
+         case FZ_IR_NEG:
+            if (op(n.a) < 0) return false;
+            n.a = (uint32_t)op(n.a);
+            break;
+         case FZ_IR_ADD: case FZ_IR_SUB: case FZ_IR_MUL: case FZ_IR_DIV:
+            if (op(n.a) < 0 || op(n.b) < 0) return false;
+            n.a = (uint32_t)op(n.a);
+            n.b = (uint32_t)op(n.b);
+            ++r.n_ops;
+            break;
+         default: return false;                            // per-stream coefficients, modulators, typed nodes: not split
+      }
+      if (n.kind == FZ_IR_NEG) ++r.n_ops;
+      add(v, n);
+   }
+   // delayed reads: the source is a node of this half (the cut wire counts for both)
+   for (uint32_t v = 0; v < N; ++v) {
+      if (nid[v] < 0 || g.nodes[v].kind != FZ_IR_DELAY || (second && v == cut)) continue;
+      const uint32_t src = g.nodes[v].a;
+      if (src >= N || nid[src] < 0) return false;
+      r.nodes[(size_t)nid[v]].a = (uint32_t)nid[src];
+   }
+   const uint32_t out = second ? g.outputs[0] : cut;
+   if (nid[out] < 0) return false;
+   r.outputs = {(uint32_t)nid[out]};
+   r.out_part = {0};
+   // lines: the parent's, for the sources this half reads through a delay; rows and depths are the parent's
+   r.line_of_node.assign(r.nodes.size(), -1);
+   for (const Line& L : g.lines) {
+      if (L.in_lds || L.far || L.f64 || nid[L.src] < 0) continue;
+      bool read_here = false;
+      for (uint32_t v = 0; v < N && !read_here; ++v)
+         read_here = nid[v] >= 0 && !(second && v == cut) && g.nodes[v].kind == FZ_IR_DELAY && g.nodes[v].a == L.src;
+      if (!read_here) continue;
+      Line l = L;
+      l.src = (uint32_t)nid[L.src];
+      r.line_of_node[l.src] = (int)r.lines.size();
+      r.lines.push_back(l);
+      r.max_delay = std::max(r.max_delay, l.depth);
+   }
+   r.n_state = g.n_state;
+   r.split = find_stage_split(r);
+   return true;
+}
+
+std::vector<Graph> find_wave_roles(const Graph& g)
+{
+   const StageSplit& sp = g.split;
+   if (!sp.ok || sp.K < 2 || sp.K % 2 || !sp.prefix.empty() || !sp.suffix.empty() || g.typed || g.n_param || g.n_mod ||
+       g.n_lds_slots || !g.far_lines.empty() || g.n_in != 1 || g.n_out != 1)
+      return {};
+   const uint32_t N = (uint32_t)g.nodes.size(), cut = sp.cuts[sp.K / 2];
+   // role 0 = everything the cut wire depends on (operands and delay lines); its delayed reads of itself included
+   std::vector<char> in_a(N, 0);
+   std::vector<uint32_t> work{cut};
+   while (!work.empty()) {
+      const uint32_t v = work.back();
+      work.pop_back();
+      if (in_a[v]) continue;
+      in_a[v] = 1;
+      const Node& n = g.nodes[v];
+      if (is_arith(n.kind)) {
+         work.push_back(n.a);
+         if (n.kind != FZ_IR_NEG) work.push_back(n.b);
+      } else if (n.kind == FZ_IR_DELAY) work.push_back(n.a);
+   }
+   // leaves (constants) and delayed reads of the cut wire are shared: give role 1 its own copies
+   for (uint32_t v = 0; v < N; ++v) {
+      const Node& n = g.nodes[v];
+      if (n.kind == FZ_IR_CONST || (n.kind == FZ_IR_DELAY && n.a == cut)) in_a[v] = 2;   // 2: in both halves
+   }
+   // role 1 may see role 0 only through the cut wire, now or delayed
+   for (uint32_t v = 0; v < N; ++v) {
+      if (in_a[v] == 1) continue;
+      const Node& n = g.nodes[v];
+      auto fine = [&](uint32_t o) { return in_a[o] != 1 || o == cut; };
+      if (is_arith(n.kind) && !(fine(n.a) && (n.kind == FZ_IR_NEG || fine(n.b)))) return {};
+      if (n.kind == FZ_IR_DELAY && in_a[v] != 2 && in_a[n.a] == 1) return {};
+   }
+   std::vector<Graph> roles(2);
+   // extract_role keeps node v for the first half when in_a[v] != 0, for the second when the flag passed is 0
+   std::vector<char> flag_a(N), flag_b(N);
+   for (uint32_t v = 0; v < N; ++v) {
+      flag_a[v] = in_a[v] != 0;                    // first half: nodes with flag set
+      flag_b[v] = in_a[v] == 1;                    // second half: nodes WITHOUT flag (role-1 nodes and the shared ones)
+   }
+   if (!extract_role(g, flag_a, cut, false, roles[0]) || !extract_role(g, flag_b, cut, true, roles[1])) return {};
+   if (!roles[0].split.ok || !roles[1].split.ok || roles[0].n_ops + roles[1].n_ops != g.n_ops) return {};
+   return roles;
+}
+
 }  // namespace fz
