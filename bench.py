@@ -320,7 +320,7 @@ def main():
     ap.add_argument("--no-config2", action="store_true", help="skip the 65 536-stream measurement (BASELINE configs[1])")
     ap.add_argument("--no-config34", action="store_true", help="skip BASELINE configs[2] and [3] (4-parallel sum, oscillator chain)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s back-to-back run")
-    ap.add_argument("--only", default="", help="profiling aid: run ONLY this secondary config (config2|config3|config3f|config4) "
+    ap.add_argument("--only", default="", help="profiling aid: run ONLY this secondary config (config2|config2h|config3|config3f|config4) "
                                                "with the forced / default variant and print its object")
     ap.add_argument("--no-autotune", action="store_true",
                     help="do not try the alternative kernel variants during warm-up (the pool's boxes differ by a few %%)")
@@ -462,7 +462,8 @@ def main():
 
     ns3 = args.streams
     if args.only:
-        fn = {"config2": config2, "config3": lambda: config3(False), "config3f": lambda: config3(True), "config4": config4}[args.only]
+        fn = {"config2": config2, "config2h": lambda: config2(32768), "config3": lambda: config3(False), "config3f": lambda: config3(True),
+              "config4": config4}[args.only]
         print(json.dumps({args.only: fn()}), flush=True)
         return
 

@@ -234,13 +234,17 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
                                    64 selectable), one in-place LDS patch per wave, one wave per SIMD; chosen automatically for
                                    blocks of >= 256 samples; FZ_VF_SM_SHORT keeps the 32-sample chunks                          */
        FZ_VF_SM_SHORT = 512u,
-       FZ_VF_WAVE_SPLIT = 1024u, /* fewer streams than lanes: a serial graph of K isomorphic segments (K even) is cut in the middle,
-                                   two waves of a workgroup evaluate the halves for the same 64 streams (the cut wire
-                                   travels through LDS, the second wave one chunk behind); one stream per lane, block_threads
-                                   counts the streams of a workgroup (64 or 128 = one or two wave pairs; default 128)     */
+       FZ_VF_WAVE_SPLIT = 1024u, /* fewer streams than lanes: a serial graph of K isomorphic segments is cut into W parts of K / W
+                                   segments, W waves of a workgroup evaluate the parts for the same 64 streams (the cut wires
+                                   travel through LDS, every wave one chunk behind the one before); one stream per lane,
+                                   block_threads counts the streams of a workgroup (a multiple of 64).  This bit: W = 2;
+                                   FZ_VF_WAVES(3), FZ_VF_WAVES(4): three / four parts.  Chosen automatically for few streams */
+       FZ_VF_WAVE_SPLIT3 = 2048u,
        FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
                                    float*): the results of graphs with double literals leave un-narrowed, float
                                    wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */
+/* bits 10..11 of flags: wave split into n = 2, 3 or 4 parts (see FZ_VF_WAVE_SPLIT) */
+#define FZ_VF_WAVES(n) ((n) >= 2 && (n) <= 4 ? ((uint32_t)((n) - 1) << 10) : 0u)
 /* bits 20..22 of flags: at most n workgroups per CU (the kernel pads its LDS); 0 = as many as fit.
  * Fewer, fatter waves keep fewer frame tiles in flight: which occupancy streams fastest from HBM depends
  * on the board -- let fz_program_tune measure it                                                   */

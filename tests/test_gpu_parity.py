@@ -670,9 +670,9 @@ SPLITTABLE = {
 @pytest.mark.parametrize("T", [1, 2, 3, 5, 13, 16, 17, 40, 64, 101, 300])
 @pytest.mark.parametrize("name", sorted(SPLITTABLE))
 def test_wave_split_kernel_vs_oracle(torch_cuda, F, name, T):
-    """FZ_VF_WAVE_SPLIT: the cut wire goes through LDS, the second wave runs a round behind; every block length (all-masked
-    blocks, blocks that end inside a round, many rounds), ragged stream counts, unroll 8 / 16 / 32 -- outputs and the
-    canonical state against the oracle / the plain kernel."""
+    """FZ_VF_WAVES(2 / 3 / 4): the cut wires go through LDS, every wave runs a round behind the one before; every block length
+    (all-masked blocks, blocks that end inside a round, many rounds), ragged stream counts, unroll 8 / 16 / 32, one or two
+    tuples per workgroup -- outputs and the canonical state against the oracle / the plain kernel."""
     g = SPLITTABLE[name]()
     prog = F.compile(F.from_sexpr(g))
     ns = 133
@@ -680,10 +680,18 @@ def test_wave_split_kernel_vs_oracle(torch_cuda, F, name, T):
     want = O.compile(g, ns).run(x)
     ref, st_ref = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
     assert ndiff(ref, want) == 0
-    for U, B in ((8, 64), (16, 128), (32, 0), (16, 64)):
-        got, st = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, U, B, WAVE_SPLIT))
-        assert ndiff(got, want) == 0, (name, T, U, B)
-        assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0, (name, T, U, B)
+    tried = 0
+    for W in (2, 3, 4):                                   # parts = waves per 64 streams: whatever the graph divides into
+        try:
+            prog.kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVES(W)), ns, T)
+        except F.FlowzError:
+            continue
+        for U, B in ((8, 64), (16, 128), (32, 0), (16, 64)):
+            got, st = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, U, B, F.C.FZ_VF_WAVES(W)))
+            assert ndiff(got, want) == 0, (name, T, W, U, B)
+            assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0, (name, T, W, U, B)
+            tried += 1
+    assert tried >= 4
 
 
 def test_wave_split_blocks_chain_tiles_and_refusals(torch_cuda, F):
@@ -706,6 +714,11 @@ def test_wave_split_blocks_chain_tiles_and_refusals(torch_cuda, F):
     xt = torch.from_numpy(x[:, :4096]).cuda()
     yt, _ = prog.run_block(F.to_tiled(xt, 1024), variant=ws)                          # tiles of 1024 streams
     assert ndiff(F.from_tiled(yt).contiguous().cpu().numpy(), want[:, :4096]) == 0
+    w3 = F.make_variant(1, 16, 0, F.C.FZ_VF_WAVES(3))                                # three parts of two biquads, one workgroup of three waves per 64 streams
+    assert prog.kernel_name(w3, 4096, 256).startswith("fz_block_kernel_p1u16b64w3f")
+    f, st = run_gpu(torch, F, prog, x[:101], variant=w3)
+    h, st = run_gpu(torch, F, prog, x[101:], variant=ws, state=st)
+    assert ndiff(np.concatenate([f, h]), want) == 0
     for bad in (G.df1_cascade(2), G.par4_sum_fanout(), G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1)))):
         with pytest.raises(F.FlowzError):
             F.compile(F.from_sexpr(bad)).run_block(torch.zeros((4, 64, 1), device="cuda"), variant=ws)

@@ -389,7 +389,7 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
     from zignal_amd.workloads import BASELINE_GRAPHS
     p = F.compile(F.from_sexpr(G.df1_cascade(6)))
     assert p.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u16b128w2f1024"
-    assert p.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u16b128w2f1024"
+    assert p.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w3f2048"              # 256 workgroups of three waves: two biquads each
     assert p.kernel_name(None, 65536, 4096).startswith("fz_block_kernel_p1u16b256s6f")       # one wave per SIMD already
     assert p.kernel_name(None, 32768, 200).startswith("fz_block_kernel_p1u16b256s6f")        # short blocks: the ends would dominate
     assert p.kernel_name(F.make_variant(0, 0, 0, 16), 32768, 4096) == "fz_block_kernel_p1u16b256f0"   # FZ_VF_NO_STAGE_PACK: the plain kernel
@@ -398,6 +398,9 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
     r = p.kernel_resources(None, 32768, 4096)
     assert r["scratch_bytes"] == 0 and r["lds_bytes"] == 2 * 8 * 64 * 16 and r["vgprs"] < 128   # two pairs x ring of 8 groups x 64 lanes x 16 B
     assert [v.flags & F.C.FZ_VF_WAVE_SPLIT for v in p.tune_candidates(32768, 4096)][1:3] == [1024, 1024]
+    assert [v.flags for v in p.tune_candidates(16384, 4096)][:3] == [0, F.C.FZ_VF_WAVES(3), F.C.FZ_VF_WAVES(2)]
+    q = F.compile(F.from_sexpr(G.df1_cascade(8)))
+    assert q.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w4f3072" and "#define FZ_WS_W 4" in q.source(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVES(4)))
     for name in ("par4_sum", "par4_sum_fanout", "osc_chain6"):
         q = F.compile(F.from_sexpr(BASELINE_GRAPHS[name]()))
         assert "w2" not in q.kernel_name(None, 32768, 4096)

@@ -28,6 +28,8 @@ pass head_p4u12wg1 $HEAD --lanes 4 --unroll 12 --block 256 --flags 1048576
 pass head_p4u16wg1 $HEAD --lanes 4 --unroll 16 --block 256 --flags 1048576
 pass c2_default    --only config2
 pass c2_u24        --only config2 --lanes 1 --unroll 24 --flags 8
+pass c2h_default   --only config2h
+pass c2h_u32       --only config2h --lanes 1 --unroll 32 --flags 1024
 pass c3_default    --only config3
 pass c3_u16wg1     --only config3 --lanes 1 --unroll 16 --block 256 --flags 1048576
 pass c3_u8wg1      --only config3 --lanes 1 --unroll 8 --block 256 --flags 1048576
@@ -39,6 +41,7 @@ pass c4_p4u8b128   --only config4 --lanes 4 --unroll 8 --block 128 --flags 20971
 # SQ counters of the headline default and of config 2 (issue / wait split, real clock)
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_head -o b -- python $R/bench.py $HEAD --no-autotune > $O/pmc_sq_head.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_c2 -o b -- python $R/bench.py --only config2 > $O/pmc_sq_c2.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_c2h -o b -- python $R/bench.py --only config2h > $O/pmc_sq_c2h.log 2>&1
 # rocprofv3 nests its output under <hostname>/: flatten
 for d in $O/trace $O/pmc_*; do [ -d "$d" ] && find $d -mindepth 2 -name '*.csv' -exec mv {} $d/ \; ; done
 ls $O | head -80

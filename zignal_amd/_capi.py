@@ -30,6 +30,11 @@ FZ_VF_STREAM_MAJOR = 128
 FZ_VF_SM_LONG, FZ_VF_SM_SHORT, FZ_VF_WAVE_SPLIT = 256, 512, 1024
 
 
+def FZ_VF_WAVES(n):
+    """wave split into n = 2, 3 or 4 parts"""
+    return (n - 1) << 10 if 2 <= n <= 4 else 0
+
+
 def FZ_VF_MAX_WG(n):
     """at most n workgroups per CU (flags bits 20..22)"""
     return (int(n) & 7) << 20

@@ -115,14 +115,17 @@ struct Graph {
    std::vector<FarRead> far_reads;   // distinct (far line, delay) pairs, in first-use order
    std::vector<uint32_t> far_lines;  // indices of far lines
    uint32_t far_min_read = 0;        // smallest delay read from a far line's HBM ring (> kRegMaxDepth); 0: none
-   // Wave split (FZ_VF_WAVE_SPLIT): the two halves of a serial graph cut at the middle wire of its stage split, each a
-   // graph of its own (1 in, 1 out; constants and state rows are the parent's) that one wave of a pair evaluates.
-   // Empty when the graph does not allow it.
-   std::vector<Graph> wave_roles;
+   // Wave split (FZ_VF_WAVES(W)): the W parts of a serial graph cut at wires of its stage split, each a graph of its own
+   // (1 in, 1 out; constants and state rows are the parent's) that one wave of a W-tuple evaluates.  wave_splits[W] for
+   // W = 2, 3, 4; empty when the graph does not allow it.
+   std::vector<std::vector<Graph>> wave_splits;
+   const std::vector<Graph>* wave_roles(uint32_t W) const { return W < wave_splits.size() && wave_splits[W].size() == W ? &wave_splits[W] : nullptr; }
 };
 
 StageSplit find_stage_split(const Graph& g);
-std::vector<Graph> find_wave_roles(const Graph& g);   // fz_split.cpp; {} or two graphs
+std::vector<Graph> find_wave_roles(const Graph& g, uint32_t W);   // fz_split.cpp; {} or W graphs
+// number of waves per stream tuple a variant asks for (flags bits 10..11: 1024 -> 2, 2048 -> 3, 3072 -> 4), 0 = no wave split
+inline uint32_t wave_split_of(uint32_t flags) { const uint32_t b = (flags >> 10) & 3u; return b ? b + 1 : 0; }
 
 // register-resident delay lines up to this depth; deeper ones become LDS rings
 constexpr uint32_t kRegMaxDepth = 8;

@@ -660,7 +660,8 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
    g.n_state = row;
    g.n_lds_slots = lds;
    g.split = find_stage_split(g);
-   g.wave_roles = find_wave_roles(g);
+   g.wave_splits.assign(5, {});
+   for (uint32_t W = 2; W <= 4; ++W) g.wave_splits[W] = find_wave_roles(g, W);
    return g;
 }
 

@@ -256,7 +256,7 @@ Variant settle_variant(fz_program* p, Variant v)
    for (;;) {
       const auto k = get_kernel(p, v, nullptr);
       if (k->res.scratch_bytes == 0) return v;
-      if ((v.flags & FZ_VF_STREAM_MAJOR) || v.U <= ((v.flags & FZ_VF_WAVE_SPLIT) ? 8u : 1u)) return v;
+      if ((v.flags & FZ_VF_STREAM_MAJOR) || v.U <= (wave_split_of(v.flags) ? 8u : 1u)) return v;
       v.U /= 2;
    }
 }
@@ -313,19 +313,21 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       fail(FZ_E_INVALID, "FZ_VF_OUT_F64 does not apply to fz_compile_typed programs: their frames carry every wire in its own type");
    if (reqU > 32 && !((v.flags & FZ_VF_SM_LONG) && (reqU == 64 || reqU == 128))) fail(FZ_E_INVALID, "unroll must be <= 32");
    if (reqB != 0 && (reqB % 64 != 0 || reqB > 1024)) fail(FZ_E_INVALID, "block_threads must be a multiple of 64, <= 1024");
-   if (v.flags & FZ_VF_WAVE_SPLIT) {
-      // two waves per 64 streams, each evaluating one half of the serial graph (fz_split.cpp: find_wave_roles)
-      if (g.wave_roles.size() != 2)
-         fail(FZ_E_UNSUPPORTED, "FZ_VF_WAVE_SPLIT: the graph is not an even number of isomorphic segments in series (1 in, 1 out, uniform coefficients, register delay lines)");
-      if (reqP > 1) fail(FZ_E_INVALID, "FZ_VF_WAVE_SPLIT needs streams_per_lane == 1");
-      if (reqB && reqB != 64 && reqB != 128) fail(FZ_E_INVALID, "FZ_VF_WAVE_SPLIT: block_threads counts the streams of a workgroup: 64 or 128");
-      if (reqU && reqU != 8 && reqU != 16 && reqU != 32) fail(FZ_E_INVALID, "FZ_VF_WAVE_SPLIT: unroll must be 8, 16 or 32");
+   if (const uint32_t W = wave_split_of(v.flags)) {
+      // W waves per 64 streams, each evaluating one part of the serial graph (fz_split.cpp: find_wave_roles)
+      if (!g.wave_roles(W))
+         fail(FZ_E_UNSUPPORTED, "wave split: the graph is not that many groups of isomorphic segments in series (1 in, 1 out, uniform coefficients, register delay lines, no scalar prefix or suffix)");
+      if (reqP > 1) fail(FZ_E_INVALID, "wave split needs streams_per_lane == 1");
+      if (reqB && (reqB % 64 || reqB * W > 1024)) fail(FZ_E_INVALID, "wave split: block_threads counts the streams of a workgroup: a multiple of 64, at most 1024 / parts");
+      if (reqU && reqU != 8 && reqU != 16 && reqU != 32) fail(FZ_E_INVALID, "wave split: unroll must be 8, 16 or 32");
       if (v.flags & (FZ_VF_STREAM_MAJOR | FZ_VF_OUT_F64 | FZ_VF_PREFETCH3))
-         fail(FZ_E_UNSUPPORTED, "FZ_VF_WAVE_SPLIT: time-major / tiled float32 frames, double buffering only");
+         fail(FZ_E_UNSUPPORTED, "wave split: time-major / tiled float32 frames, double buffering only");
       v.P = 1;
-      v.U = reqU ? reqU : 16;
-      v.block = reqB ? reqB : 128;                      // two wave pairs per workgroup: one wave on each SIMD of a CU
-      v.flags &= ~(uint32_t)(FZ_VF_STAGE_PACK | FZ_VF_NO_STAGE_PACK | FZ_VF_SLP);   // (each half is stage-packed by itself)
+      v.U = reqU ? reqU : (W == 2 ? 16 : 32);           // (one barrier per round: three and four waves in lockstep do better with longer rounds)
+      // the waves of a workgroup go to consecutive SIMDs of a CU: pairs come two to a workgroup (one wave on each of the
+      // four SIMDs), triples and quadruples one
+      v.block = reqB ? reqB : (W == 2 ? 128 : 64);
+      v.flags &= ~(uint32_t)(FZ_VF_STAGE_PACK | FZ_VF_NO_STAGE_PACK | FZ_VF_SLP);   // (each part is stage-packed by itself)
       return v;
    }
    if (reqP) {
@@ -363,16 +365,24 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       if (v.flags & FZ_VF_PREFETCH3) fail(FZ_E_INVALID, "FZ_VF_PREFETCH3 is not available with delays beyond LDS");
       v.U = std::min(v.U, cap);
    }
-   // wave split: fewer streams than 128 per CU -- two waves per 64 streams, each one half of the serial graph (measured,
-   // 6-biquad cascade: 0.23 ms against 0.33 ms per 4096 samples at 32 768 streams, 0.22 / 0.31 at 16 384; at 49 152 streams
-   // the 384 workgroups no longer spread evenly over 256 CUs and the single-wave kernel wins again)
-   if (!reqP && !reqB && g.wave_roles.size() == 2 && n_streams <= 32768 && n_samples >= 256 && (reqU == 0 || reqU == 8 || reqU == 16 || reqU == 32) &&
+   // wave split: fewer streams than 128 per CU -- W waves per 64 streams, each one part of the serial graph (measured,
+   // 6-biquad cascade, ms per 4096 samples: 32 768 streams 0.23 with two parts against 0.31-0.33 with the single wave;
+   // 16 384 streams 0.17 with three parts, 0.22 with two, 0.30 single; at 49 152 streams the 384 workgroups of pairs no
+   // longer spread evenly over 256 CUs and the single-wave kernel wins again; profiles/r02/sweep_wave_split.txt)
+   if (!reqP && !reqB && n_samples >= 256 && (reqU == 0 || reqU == 8 || reqU == 16 || reqU == 32) &&
        !(v.flags & (FZ_VF_STAGE_PACK | FZ_VF_NO_STAGE_PACK | FZ_VF_OUT_F64 | FZ_VF_PREFETCH3 | FZ_VF_STREAM_MAJOR | FZ_VF_SLP))) {
-      v.P = 1;
-      v.U = reqU ? reqU : 16;
-      v.block = 128;
-      v.flags |= FZ_VF_WAVE_SPLIT;
-      return v;
+      // the most parts whose waves still find a SIMD each: W waves per 64 streams on 1024 SIMDs, whole workgroups per CU
+      // (pairs: two to a workgroup, 128 streams per CU; triples / quadruples: one workgroup of 64 streams per CU)
+      uint32_t W = 0;
+      if (n_streams <= 16384) W = g.wave_roles(4) ? 4 : g.wave_roles(3) ? 3 : 0;
+      if (!W && n_streams <= 32768 && g.wave_roles(2)) W = 2;
+      if (W) {
+         v.P = 1;
+         v.U = reqU ? reqU : (W == 2 ? 16 : 32);
+         v.block = W == 2 ? 128 : 64;
+         v.flags |= (W - 1) << 10;
+         return v;
+      }
    }
    // stage packing: one stream per lane, pairs of isomorphic graph segments in one v_pk_* (fz_split.cpp)
    if (v.flags & FZ_VF_STAGE_PACK) {
@@ -714,7 +724,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, kbuf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
    const unsigned grid = (unsigned)((h.n_groups + v.block - 1) / v.block);
    // (wave split: v.block counts the 64 streams of a workgroup; two waves evaluate them)
-   const unsigned threads = (v.flags & FZ_VF_WAVE_SPLIT) ? v.block * 2u : v.block;
+   const unsigned threads = wave_split_of(v.flags) ? v.block * wave_split_of(v.flags) : v.block;
    FZ_HIP(hipModuleLaunchKernel((hipFunction_t)fn, grid, 1, 1, threads, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
    static const bool debug = std::getenv("FLOWZ_HIP_DEBUG") != nullptr;
    if (debug) {
@@ -730,12 +740,13 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
 {
    const Variant d = resolve_variant(g, nullptr, n_streams, n_samples);
    std::vector<fz_variant> cands{fz_variant{0, 0, 0, 0}};
-   if (d.flags & FZ_VF_WAVE_SPLIT) {            // few streams: the wave split against the single stage-packed wave
-      cands.push_back(fz_variant{1, 32, 0, FZ_VF_WAVE_SPLIT});
-      cands.push_back(fz_variant{1, 16, 64, FZ_VF_WAVE_SPLIT});
+   if (const uint32_t W = wave_split_of(d.flags)) {            // few streams: the wave splits against the single stage-packed wave
+      cands.push_back(fz_variant{1, W == 2 ? 32u : 16u, 0, (W - 1) << 10});
+      if (W != 2 && g.wave_roles(2)) cands.push_back(fz_variant{1, 16, 0, FZ_VF_WAVE_SPLIT});
+      if (W == 2) cands.push_back(fz_variant{1, 16, 64, FZ_VF_WAVE_SPLIT});
       cands.push_back(fz_variant{1, 16, 0, FZ_VF_STAGE_PACK});
    } else if (d.flags & FZ_VF_STAGE_PACK) {
-      if (g.wave_roles.size() == 2 && n_streams < 65536) {
+      if (g.wave_roles(2) && n_streams < 65536) {
          cands.push_back(fz_variant{1, 16, 64, FZ_VF_WAVE_SPLIT});
          cands.push_back(fz_variant{1, 16, 128, FZ_VF_WAVE_SPLIT});
       }

@@ -266,17 +266,40 @@ StageSplit find_stage_split(const Graph& g)
 }
 
 // ---- wave split ---------------------------------------------------------------------------------------------------
-// Fewer streams than the chip has lanes: half the SIMDs idle while every wave carries the whole serial graph.  A graph that
-// is a series of K isomorphic segments (K even, no scalar prefix or suffix) is cut at its middle wire m = cuts[K/2]:
-//    in -> [ role 0: segments 0 .. K/2-1 ] -> m -> [ role 1: segments K/2 .. K-1 ] -> out
-// Two waves of a workgroup evaluate the two halves for the same 64 streams; m travels through LDS, role 1 one chunk of
-// samples behind role 0 (fz_block_kernel.hip.inc, FZ_VF_WAVE_SPLIT).  Each half is a graph of its own here -- node ids
-// renumbered, constant slots and state rows the parent's -- so that the ordinary generators (and the stage packing of each
-// half: a 3-biquad half is one packed pair and a scalar stage) apply to it unchanged.  Delay lines of the cut wire are kept
-// by both halves (role 0 reads them as its own output's past, role 1 as its input's past): the same values in both.
-static bool extract_role(const Graph& g, const std::vector<char>& in_a, uint32_t cut, bool second, Graph& r)
+// Fewer streams than the chip has lanes: SIMDs idle while every wave carries the whole serial graph.  A graph that is a
+// series of K isomorphic segments (no scalar prefix or suffix) is cut into W parts of K / W segments at the wires
+// cuts[K/W], cuts[2K/W], ...:
+//    in -> [ part 0 ] -> m_1 -> [ part 1 ] -> m_2 -> ... -> [ part W-1 ] -> out
+// W waves of a workgroup evaluate the parts for the same 64 streams; the cut wires travel through LDS, every part one
+// chunk of samples behind the one before (fz_block_kernel.hip.inc, FZ_VF_WAVE_SPLIT).  Each part is a graph of its own here
+// -- node ids renumbered, constant slots and state rows the parent's -- so that the ordinary generators (and the stage
+// packing of each part: a 3-biquad part is one packed pair and a scalar stage) apply to it unchanged.  Delay lines of a
+// cut wire are kept by both neighbours (the earlier part reads them as its own output's past, the later one as its
+// input's past): the same values in both.
+static std::vector<char> closure_of(const Graph& g, uint32_t root)
+{
+   std::vector<char> in(g.nodes.size(), 0);
+   std::vector<uint32_t> work{root};
+   while (!work.empty()) {
+      const uint32_t v = work.back();
+      work.pop_back();
+      if (in[v]) continue;
+      in[v] = 1;
+      const Node& n = g.nodes[v];
+      if (is_arith(n.kind)) {
+         work.push_back(n.a);
+         if (n.kind != FZ_IR_NEG) work.push_back(n.b);
+      } else if (n.kind == FZ_IR_DELAY) work.push_back(n.a);
+   }
+   return in;
+}
+
+// part between the wires cin (its input; N: the graph input) and cout (its output): the nodes cout depends on that cin
+// does not, constants, and the delayed reads of cin
+static bool extract_part(const Graph& g, const std::vector<char>* before, const std::vector<char>& upto, uint32_t cin, uint32_t cout, Graph& r)
 {
    const uint32_t N = (uint32_t)g.nodes.size();
+   const bool first = cin == N;
    std::vector<int> nid(N, -1);
    r = Graph();
    r.n_in = r.n_out = r.n_out_wires = 1;
@@ -287,53 +310,60 @@ static bool extract_role(const Graph& g, const std::vector<char>& in_a, uint32_t
       nid[v] = (int)r.nodes.size();
       r.nodes.push_back(n);
    };
-   if (second) {
+   if (!first) {
       Node in{};
       in.kind = FZ_IR_INPUT;
-      add(cut, in);                                       // the cut wire is this half's input
+      add(cin, in);                                       // the cut wire is this part's input
    }
+   auto mine = [&](uint32_t v) {
+      const Node& n = g.nodes[v];
+      if (!first && v == cin) return false;               // (added above)
+      if (!upto[v]) return false;
+      if (n.kind == FZ_IR_CONST) return true;
+      if (n.kind == FZ_IR_DELAY && !first && n.a == cin) return true;
+      return first || !(*before)[v];
+   };
    for (uint32_t v = 0; v < N; ++v) {
-      if ((in_a[v] != 0) == second || (second && v == cut)) continue;   // the other half's node
+      if (!mine(v)) continue;
       Node n = g.nodes[v];
       auto op = [&](uint32_t o) -> int { return o < N ? nid[o] : -1; };
       switch (n.kind) {
-         case FZ_IR_INPUT: if (second) return false; break;
+         case FZ_IR_INPUT: if (!first) return false; break;
          case FZ_IR_CONST: break;
          case FZ_IR_DELAY: break;                          // source patched below (it may come later in the order)
          case FZ_IR_NEG:
             if (op(n.a) < 0) return false;
             n.a = (uint32_t)op(n.a);
+            ++r.n_ops;
             break;
          case FZ_IR_ADD: case FZ_IR_SUB: case FZ_IR_MUL: case FZ_IR_DIV:
-            if (op(n.a) < 0 || op(n.b) < 0) return false;
+            if (op(n.a) < 0 || op(n.b) < 0) return false;  // an operand from an earlier part that is not the cut wire
             n.a = (uint32_t)op(n.a);
             n.b = (uint32_t)op(n.b);
             ++r.n_ops;
             break;
          default: return false;                            // per-stream coefficients, modulators, typed nodes: not split
       }
-      if (n.kind == FZ_IR_NEG) ++r.n_ops;
       add(v, n);
    }
-   // delayed reads: the source is a node of this half (the cut wire counts for both)
-   for (uint32_t v = 0; v < N; ++v) {
-      if (nid[v] < 0 || g.nodes[v].kind != FZ_IR_DELAY || (second && v == cut)) continue;
+   for (uint32_t v = 0; v < N; ++v) {                       // delayed reads: the source is a node of this part (its input included)
+      if (nid[v] < 0 || g.nodes[v].kind != FZ_IR_DELAY || (!first && v == cin)) continue;
       const uint32_t src = g.nodes[v].a;
       if (src >= N || nid[src] < 0) return false;
       r.nodes[(size_t)nid[v]].a = (uint32_t)nid[src];
    }
-   const uint32_t out = second ? g.outputs[0] : cut;
-   if (nid[out] < 0) return false;
-   r.outputs = {(uint32_t)nid[out]};
+   if (nid[cout] < 0) return false;
+   r.outputs = {(uint32_t)nid[cout]};
    r.out_part = {0};
-   // lines: the parent's, for the sources this half reads through a delay; rows and depths are the parent's
+   // lines: the parent's, for the sources this part reads through a delay; rows and depths are the parent's
    r.line_of_node.assign(r.nodes.size(), -1);
    for (const Line& L : g.lines) {
-      if (L.in_lds || L.far || L.f64 || nid[L.src] < 0) continue;
+      if (nid[L.src] < 0) continue;
       bool read_here = false;
       for (uint32_t v = 0; v < N && !read_here; ++v)
-         read_here = nid[v] >= 0 && !(second && v == cut) && g.nodes[v].kind == FZ_IR_DELAY && g.nodes[v].a == L.src;
+         read_here = nid[v] >= 0 && !(!first && v == cin) && g.nodes[v].kind == FZ_IR_DELAY && g.nodes[v].a == L.src;
       if (!read_here) continue;
+      if (L.in_lds || L.far || L.f64) return false;
       Line l = L;
       l.src = (uint32_t)nid[L.src];
       r.line_of_node[l.src] = (int)r.lines.size();
@@ -342,52 +372,25 @@ static bool extract_role(const Graph& g, const std::vector<char>& in_a, uint32_t
    }
    r.n_state = g.n_state;
    r.split = find_stage_split(r);
-   return true;
+   return r.split.ok;
 }
 
-std::vector<Graph> find_wave_roles(const Graph& g)
+std::vector<Graph> find_wave_roles(const Graph& g, uint32_t W)
 {
    const StageSplit& sp = g.split;
-   if (!sp.ok || sp.K < 2 || sp.K % 2 || !sp.prefix.empty() || !sp.suffix.empty() || g.typed || g.n_param || g.n_mod ||
+   if (W < 2 || !sp.ok || sp.K < W || sp.K % W || !sp.prefix.empty() || !sp.suffix.empty() || g.typed || g.n_param || g.n_mod ||
        g.n_lds_slots || !g.far_lines.empty() || g.n_in != 1 || g.n_out != 1)
       return {};
-   const uint32_t N = (uint32_t)g.nodes.size(), cut = sp.cuts[sp.K / 2];
-   // role 0 = everything the cut wire depends on (operands and delay lines); its delayed reads of itself included
-   std::vector<char> in_a(N, 0);
-   std::vector<uint32_t> work{cut};
-   while (!work.empty()) {
-      const uint32_t v = work.back();
-      work.pop_back();
-      if (in_a[v]) continue;
-      in_a[v] = 1;
-      const Node& n = g.nodes[v];
-      if (is_arith(n.kind)) {
-         work.push_back(n.a);
-         if (n.kind != FZ_IR_NEG) work.push_back(n.b);
-      } else if (n.kind == FZ_IR_DELAY) work.push_back(n.a);
+   const uint32_t N = (uint32_t)g.nodes.size(), m = sp.K / W;
+   std::vector<std::vector<char>> clo;                     // closure of the wire that ends part k
+   for (uint32_t k = 0; k < W; ++k) clo.push_back(closure_of(g, sp.cuts[(k + 1) * m]));
+   std::vector<Graph> roles(W);
+   uint32_t ops = 0;
+   for (uint32_t k = 0; k < W; ++k) {
+      if (!extract_part(g, k ? &clo[k - 1] : nullptr, clo[k], k ? sp.cuts[k * m] : N, sp.cuts[(k + 1) * m], roles[k])) return {};
+      ops += roles[k].n_ops;
    }
-   // leaves (constants) and delayed reads of the cut wire are shared: give role 1 its own copies
-   for (uint32_t v = 0; v < N; ++v) {
-      const Node& n = g.nodes[v];
-      if (n.kind == FZ_IR_CONST || (n.kind == FZ_IR_DELAY && n.a == cut)) in_a[v] = 2;   // 2: in both halves
-   }
-   // role 1 may see role 0 only through the cut wire, now or delayed
-   for (uint32_t v = 0; v < N; ++v) {
-      if (in_a[v] == 1) continue;
-      const Node& n = g.nodes[v];
-      auto fine = [&](uint32_t o) { return in_a[o] != 1 || o == cut; };
-      if (is_arith(n.kind) && !(fine(n.a) && (n.kind == FZ_IR_NEG || fine(n.b)))) return {};
-      if (n.kind == FZ_IR_DELAY && in_a[v] != 2 && in_a[n.a] == 1) return {};
-   }
-   std::vector<Graph> roles(2);
-   // extract_role keeps node v for the first half when in_a[v] != 0, for the second when the flag passed is 0
-   std::vector<char> flag_a(N), flag_b(N);
-   for (uint32_t v = 0; v < N; ++v) {
-      flag_a[v] = in_a[v] != 0;                    // first half: nodes with flag set
-      flag_b[v] = in_a[v] == 1;                    // second half: nodes WITHOUT flag (role-1 nodes and the shared ones)
-   }
-   if (!extract_role(g, flag_a, cut, false, roles[0]) || !extract_role(g, flag_b, cut, true, roles[1])) return {};
-   if (!roles[0].split.ok || !roles[1].split.ok || roles[0].n_ops + roles[1].n_ops != g.n_ops) return {};
+   if (ops != g.n_ops) return {};                          // every operation sits in exactly one part
    return roles;
 }
 
