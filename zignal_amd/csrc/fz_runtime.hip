@@ -677,6 +677,9 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       }
    }
    Variant v = resolve_variant(g, uv, n_streams, n_samples);
+   // time-major frames of many streams: the rows are megabytes apart, every row in flight is another page, and 16 rows per
+   // lane do better than 32 (1 M streams: 6.46 ms against 6.88 ms; stream-tiled frames keep 32: tools/slab_probe.py)
+   if (!tile_streams && !(v.flags & FZ_VF_STREAM_MAJOR) && !(uv && uv->unroll) && v.P == 2 && v.U == 32 && n_streams >= (1u << 19)) v.U = 16;
    if (tile_streams) {
       // a workgroup must not straddle tiles: shrink the lane packing / block until it divides
       const bool fixedP = uv && uv->streams_per_lane, fixedB = uv && uv->block_threads;
