@@ -694,6 +694,46 @@ def test_wave_split_kernel_vs_oracle(torch_cuda, F, name, T):
     assert tried >= 4
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_wave_split_random_cascades(torch_cuda, F, seed):
+    """random serial filters (form, 4 .. 16 stages, random stable coefficients), random stream counts and block lengths,
+    every split the graph allows with a random unroll and workgroup size -- against the oracle, two chained blocks."""
+    rng = np.random.default_rng(9000 + seed)
+    form = ["df1", "df2", "df1t"][seed % 3]
+    n = int(rng.choice([4, 6, 8, 10, 12, 16]))
+
+    def stage():
+        if form == "df1t":
+            return G.df1t()
+        r, th = rng.uniform(0.3, 0.95), rng.uniform(0.1, 3.0)                      # poles inside the unit circle
+        c = (rng.uniform(0.1, 1.0), rng.uniform(-1, 1), rng.uniform(-1, 1), 2 * r * np.cos(th), -r * r)
+        return (G.df1 if form == "df1" else G.df2)(*[float(np.float32(v)) for v in c])
+
+    g = stage()
+    for _ in range(n - 1):
+        g = G.seq(g, stage())
+    prog = F.compile(F.from_sexpr(g))
+    ns, T = int(rng.integers(1, 400)), int(rng.integers(1, 700))
+    x = O.synth_input(seed, np.arange(ns), T)
+    want = O.compile(g, ns).run(x)
+    ref, st_ref = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+    assert ndiff(ref, want) == 0
+    tried = 0
+    for W in (2, 3, 4):
+        v = F.make_variant(1, int(rng.choice([8, 16, 32])), int(rng.choice([0, 64, 128])), F.C.FZ_VF_WAVES(W))
+        try:
+            prog.kernel_name(v, ns, T)
+        except F.FlowzError:
+            continue
+        cut = int(rng.integers(0, T + 1))
+        a, st = run_gpu(torch_cuda, F, prog, x[:cut], variant=v) if cut else (x[:0], None)
+        b, st = run_gpu(torch_cuda, F, prog, x[cut:], variant=v, state=st) if cut < T else (x[:0], st)
+        assert ndiff(np.concatenate([a, b]), want) == 0, (form, n, ns, T, W, cut)
+        assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0
+        tried += 1
+    assert tried >= 1
+
+
 def test_wave_split_blocks_chain_tiles_and_refusals(torch_cuda, F):
     """blocks of a wave-split kernel chain with every other variant through the canonical state; stream-tiled frames;
     graphs that are not two isomorphic halves are refused."""

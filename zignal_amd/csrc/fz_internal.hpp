@@ -122,7 +122,7 @@ struct Graph {
    const std::vector<Graph>* wave_roles(uint32_t W) const { return W < wave_splits.size() && wave_splits[W].size() == W ? &wave_splits[W] : nullptr; }
 };
 
-StageSplit find_stage_split(const Graph& g);
+StageSplit find_stage_split(const Graph& g, bool plain = false, uint32_t divisor = 0);
 std::vector<Graph> find_wave_roles(const Graph& g, uint32_t W);   // fz_split.cpp; {} or W graphs
 // number of waves per stream tuple a variant asks for (flags bits 10..11: 1024 -> 2, 2048 -> 3, 3072 -> 4), 0 = no wave split
 inline uint32_t wave_split_of(uint32_t flags) { const uint32_t b = (flags >> 10) & 3u; return b ? b + 1 : 0; }

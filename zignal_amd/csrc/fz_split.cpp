@@ -89,7 +89,9 @@ struct Matcher {
 
 }  // namespace
 
-StageSplit find_stage_split(const Graph& g)
+// plain: the chain runs from the graph input to the graph output (no scalar prefix / suffix); divisor: only segment counts
+// that are multiples of it (both for the wave split, which cuts the chain itself into parts)
+StageSplit find_stage_split(const Graph& g, bool plain, uint32_t divisor)
 {
    StageSplit none;
    if (g.n_in != 1 || g.n_out != 1 || g.n_lds_slots != 0 || !g.far_lines.empty() || g.n_ops < 2) return none;
@@ -129,7 +131,7 @@ StageSplit find_stage_split(const Graph& g)
    // rest of the graph (closure(output) minus closure(e)) is a scalar SUFFIX: it sees the chain only
    // through e (now or delayed), constants and itself.  Later wires first (the shortest suffix).
    std::vector<uint32_t> ends{gout};
-   for (uint32_t e = N; e-- > 0;) {
+   for (uint32_t e = N; e-- > 0 && !plain;) {
       if (!is_arith(g.nodes[e].kind) || e == gout || !closure[gout][e] || (g.n_ops - cnt[e]) * 2 > g.n_ops) continue;
       bool ok = true;
       for (uint32_t v = 0; v < N && ok; ++v) {
@@ -150,11 +152,12 @@ StageSplit find_stage_split(const Graph& g)
    // most segments first (the shortest dependent chains), then the shortest suffix, then the shortest prefix
    for (uint32_t K = 8; K >= 2; K -= 2)
    for (uint32_t out : ends) {
+   if (divisor && K % divisor) continue;
    const uint32_t chain_ops = cnt[out];
    // chain input candidates: the graph input itself (no prefix), then every arithmetic wire p whose
    // closure is a scalar PREFIX evaluated at the time of segment 0 (e.g. an oscillator in front of a cascade)
    std::vector<uint32_t> starts{in};
-   for (uint32_t c = 0; c < N; ++c)
+   for (uint32_t c = 0; c < N && !plain; ++c)
       if (is_arith(g.nodes[c].kind) && c != out && closure[out][c] && cnt[c] * 2 <= chain_ops) starts.push_back(c);
    for (uint32_t p0 : starts) {
       const uint32_t base = p0 == in ? 0u : cnt[p0];
@@ -377,10 +380,11 @@ static bool extract_part(const Graph& g, const std::vector<char>* before, const 
 
 std::vector<Graph> find_wave_roles(const Graph& g, uint32_t W)
 {
-   const StageSplit& sp = g.split;
-   if (W < 2 || !sp.ok || sp.K < W || sp.K % W || !sp.prefix.empty() || !sp.suffix.empty() || g.typed || g.n_param || g.n_mod ||
-       g.n_lds_slots || !g.far_lines.empty() || g.n_in != 1 || g.n_out != 1)
-      return {};
+   if (W < 2 || !g.split.ok || g.typed || g.n_param || g.n_mod || g.n_lds_slots || !g.far_lines.empty() || g.n_in != 1 || g.n_out != 1) return {};
+   // the chain itself, input to output, in a number of segments the parts divide (the graph's own stage split may prefer
+   // more segments behind a scalar prefix: a 12-biquad cascade is 8 segments of 13 operations after 4, but also 6 x 2 biquads)
+   const StageSplit sp = find_stage_split(g, true, W);
+   if (!sp.ok || sp.K < W || sp.K % W || !sp.prefix.empty() || !sp.suffix.empty()) return {};
    const uint32_t N = (uint32_t)g.nodes.size(), m = sp.K / W;
    std::vector<std::vector<char>> clo;                     // closure of the wire that ends part k
    for (uint32_t k = 0; k < W; ++k) clo.push_back(closure_of(g, sp.cuts[(k + 1) * m]));
