@@ -240,6 +240,10 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
                                    block_threads counts the streams of a workgroup (a multiple of 64).  This bit: W = 2;
                                    FZ_VF_WAVES(3), FZ_VF_WAVES(4): three / four parts.  Chosen automatically for few streams */
        FZ_VF_WAVE_SPLIT3 = 2048u,
+       FZ_VF_IO_WAVE = 32768u,  /* one more wave per 64 streams does all the frame I/O: it loads the input rows two rounds ahead and
+                                   hands them to the compute wave(s) through LDS, and stores the rows they hand back; the compute
+                                   wave is left with arithmetic and LDS accesses.  Alone (a stage-packable graph: one compute wave
+                                   + one I/O wave, 4 such pairs per workgroup) or together with FZ_VF_WAVES(n)                   */
        FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
                                    float*): the results of graphs with double literals leave un-narrowed, float
                                    wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */

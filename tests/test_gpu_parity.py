@@ -681,17 +681,48 @@ def test_wave_split_kernel_vs_oracle(torch_cuda, F, name, T):
     ref, st_ref = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
     assert ndiff(ref, want) == 0
     tried = 0
-    for W in (2, 3, 4):                                   # parts = waves per 64 streams: whatever the graph divides into
+    for W, io in ((2, 0), (3, 0), (4, 0), (1, 1), (2, 1), (3, 1)):   # parts = compute waves per 64 streams (whatever the graph divides into), + an I/O wave
+        fl = F.C.FZ_VF_WAVES(W) | (F.C.FZ_VF_IO_WAVE if io else 0)
         try:
-            prog.kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVES(W)), ns, T)
+            prog.kernel_name(F.make_variant(1, 16, 0, fl), ns, T)
         except F.FlowzError:
             continue
         for U, B in ((8, 64), (16, 128), (32, 0), (16, 64)):
-            got, st = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, U, B, F.C.FZ_VF_WAVES(W)))
-            assert ndiff(got, want) == 0, (name, T, W, U, B)
-            assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0, (name, T, W, U, B)
+            got, st = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, U, B, fl))
+            assert ndiff(got, want) == 0, (name, T, W, io, U, B)
+            assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0, (name, T, W, io, U, B)
             tried += 1
-    assert tried >= 4
+    assert tried >= 8
+
+
+@pytest.mark.parametrize("T", [1, 7, 64, 101, 300])
+@pytest.mark.parametrize("name", sorted(PACKABLE))
+def test_io_wave_kernel_vs_oracle(torch_cuda, F, name, T):
+    """FZ_VF_IO_WAVE alone: every stage-packable graph (scalar prefix / suffix included) as one compute wave next to an I/O
+    wave -- the input rows reach it through LDS two rounds after they were requested, the output rows leave the same way."""
+    g = PACKABLE[name]()
+    prog = F.compile(F.from_sexpr(g))
+    ns = 197
+    x = O.synth_input(SEED + 6, np.arange(ns), T)
+    want = O.compile(g, ns).run(x)
+    ref, st_ref = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+    for U, B in ((16, 0), (8, 128), (32, 64)):
+        got, st = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, U, B, F.C.FZ_VF_IO_WAVE))
+        assert ndiff(got, want) == 0, (name, T, U, B)
+        assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0, (name, T, U, B)
+
+
+def test_io_wave_with_per_stream_coefficients(torch_cuda, F):
+    """resonator (scalar prefix) -> 6 DF1 stages with 31 per-stream coefficients (config 4's graph) behind an I/O wave"""
+    ns = 200
+    prog = F.compile(F.from_sexpr(G.osc_chain(6)))
+    P = W.osc_chain_params(SEED + 3, np.arange(ns))
+    x = np.zeros((333, ns, 1), np.float32)
+    x[0] = 1.0
+    got, st = run_gpu(torch_cuda, F, prog, x, params=P, variant=F.make_variant(1, 16, 0, F.C.FZ_VF_IO_WAVE))
+    assert ndiff(got, C.osc_chain(P, x)) == 0
+    ref, st_ref = run_gpu(torch_cuda, F, prog, x, params=P, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+    assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -719,8 +750,9 @@ def test_wave_split_random_cascades(torch_cuda, F, seed):
     ref, st_ref = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
     assert ndiff(ref, want) == 0
     tried = 0
-    for W in (2, 3, 4):
-        v = F.make_variant(1, int(rng.choice([8, 16, 32])), int(rng.choice([0, 64, 128])), F.C.FZ_VF_WAVES(W))
+    for W in (1, 2, 3, 4):
+        io = F.C.FZ_VF_IO_WAVE if (W == 1 or rng.random() < 0.5) else 0
+        v = F.make_variant(1, int(rng.choice([8, 16, 32])), int(rng.choice([0, 64, 128])), F.C.FZ_VF_WAVES(W) | io)
         try:
             prog.kernel_name(v, ns, T)
         except F.FlowzError:

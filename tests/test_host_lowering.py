@@ -388,22 +388,29 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
     suffix, per-stream coefficients, several wires, an odd or a single pair of segments."""
     from zignal_amd.workloads import BASELINE_GRAPHS
     p = F.compile(F.from_sexpr(G.df1_cascade(6)))
-    assert p.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u16b128w2f1024"
+    assert p.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u16b128w2f1024"             # two compute waves per 64 streams
     assert p.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w3f2048"              # 256 workgroups of three waves: two biquads each
     assert p.kernel_name(None, 65536, 4096).startswith("fz_block_kernel_p1u16b256s6f")       # one wave per SIMD already
+    assert p.kernel_name(F.make_variant(0, 0, 0, F.C.FZ_VF_IO_WAVE), 65536, 4096) == "fz_block_kernel_p1u16b256w1iof32768"   # ... or an I/O wave next to it
     assert p.kernel_name(None, 32768, 200).startswith("fz_block_kernel_p1u16b256s6f")        # short blocks: the ends would dominate
     assert p.kernel_name(F.make_variant(0, 0, 0, 16), 32768, 4096) == "fz_block_kernel_p1u16b256f0"   # FZ_VF_NO_STAGE_PACK: the plain kernel
     src = p.source(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT))
     assert "namespace fz_r0 {" in src and "namespace fz_r1 {" in src and "#define FZ_WS_K0 2" in src and "#define FZ_WS_K1 2" in src
-    r = p.kernel_resources(None, 32768, 4096)
+    r = p.kernel_resources(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT), 32768, 4096)
     assert r["scratch_bytes"] == 0 and r["lds_bytes"] == 2 * 8 * 64 * 16 and r["vgprs"] < 128   # two pairs x ring of 8 groups x 64 lanes x 16 B
-    assert [v.flags & F.C.FZ_VF_WAVE_SPLIT for v in p.tune_candidates(32768, 4096)][1:3] == [1024, 1024]
-    assert [v.flags for v in p.tune_candidates(16384, 4096)][:3] == [0, F.C.FZ_VF_WAVES(3), F.C.FZ_VF_WAVES(2)]
+    IO = F.C.FZ_VF_IO_WAVE
+    r = p.kernel_resources(F.make_variant(0, 0, 0, IO), 65536, 4096)
+    assert r["scratch_bytes"] == 0 and r["lds_bytes"] == 4 * 2 * 16 * 64 * 16                   # four (compute, I/O) pairs x two rings of 16 groups
+    assert [v.flags for v in p.tune_candidates(32768, 4096)][:4] == [0, F.C.FZ_VF_WAVES(2) | IO, F.C.FZ_VF_WAVES(2), 8]
+    assert [v.flags for v in p.tune_candidates(16384, 4096)][:4] == [0, F.C.FZ_VF_WAVES(3) | IO, F.C.FZ_VF_WAVES(3), F.C.FZ_VF_WAVES(2)]
+    assert IO in [v.flags for v in p.tune_candidates(65536, 4096)]
     q = F.compile(F.from_sexpr(G.df1_cascade(8)))
     assert q.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w4f3072" and "#define FZ_WS_W 4" in q.source(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVES(4)))
+    src = p.source(F.make_variant(1, 16, 0, IO))
+    assert "#define FZ_WS_IO 1" in src and "#define FZ_WS_W 1" in src and "#define FZ_WS_K0 6" in src
     for name in ("par4_sum", "par4_sum_fanout", "osc_chain6"):
         q = F.compile(F.from_sexpr(BASELINE_GRAPHS[name]()))
-        assert "w2" not in q.kernel_name(None, 32768, 4096)
+        assert "w" not in q.kernel_name(None, 32768, 4096).split("b", 2)[2]
         with pytest.raises(F.FlowzError):
             q.kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT), 32768, 4096)
     for bad in (G.df1_cascade(2), G.df1_cascade(3), G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1)))):

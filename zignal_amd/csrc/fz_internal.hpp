@@ -119,13 +119,19 @@ struct Graph {
    // (1 in, 1 out; constants and state rows are the parent's) that one wave of a W-tuple evaluates.  wave_splits[W] for
    // W = 2, 3, 4; empty when the graph does not allow it.
    std::vector<std::vector<Graph>> wave_splits;
-   const std::vector<Graph>* wave_roles(uint32_t W) const { return W < wave_splits.size() && wave_splits[W].size() == W ? &wave_splits[W] : nullptr; }
+   // (W = 1: the graph itself, when it is stage-packable -- the compute wave next to an I/O wave)
+   const std::vector<Graph>* wave_roles(uint32_t W) const { return W && W < wave_splits.size() && wave_splits[W].size() == W ? &wave_splits[W] : nullptr; }
 };
 
 StageSplit find_stage_split(const Graph& g, bool plain = false, uint32_t divisor = 0);
 std::vector<Graph> find_wave_roles(const Graph& g, uint32_t W);   // fz_split.cpp; {} or W graphs
 // number of waves per stream tuple a variant asks for (flags bits 10..11: 1024 -> 2, 2048 -> 3, 3072 -> 4), 0 = no wave split
 inline uint32_t wave_split_of(uint32_t flags) { const uint32_t b = (flags >> 10) & 3u; return b ? b + 1 : 0; }
+// FZ_VF_IO_WAVE: one more wave per tuple does the frame I/O.  Parts of the graph a tuple's compute waves evaluate (0: the ordinary
+// kernels), and waves per tuple
+inline uint32_t ws_io(uint32_t flags) { return (flags & FZ_VF_IO_WAVE) ? 1u : 0u; }
+inline uint32_t ws_parts(uint32_t flags) { const uint32_t W = wave_split_of(flags); return W ? W : ws_io(flags); }
+inline uint32_t ws_waves(uint32_t flags) { return ws_parts(flags) + (ws_parts(flags) ? ws_io(flags) : 0u); }
 
 // register-resident delay lines up to this depth; deeper ones become LDS rings
 constexpr uint32_t kRegMaxDepth = 8;

@@ -256,7 +256,7 @@ Variant settle_variant(fz_program* p, Variant v)
    for (;;) {
       const auto k = get_kernel(p, v, nullptr);
       if (k->res.scratch_bytes == 0) return v;
-      if ((v.flags & FZ_VF_STREAM_MAJOR) || v.U <= (wave_split_of(v.flags) ? 8u : 1u)) return v;
+      if ((v.flags & FZ_VF_STREAM_MAJOR) || v.U <= (ws_parts(v.flags) ? 8u : 1u)) return v;
       v.U /= 2;
    }
 }
@@ -313,20 +313,29 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       fail(FZ_E_INVALID, "FZ_VF_OUT_F64 does not apply to fz_compile_typed programs: their frames carry every wire in its own type");
    if (reqU > 32 && !((v.flags & FZ_VF_SM_LONG) && (reqU == 64 || reqU == 128))) fail(FZ_E_INVALID, "unroll must be <= 32");
    if (reqB != 0 && (reqB % 64 != 0 || reqB > 1024)) fail(FZ_E_INVALID, "block_threads must be a multiple of 64, <= 1024");
-   if (const uint32_t W = wave_split_of(v.flags)) {
-      // W waves per 64 streams, each evaluating one part of the serial graph (fz_split.cpp: find_wave_roles)
+   if (const uint32_t W = ws_parts(v.flags)) {
+      // W compute waves per 64 streams, each evaluating one part of the serial graph (fz_split.cpp: find_wave_roles), and with
+      // FZ_VF_IO_WAVE one more wave for the frame I/O
+      const uint32_t waves = ws_waves(v.flags);
       if (!g.wave_roles(W))
-         fail(FZ_E_UNSUPPORTED, "wave split: the graph is not that many groups of isomorphic segments in series (1 in, 1 out, uniform coefficients, register delay lines, no scalar prefix or suffix)");
+         fail(FZ_E_UNSUPPORTED, W == 1 ? "FZ_VF_IO_WAVE: the graph is not stage-packable (1 in, 1 out, register delay lines)"
+                                       : "wave split: the graph is not that many groups of isomorphic segments in series (1 in, 1 out, uniform coefficients, register delay lines, no scalar prefix or suffix)");
       if (reqP > 1) fail(FZ_E_INVALID, "wave split needs streams_per_lane == 1");
-      if (reqB && (reqB % 64 || reqB * W > 1024)) fail(FZ_E_INVALID, "wave split: block_threads counts the streams of a workgroup: a multiple of 64, at most 1024 / parts");
+      if (reqB && (reqB % 64 || reqB * waves > 1024)) fail(FZ_E_INVALID, "wave split: block_threads counts the streams of a workgroup: a multiple of 64, at most 1024 / waves per tuple");
       if (reqU && reqU != 8 && reqU != 16 && reqU != 32) fail(FZ_E_INVALID, "wave split: unroll must be 8, 16 or 32");
       if (v.flags & (FZ_VF_STREAM_MAJOR | FZ_VF_OUT_F64 | FZ_VF_PREFETCH3))
          fail(FZ_E_UNSUPPORTED, "wave split: time-major / tiled float32 frames, double buffering only");
       v.P = 1;
-      v.U = reqU ? reqU : (W == 2 ? 16 : 32);           // (one barrier per round: three and four waves in lockstep do better with longer rounds)
+      v.U = reqU ? reqU : (W <= 2 ? 16 : 32);           // (one barrier per round: three and four waves in lockstep do better with longer rounds)
       // the waves of a workgroup go to consecutive SIMDs of a CU: pairs come two to a workgroup (one wave on each of the
       // four SIMDs), triples and quadruples one
-      v.block = reqB ? reqB : (W == 2 ? 128 : 64);
+      // (with I/O waves: one compute wave on each SIMD and the I/O waves next to them -- 4 tuples for one part, 2 for two)
+      v.block = reqB ? reqB : (ws_io(v.flags) ? (W == 1 ? 256 : W == 2 ? 128 : 64) : (W == 2 ? 128 : 64));
+      {  // the rings of a workgroup must fit the CU's LDS: tuples x hand-offs x ring x 1 KiB
+         const uint32_t K0 = (*g.wave_roles(W))[0].split.K, ring = (K0 - 1 > 4 ? v.U : v.U / 2), nring = W - 1 + 2 * ws_io(v.flags);
+         while ((uint64_t)(v.block / 64) * nring * ring * 1024 > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
+         if ((uint64_t)(v.block / 64) * nring * ring * 1024 > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "wave split: the hand-off rings do not fit the LDS with this unroll and block size");
+      }
       v.flags &= ~(uint32_t)(FZ_VF_STAGE_PACK | FZ_VF_NO_STAGE_PACK | FZ_VF_SLP);   // (each part is stage-packed by itself)
       return v;
    }
@@ -376,12 +385,12 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       uint32_t W = 0;
       if (n_streams <= 16384) W = g.wave_roles(4) ? 4 : g.wave_roles(3) ? 3 : 0;
       if (!W && n_streams <= 32768 && g.wave_roles(2)) W = 2;
+      // (an I/O wave next to the compute waves, FZ_VF_IO_WAVE, is not a default: it measured +3 % on one board -- 0.374 ms
+      //  against 0.387 ms per 4096 samples at 65 536 streams, 97 % of what a plain copy gets there -- and -4 % on the next;
+      //  fz_program_tune tries it: profiles/r02/sweep_io_wave.txt)
       if (W) {
-         v.P = 1;
-         v.U = reqU ? reqU : (W == 2 ? 16 : 32);
-         v.block = W == 2 ? 128 : 64;
-         v.flags |= (W - 1) << 10;
-         return v;
+         fz_variant q{1, reqU, 0, v.flags | (W - 1) << 10};
+         return resolve_variant(g, &q, n_streams, n_samples);
       }
    }
    // stage packing: one stream per lane, pairs of isomorphic graph segments in one v_pk_* (fz_split.cpp)
@@ -727,7 +736,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, kbuf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
    const unsigned grid = (unsigned)((h.n_groups + v.block - 1) / v.block);
    // (wave split: v.block counts the 64 streams of a workgroup; two waves evaluate them)
-   const unsigned threads = wave_split_of(v.flags) ? v.block * wave_split_of(v.flags) : v.block;
+   const unsigned threads = ws_parts(v.flags) ? v.block * ws_waves(v.flags) : v.block;
    FZ_HIP(hipModuleLaunchKernel((hipFunction_t)fn, grid, 1, 1, threads, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
    static const bool debug = std::getenv("FLOWZ_HIP_DEBUG") != nullptr;
    if (debug) {
@@ -743,16 +752,14 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
 {
    const Variant d = resolve_variant(g, nullptr, n_streams, n_samples);
    std::vector<fz_variant> cands{fz_variant{0, 0, 0, 0}};
-   if (const uint32_t W = wave_split_of(d.flags)) {            // few streams: the wave splits against the single stage-packed wave
-      cands.push_back(fz_variant{1, W == 2 ? 32u : 16u, 0, (W - 1) << 10});
-      if (W != 2 && g.wave_roles(2)) cands.push_back(fz_variant{1, 16, 0, FZ_VF_WAVE_SPLIT});
-      if (W == 2) cands.push_back(fz_variant{1, 16, 64, FZ_VF_WAVE_SPLIT});
+   if (const uint32_t W = ws_parts(d.flags)) {            // few streams: wave splits, with and without an I/O wave, against the single stage-packed wave
+      const uint32_t wbits = (W - 1) << 10;
+      cands.push_back(fz_variant{1, 0, 0, wbits | FZ_VF_IO_WAVE});
+      cands.push_back(fz_variant{1, W == 2 ? 32u : 16u, 0, wbits});
+      if (W > 2 && g.wave_roles(2)) cands.push_back(fz_variant{1, 16, 0, FZ_VF_WAVE_SPLIT});
       cands.push_back(fz_variant{1, 16, 0, FZ_VF_STAGE_PACK});
    } else if (d.flags & FZ_VF_STAGE_PACK) {
-      if (g.wave_roles(2) && n_streams < 65536) {
-         cands.push_back(fz_variant{1, 16, 64, FZ_VF_WAVE_SPLIT});
-         cands.push_back(fz_variant{1, 16, 128, FZ_VF_WAVE_SPLIT});
-      }
+      if (n_streams <= 65536 && g.wave_roles(1)) cands.push_back(fz_variant{1, 16, 0, FZ_VF_IO_WAVE});   // one compute + one I/O wave per 64 streams
       cands.push_back(fz_variant{1, 24, 0, FZ_VF_STAGE_PACK});
       cands.push_back(fz_variant{1, 32, 0, FZ_VF_STAGE_PACK});
    } else if (d.P == 2) {            // many streams, narrow frames: lane packing x prefetch depth x workgroups per CU
