@@ -28,7 +28,9 @@ pass head_p4u12wg1 $HEAD --lanes 4 --unroll 12 --block 256 --flags 1048576
 pass head_p4u16wg1 $HEAD --lanes 4 --unroll 16 --block 256 --flags 1048576
 pass c2_default    --only config2
 pass c2_u24        --only config2 --lanes 1 --unroll 24 --flags 8
+pass c2_io         --only config2 --lanes 1 --unroll 16 --flags 32768
 pass c2h_default   --only config2h
+pass c2h_io        --only config2h --lanes 1 --flags 33792
 pass c2h_u32       --only config2h --lanes 1 --unroll 32 --flags 1024
 pass c3_default    --only config3
 pass c3_u16wg1     --only config3 --lanes 1 --unroll 16 --block 256 --flags 1048576
