@@ -258,6 +258,11 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
 int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */
 /* the same with the variant's automatic fields resolved as fz_run_block would for this block shape */
 int fz_program_build_for(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples);
+/* Part k of the wave split into n_parts (FZ_VF_WAVES(n_parts); n_parts = 1: the graph itself next to an I/O wave) as a
+ * program of its own, for inspection (fz_program_ir, fz_program_lines, fz_program_info): input = the cut wire before the
+ * part (the graph input for k = 0), output = the cut wire behind it; constant slots are the parent's.  FZ_E_UNSUPPORTED when
+ * the graph does not split that way.  Destroy with fz_program_destroy.                                                */
+int fz_program_wave_part(const fz_program* p, uint32_t n_parts, uint32_t k, fz_program** out);
 /* Registers, LDS and scratch memory of a variant's kernel, from the code object's metadata (JITs it; no device needed).
  * The unroll of a variant is an UPPER bound for time-major / tiled frames: a kernel whose prefetch buffers and delay lines
  * do not fit the register file would keep some of them in scratch memory, so fz_run_block halves the unroll until nothing

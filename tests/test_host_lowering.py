@@ -418,6 +418,47 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
             F.compile(F.from_sexpr(bad)).kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT), 4096, 4096)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_wave_parts_compose_to_the_whole_graph(seed):
+    """find_wave_roles on the GPU-less box: fz_program_wave_part hands out every part of every split as a program of its own;
+    their lowered IR, evaluated one after the other through the test interpreter, is the oracle of the whole graph bit for bit;
+    the parts share the operations of the graph exactly, and each is stage-packable by itself."""
+    rng = np.random.default_rng(9500 + seed)
+    form = ["df1", "df2", "df1t"][seed % 3]
+    n = [4, 6, 8, 10, 12, 16][seed % 6]
+
+    def stage():
+        if form == "df1t":
+            return G.df1t()
+        r, th = rng.uniform(0.3, 0.95), rng.uniform(0.1, 3.0)
+        c = (rng.uniform(0.1, 1.0), rng.uniform(-1, 1), rng.uniform(-1, 1), 2 * r * np.cos(th), -r * r)
+        return (G.df1 if form == "df1" else G.df2)(*[float(np.float32(v)) for v in c])
+
+    g = stage()
+    for _ in range(n - 1):
+        g = G.seq(g, stage())
+    p = F.compile(F.from_sexpr(g))
+    x = O.synth_input(seed, np.arange(3), 70)
+    want = O.compile(g, 3).run(x)
+    splits = 0
+    for W in (1, 2, 3, 4):
+        try:
+            parts = [p.wave_part(W, k) for k in range(W)]
+        except F.FlowzError:
+            continue
+        assert sum(q.n_ops for q in parts) == p.n_ops and all(q.stage_packable and (q.n_in, q.n_out) == (1, 1) for q in parts)
+        y = x
+        for q in parts:
+            y, _ = run_ir(q, y)
+        assert np.array_equal(y.view(np.uint32), want.view(np.uint32)), (form, n, W)
+        splits += 1
+    assert splits >= 2                                    # at least the whole graph (I/O wave) and two parts
+    with pytest.raises(F.FlowzError):
+        p.wave_part(2, 2)
+    with pytest.raises(F.FlowzError):
+        F.compile(F.from_sexpr(G.par4_sum())).wave_part(2, 0)
+
+
 def test_sample_rate_modulators_lower_like_the_oracle():
     """fz_modulator: the std::ref terminal at sample rate (flowz/README.md:42-61).  Lowered IR == oracle; the graph is never
     stage-packed; launching without a modulation array is refused."""

@@ -108,6 +108,7 @@ def _load():
         "fz_program_set_const": (ctypes.c_int, [P, u32, f32]),
         "fz_program_build": (ctypes.c_int, [P, ctypes.POINTER(Variant)]),
         "fz_program_build_for": (ctypes.c_int, [P, ctypes.POINTER(Variant), u64, u32]),
+        "fz_program_wave_part": (ctypes.c_int, [P, u32, u32, ctypes.POINTER(P)]),
         "fz_program_kernel_resources": (ctypes.c_int, [P, ctypes.POINTER(Variant), u64, u32, ctypes.c_int, ctypes.POINTER(KernelResources)]),
         "fz_program_kernel_name": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, ctypes.c_char_p, ctypes.c_size_t]),
         "fz_program_source": (ctypes.c_long, [P, ctypes.POINTER(Variant), ctypes.c_char_p, ctypes.c_size_t]),

@@ -31,6 +31,21 @@ int fz_compile(const fz_expr* e, fz_program** out)
       return FZ_OK;)
 }
 
+int fz_program_wave_part(const fz_program* p, uint32_t n_parts, uint32_t k, fz_program** out)
+{
+   FZ_GUARD(
+      if (!p || !out) fail(FZ_E_INVALID, "fz_program_wave_part: null argument");
+      const std::vector<Graph>* roles = p->g.wave_roles(n_parts);
+      if (!roles) fail(FZ_E_UNSUPPORTED, "fz_program_wave_part: the graph does not split into that many parts");
+      if (k >= n_parts) fail(FZ_E_INVALID, "fz_program_wave_part: part index out of range");
+      auto* q = new fz_program();
+      q->g = (*roles)[k];
+      q->g.wave_splits.assign(5, {});
+      q->graph_hash = graph_structure_hash(q->g);
+      *out = q;
+      return FZ_OK;)
+}
+
 int fz_compile_typed(const fz_expr* e, const uint32_t* in_dtypes, uint32_t n_in_wires, fz_program** out)
 {
    FZ_GUARD(

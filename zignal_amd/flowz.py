@@ -230,12 +230,25 @@ class Program:
             C.check(C.lib.fz_compile_typed(self.expr._h, arr, len(dts), ctypes.byref(h)))
         else:
             C.check(C.lib.fz_compile(self.expr._h, ctypes.byref(h)))
+        self._adopt(h)
+
+    def _adopt(self, h):
         self._h = h
         info = C.Info()
         C.check(C.lib.fz_program_info(self._h, ctypes.byref(info)))
         self.info = info
         for f, _ in C.Info._fields_:
             setattr(self, f, getattr(info, f))
+
+    def wave_part(self, n_parts: int, k: int) -> "Program":
+        """Part k of the wave split into n_parts (FZ_VF_WAVES) as a program of its own, for inspection: its input is the cut
+        wire before the part, its output the cut wire behind it."""
+        h = ctypes.c_void_p()
+        C.check(C.lib.fz_program_wave_part(self._h, int(n_parts), int(k), ctypes.byref(h)))
+        q = Program.__new__(Program)
+        q.expr = None
+        q._adopt(h)
+        return q
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
