@@ -256,7 +256,12 @@ Variant settle_variant(fz_program* p, Variant v)
    for (;;) {
       const auto k = get_kernel(p, v, nullptr);
       if (k->res.scratch_bytes == 0) return v;
-      if ((v.flags & FZ_VF_STREAM_MAJOR) || v.U <= (ws_parts(v.flags) ? 8u : 1u)) return v;
+      if (v.flags & FZ_VF_STREAM_MAJOR) return v;
+      if (ws_parts(v.flags) && v.block * ws_waves(v.flags) > 256 && v.block > 64) {
+         v.block /= 2;                                   // more than four waves per workgroup cap the registers of a lane at 256: fewer tuples per workgroup first
+         continue;
+      }
+      if (v.U <= (ws_parts(v.flags) ? 8u : 1u)) return v;
       v.U /= 2;
    }
 }
