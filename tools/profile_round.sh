@@ -37,6 +37,7 @@ pass c3_u16wg1     --only config3 --lanes 1 --unroll 16 --block 256 --flags 1048
 pass c3_u8wg1      --only config3 --lanes 1 --unroll 8 --block 256 --flags 1048576
 pass c3f_default   --only config3f
 pass c3f_p4u8b128  --only config3f --lanes 4 --unroll 8 --block 128 --flags 2097152
+pass c3f_p4u8wg1   --only config3f --lanes 4 --unroll 8 --block 256 --flags 1048576
 pass c4_default    --only config4
 pass c4_p4u8b128   --only config4 --lanes 4 --unroll 8 --block 128 --flags 2097152
 [ -n "$PASSES_ONLY" ] && { for d in $O/pmc_*; do [ -d "$d" ] && find $d -mindepth 2 -name '*.csv' -exec mv {} $d/ \; ; done; ls $O | wc -l; exit 0; }

@@ -804,7 +804,7 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
    hipEvent_t e0, e1;
    FZ_HIP(hipEventCreate(&e0));
    FZ_HIP(hipEventCreate(&e1));
-   float best_ms = 0.f;
+   float best_ms = 0.f, default_ms = 0.f;
    int best = -1;
    std::string first_error;
    // the default is measured twice: the first pass only brings the clocks and the memory system up to
@@ -832,6 +832,7 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
                          kernel_name(g, resolve_variant(g, &cands[c], n_streams, n_samples)).c_str(), (unsigned long long)n_streams,
                          tile_streams, cands[c].streams_per_lane, cands[c].unroll, cands[c].block_threads, cands[c].flags, ms,
                          warmup ? " (warm-up pass)" : "");
+         if (!warmup && c == 0) default_ms = ms;
          if (!warmup && (best < 0 || ms < best_ms)) {
             best = (int)c;
             best_ms = ms;
@@ -848,6 +849,11 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
    (void)hipEventDestroy(e0);
    (void)hipEventDestroy(e1);
    if (best < 0) fail(FZ_E_INVALID, "fz_program_tune: no variant could run: " + first_error);
+   // repeated measurements of one variant scatter by 1-2 %: a candidate replaces the library default only when it wins by more
+   if (best > 0 && default_ms > 0.f && best_ms > 0.985f * default_ms) {
+      best = 0;
+      best_ms = default_ms;
+   }
    int dev = 0;
    FZ_HIP(hipGetDevice(&dev));
    {
