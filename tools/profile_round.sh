@@ -38,6 +38,18 @@ pass c3_u8wg1      --only config3 --lanes 1 --unroll 8 --block 256 --flags 10485
 pass c3f_default   --only config3f
 pass c3f_p4u8b128  --only config3f --lanes 4 --unroll 8 --block 128 --flags 2097152
 pass c3f_p4u8wg1   --only config3f --lanes 4 --unroll 8 --block 256 --flags 1048576
+# every other plan fz_program_tune may select for the fan-out sum and the oscillator chain
+for cfg in c3f:config3f c4:config4; do
+  t=${cfg%%:*}; o=${cfg##*:}
+  pass ${t}_p2u16     --only $o --lanes 2 --unroll 16
+  pass ${t}_p4u8      --only $o --lanes 4 --unroll 8
+  pass ${t}_p2u16wg2  --only $o --lanes 2 --unroll 16 --block 256 --flags 2097152
+  pass ${t}_p2u32wg2  --only $o --lanes 2 --unroll 32 --block 256 --flags 2097152
+  pass ${t}_p4u12wg1  --only $o --lanes 4 --unroll 12 --block 256 --flags 1048576
+  pass ${t}_p4u16wg1  --only $o --lanes 4 --unroll 16 --block 256 --flags 1048576
+  pass ${t}_p4u4wg2   --only $o --lanes 4 --unroll 4 --block 256 --flags 2097152
+done
+pass c4_p4u8wg1    --only config4 --lanes 4 --unroll 8 --block 256 --flags 1048576
 pass c4_default    --only config4
 pass c4_p4u8b128   --only config4 --lanes 4 --unroll 8 --block 128 --flags 2097152
 [ -n "$PASSES_ONLY" ] && { for d in $O/pmc_*; do [ -d "$d" ] && find $d -mindepth 2 -name '*.csv' -exec mv {} $d/ \; ; done; ls $O | wc -l; exit 0; }
