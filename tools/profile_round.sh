@@ -10,8 +10,9 @@ python $R/bench.py > $O/bench_plain.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py > $O/bench_trace.log 2>&1
 fi
 HEAD="--steps 3 --warmup 1 --no-cpu-baseline --no-config2 --no-config34 --no-sustained"
-pass() {   # pass <tag> <bench args...>: one FETCH_SIZE and one WRITE_SIZE run
+pass() {   # pass <tag> <bench args...>: one FETCH_SIZE and one WRITE_SIZE run   (ONLY_TAGS=<regex>: just the matching passes)
   tag=$1; shift
+  if [ -n "$ONLY_TAGS" ] && ! echo "$tag" | grep -Eq "$ONLY_TAGS"; then return; fi
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $O/pmc_${tag}_$c -o b -- python $R/bench.py "$@" > $O/pmc_${tag}_$c.log 2>&1
   done
