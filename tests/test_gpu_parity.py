@@ -664,6 +664,11 @@ SPLITTABLE = {
     "cascade4_distinct_coeffs": lambda: G.df1_cascade(4, [G.STABLE, G.PAR4_SETS[0], G.PAR4_SETS[1], G.PAR4_SETS[2]]),
     "cascade6_distinct_coeffs": lambda: G.df1_cascade(6, [G.STABLE, G.PAR4_SETS[0], G.PAR4_SETS[1], G.PAR4_SETS[2], G.PAR4_SETS[3], G.STABLE]),
     "df2_x4": lambda: G.seq(G.seq(G.df2(*G.STABLE), G.df2(*G.PAR4_SETS[3])), G.seq(G.df2(*G.PAR4_SETS[1]), G.df2(*G.STABLE))),
+    # a scalar prefix goes with the first part, a scalar suffix with the last one
+    "cascade7_prefix_stage": lambda: G.df1_cascade(7),
+    "cascade6_output_gain": lambda: G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1))),
+    "integrator_cascade4_gain": lambda: G.seq(G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 1)), G.IN(2))), G.seq(G.df1_cascade(4), G.mul(G.IN(1), G.lit(1.5)))),
+    "cascade4_smoothing_one_pole": lambda: G.seq(G.df1_cascade(4), G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 1)), G.mul(G.lit(0.5), G.IN(2))))),
 }
 
 
@@ -766,6 +771,30 @@ def test_wave_split_random_cascades(torch_cuda, F, seed):
     assert tried >= 1
 
 
+@pytest.mark.parametrize("T", [5, 64, 300, 1000])
+def test_wave_split_with_scalar_prefix_and_per_stream_coefficients(torch_cuda, F, T):
+    """config 4's graph -- resonator (scalar prefix) -> 6 DF1 stages, 31 per-stream coefficients -- in two and three parts, with and
+    without an I/O wave: the prefix and its coefficients go with part 0; against the compiled C oracle, chained blocks."""
+    ns = 200
+    prog = F.compile(F.from_sexpr(G.osc_chain(6)))
+    P = W.osc_chain_params(SEED + 3, np.arange(ns))
+    x = np.zeros((T, ns, 1), np.float32)
+    x[0] = 1.0
+    want = C.osc_chain(P, x)
+    ref, st_ref = run_gpu(torch_cuda, F, prog, x, params=P, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+    assert ndiff(ref, want) == 0
+    for fl in (F.C.FZ_VF_WAVES(2), F.C.FZ_VF_WAVES(3), F.C.FZ_VF_WAVES(2) | F.C.FZ_VF_IO_WAVE, F.C.FZ_VF_WAVES(3) | F.C.FZ_VF_IO_WAVE):
+        v = F.make_variant(1, 16, 0, fl)
+        got, st = run_gpu(torch_cuda, F, prog, x, params=P, variant=v)
+        assert ndiff(got, want) == 0 and ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0, (T, fl)
+        cut = T // 3 + 1
+        a, st1 = run_gpu(torch_cuda, F, prog, x[:cut], params=P, variant=v)
+        b, _ = run_gpu(torch_cuda, F, prog, x[cut:], params=P, variant=v, state=st1) if cut < T else (x[:0], None)
+        assert ndiff(np.concatenate([a, b]), want) == 0, (T, fl)
+    with pytest.raises(F.FlowzError):
+        prog.kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVES(4)), ns, T)         # six segments do not make four parts
+
+
 def test_wave_split_blocks_chain_tiles_and_refusals(torch_cuda, F):
     """blocks of a wave-split kernel chain with every other variant through the canonical state; stream-tiled frames;
     graphs that are not two isomorphic halves are refused."""
@@ -791,7 +820,7 @@ def test_wave_split_blocks_chain_tiles_and_refusals(torch_cuda, F):
     f, st = run_gpu(torch, F, prog, x[:101], variant=w3)
     h, st = run_gpu(torch, F, prog, x[101:], variant=ws, state=st)
     assert ndiff(np.concatenate([f, h]), want) == 0
-    for bad in (G.df1_cascade(2), G.par4_sum_fanout(), G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1)))):
+    for bad in (G.df1_cascade(2), G.df1_cascade(3), G.par4_sum_fanout()):
         with pytest.raises(F.FlowzError):
             F.compile(F.from_sexpr(bad)).run_block(torch.zeros((4, 64, 1), device="cuda"), variant=ws)
     with pytest.raises(F.FlowzError):

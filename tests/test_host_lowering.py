@@ -408,14 +408,43 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
     assert q.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w4f3072" and "#define FZ_WS_W 4" in q.source(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVES(4)))
     src = p.source(F.make_variant(1, 16, 0, IO))
     assert "#define FZ_WS_IO 1" in src and "#define FZ_WS_W 1" in src and "#define FZ_WS_K0 6" in src
-    for name in ("par4_sum", "par4_sum_fanout", "osc_chain6"):
+    for name in ("par4_sum", "par4_sum_fanout"):
         q = F.compile(F.from_sexpr(BASELINE_GRAPHS[name]()))
         assert "w" not in q.kernel_name(None, 32768, 4096).split("b", 2)[2]
         with pytest.raises(F.FlowzError):
             q.kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT), 32768, 4096)
-    for bad in (G.df1_cascade(2), G.df1_cascade(3), G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1)))):
+    q = F.compile(F.from_sexpr(BASELINE_GRAPHS["osc_chain6"]()))          # scalar prefix + per-stream coefficients: they go with part 0
+    assert q.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u16b128w2f1024" and q.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w3f2048"
+    assert [q.wave_part(3, k).n_ops for k in range(3)] == [21, 18, 18] and q.wave_part(3, 0).n_param == q.n_param
+    for bad in (G.df1_cascade(2), G.df1_cascade(3), G.par4_sum()):
         with pytest.raises(F.FlowzError):
             F.compile(F.from_sexpr(bad)).kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT), 4096, 4096)
+
+
+def test_wave_parts_with_prefix_suffix_and_per_stream_coefficients_compose():
+    """a scalar prefix (an oscillator, an odd first stage) goes with the first part, a scalar suffix (output gain, smoothing
+    one-pole) with the last, per-stream coefficients with whoever reads them: the parts' IR composed == the oracle"""
+    ns = 3
+    cases = {"osc6": G.osc_chain(6), "c6gain": G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1))), "c7": G.df1_cascade(7),
+             "int_c4_gain": G.seq(G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 1)), G.IN(2))), G.seq(G.df1_cascade(4), G.mul(G.IN(1), G.lit(1.5)))),
+             "c4_onepole": G.seq(G.df1_cascade(4), G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 1)), G.mul(G.lit(0.5), G.IN(2)))))}
+    for name, g in cases.items():
+        p = F.compile(F.from_sexpr(g))
+        P = W.osc_chain_params(5, np.arange(ns)) if p.n_param else None
+        x = O.synth_input(3, np.arange(ns), 60)
+        want = O.compile(g, ns, params=P).run(x)
+        done = 0
+        for Wn in (2, 3):
+            try:
+                parts = [p.wave_part(Wn, k) for k in range(Wn)]
+            except F.FlowzError:
+                continue
+            y = x
+            for q in parts:
+                y, _ = run_ir(q, y, params=P)
+            assert np.array_equal(y.view(np.uint32), want.view(np.uint32)) and sum(q.n_ops for q in parts) == p.n_ops, (name, Wn)
+            done += 1
+        assert done >= 1, name
 
 
 @pytest.mark.parametrize("seed", range(12))

@@ -324,7 +324,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       const uint32_t waves = ws_waves(v.flags);
       if (!g.wave_roles(W))
          fail(FZ_E_UNSUPPORTED, W == 1 ? "FZ_VF_IO_WAVE: the graph is not stage-packable (1 in, 1 out, register delay lines)"
-                                       : "wave split: the graph is not that many groups of isomorphic segments in series (1 in, 1 out, uniform coefficients, register delay lines, no scalar prefix or suffix)");
+                                       : "wave split: the graph is not that many groups of isomorphic segments in series (1 in, 1 out, register delay lines)");
       if (reqP > 1) fail(FZ_E_INVALID, "wave split needs streams_per_lane == 1");
       if (reqB && (reqB % 64 || reqB * waves > 1024)) fail(FZ_E_INVALID, "wave split: block_threads counts the streams of a workgroup: a multiple of 64, at most 1024 / waves per tuple");
       if (reqU && reqU != 8 && reqU != 16 && reqU != 32) fail(FZ_E_INVALID, "wave split: unroll must be 8, 16 or 32");

@@ -322,7 +322,7 @@ static bool extract_part(const Graph& g, const std::vector<char>* before, const 
       const Node& n = g.nodes[v];
       if (!first && v == cin) return false;               // (added above)
       if (!upto[v]) return false;
-      if (n.kind == FZ_IR_CONST) return true;
+      if (n.kind == FZ_IR_CONST || n.kind == FZ_IR_PARAM) return true;
       if (n.kind == FZ_IR_DELAY && !first && n.a == cin) return true;
       return first || !(*before)[v];
    };
@@ -333,6 +333,7 @@ static bool extract_part(const Graph& g, const std::vector<char>* before, const 
       switch (n.kind) {
          case FZ_IR_INPUT: if (!first) return false; break;
          case FZ_IR_CONST: break;
+         case FZ_IR_PARAM: r.n_param = g.n_param; break;   // per-stream coefficient: the parent's row
          case FZ_IR_DELAY: break;                          // source patched below (it may come later in the order)
          case FZ_IR_NEG:
             if (op(n.a) < 0) return false;
@@ -380,18 +381,23 @@ static bool extract_part(const Graph& g, const std::vector<char>* before, const 
 
 std::vector<Graph> find_wave_roles(const Graph& g, uint32_t W)
 {
-   if (W < 2 || !g.split.ok || g.typed || g.n_param || g.n_mod || g.n_lds_slots || !g.far_lines.empty() || g.n_in != 1 || g.n_out != 1) return {};
+   if (W < 2 || !g.split.ok || g.typed || g.n_mod || g.n_lds_slots || !g.far_lines.empty() || g.n_in != 1 || g.n_out != 1) return {};
    // the chain itself, input to output, in a number of segments the parts divide (the graph's own stage split may prefer
-   // more segments behind a scalar prefix: a 12-biquad cascade is 8 segments of 13 operations after 4, but also 6 x 2 biquads)
-   const StageSplit sp = find_stage_split(g, true, W);
-   if (!sp.ok || sp.K < W || sp.K % W || !sp.prefix.empty() || !sp.suffix.empty()) return {};
+   // more segments behind a scalar prefix: a 12-biquad cascade is 8 segments of 13 operations after 4, but also 6 x 2 biquads);
+   // failing that the graph's own split, scalar prefix and suffix included: they go with the first and the last part
+   // (an oscillator in front of a cascade: part 0 is the oscillator and the first stages)
+   StageSplit sp = find_stage_split(g, true, W);
+   if (!sp.ok || sp.K < W || sp.K % W) sp = g.split;
+   if (!sp.ok || sp.K < W || sp.K % W) return {};
    const uint32_t N = (uint32_t)g.nodes.size(), m = sp.K / W;
    std::vector<std::vector<char>> clo;                     // closure of the wire that ends part k
-   for (uint32_t k = 0; k < W; ++k) clo.push_back(closure_of(g, sp.cuts[(k + 1) * m]));
+   std::vector<uint32_t> ends(W);                          // the wire behind part k; the last part ends at the graph output (suffix included)
+   for (uint32_t k = 0; k < W; ++k) ends[k] = k + 1 < W ? sp.cuts[(k + 1) * m] : g.outputs[0];
+   for (uint32_t k = 0; k < W; ++k) clo.push_back(closure_of(g, ends[k]));
    std::vector<Graph> roles(W);
    uint32_t ops = 0;
    for (uint32_t k = 0; k < W; ++k) {
-      if (!extract_part(g, k ? &clo[k - 1] : nullptr, clo[k], k ? sp.cuts[k * m] : N, sp.cuts[(k + 1) * m], roles[k])) return {};
+      if (!extract_part(g, k ? &clo[k - 1] : nullptr, clo[k], k ? ends[k - 1] : N, ends[k], roles[k])) return {};
       ops += roles[k].n_ops;
    }
    if (ops != g.n_ops) return {};                          // every operation sits in exactly one part
