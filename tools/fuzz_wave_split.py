@@ -36,6 +36,13 @@ for seed in range(first, first + count):
     g = stage()
     for _ in range(n - 1):
         g = G.seq(g, stage())
+    r = rng.random()
+    if r < 0.2:                                            # a scalar prefix in front of the chain
+        g = G.seq(G.fb(G.add(G.mul(G.lit(float(np.float32(rng.uniform(0.1, 0.6)))), G.DEL(1, 1)), G.IN(2))), g)
+    elif r < 0.4:                                          # a scalar suffix behind it
+        g = G.seq(g, G.mul(G.lit(float(np.float32(rng.uniform(0.2, 1.5)))), G.IN(1)))
+    elif r < 0.5:                                          # both
+        g = G.seq(G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 1)), G.IN(2))), G.seq(g, G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 1)), G.mul(G.lit(0.5), G.IN(2))))))
     prog = F.compile(F.from_sexpr(g))
     ns, T = int(rng.integers(1, 700)), int(rng.integers(1, 1500))
     x = O.synth_input(seed, np.arange(ns), T)
