@@ -795,6 +795,35 @@ def test_wave_split_with_scalar_prefix_and_per_stream_coefficients(torch_cuda, F
         prog.kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVES(4)), ns, T)         # six segments do not make four parts
 
 
+def test_wave_split_windows_and_block_rate_coefficients(torch_cuda, F):
+    """windows of a long recording (fz_run_block_window: rows [row0, row0 + n) of larger frame buffers, time-major and tiled) through
+    the wave-split and I/O-wave kernels, per-stream coefficients swapped between the windows (config 4's graph)."""
+    torch = torch_cuda
+    ns, T, tile = 1024, 900, 256
+    g = G.osc_chain(6)
+    prog = F.compile(F.from_sexpr(g))
+    x = O.synth_input(SEED + 93, np.arange(ns), T)
+    cuts = [0, 300, 301, 640, 900]
+    Ps = [W.osc_chain_params(SEED + 94 + k, np.arange(ns)) for k in range(len(cuts) - 1)]
+    f = O.compile(g, ns, params=Ps[0])
+    want = []
+    for k in range(len(cuts) - 1):
+        f._params = np.ascontiguousarray(Ps[k], np.float32)
+        want.append(f.run(x[cuts[k]:cuts[k + 1]]))
+    want = np.concatenate(want)
+    variants = [F.make_variant(1, 16, 0, F.C.FZ_VF_WAVES(2)), F.make_variant(1, 32, 0, F.C.FZ_VF_WAVES(3) | F.C.FZ_VF_IO_WAVE),
+                F.make_variant(1, 16, 0, F.C.FZ_VF_IO_WAVE), F.make_variant(1, 8, 64, F.C.FZ_VF_WAVES(3))]
+    for tiled in (False, True):
+        xd = torch.from_numpy(x).cuda()
+        xd = F.to_tiled(xd, tile) if tiled else xd
+        od = torch.zeros_like(xd)
+        st = torch.zeros((prog.n_state, ns), dtype=torch.float32, device="cuda")
+        for k in range(len(cuts) - 1):
+            prog.run_window(xd, od, st, cuts[k], cuts[k + 1] - cuts[k], params=torch.from_numpy(Ps[k]).cuda(), variant=variants[k])
+        got = (F.from_tiled(od) if tiled else od).contiguous().cpu().numpy()
+        assert ndiff(got, want) == 0, tiled
+
+
 def test_wave_split_blocks_chain_tiles_and_refusals(torch_cuda, F):
     """blocks of a wave-split kernel chain with every other variant through the canonical state; stream-tiled frames;
     graphs that are not two isomorphic halves are refused."""
