@@ -46,7 +46,7 @@ static fz_expr* parse(std::istringstream& in)
 int main()
 {
    std::string line;
-   unsigned n = 0, lowered = 0, rejected = 0, packable = 0;
+   unsigned n = 0, lowered = 0, rejected = 0, packable = 0, split = 0;
    size_t bytes = 0;
    while (std::getline(std::cin, line)) {
       if (line.empty()) continue;
@@ -71,12 +71,19 @@ int main()
             v.P = 1; v.U = 16; v.block = 256; v.flags = FZ_VF_STAGE_PACK;
             bytes += full_source(g, v).size();
          }
+         for (uint32_t W = 1; W <= 4; ++W)                  // wave splits / the I/O wave: role extraction ran in lower(), now their bodies
+            if (g.wave_roles(W)) {
+               Variant v;
+               v.P = 1; v.U = 16; v.block = 64; v.flags = (W > 1 ? (W - 1) << 10 : 0u) | (W == 1 || (n & 1) ? (uint32_t)FZ_VF_IO_WAVE : 0u);
+               bytes += full_source(g, v).size();
+               ++split;
+            }
          (void)max_input_delays(e);
       } catch (const Error&) {
          ++rejected;
       }
       fz_expr_release(e);
    }
-   std::printf("graphs %u lowered %u rejected %u stage-packable %u generated %zu bytes\n", n, lowered, rejected, packable, bytes);
+   std::printf("graphs %u lowered %u rejected %u stage-packable %u wave-split bodies %u generated %zu bytes\n", n, lowered, rejected, packable, split, bytes);
    return lowered > 0 ? 0 : 1;
 }

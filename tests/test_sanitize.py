@@ -35,7 +35,7 @@ def test_lowering_and_codegen_under_asan_ubsan(tmp_path):
     for seed in range(300):
         lines.append(prefix(R.make(seed)[0]))
         lines.append(prefix(R.make_typed(seed)[0]))
-    for g in (G.df1_cascade(6), G.df1_cascade(7), G.par4_sum(), G.par4_sum_fanout(), G.osc_chain(6), G.cross_wire(),
+    for g in (G.df1_cascade(6), G.df1_cascade(7), G.df1_cascade(8), G.df1_cascade(12), G.df1_cascade(16), G.par4_sum(), G.par4_sum_fanout(), G.osc_chain(6), G.cross_wire(),
               G.one_pole_readme(), G.mixed_precision_biquad(), G.complex_mix(), G.df1t(), G.df2t(),
               ("seq", ("in", 1), ("del", 1, 300)), ("seq", ("in", 1), ("add", ("del", 1, 40), ("del", 1, 5000))),
               ("seq", ("in", 1), ("add", ("del", 1, 12), ("del", 1, 700))),                       # far line + mid-range read
@@ -55,3 +55,4 @@ def test_lowering_and_codegen_under_asan_ubsan(tmp_path):
     assert "lowered" in out.stdout
     n_low = int(out.stdout.split("lowered")[1].split()[0])
     assert n_low > 500, out.stdout
+    assert int(out.stdout.split("wave-split bodies")[1].split()[0]) >= 15, out.stdout   # role extraction + the bodies of every split
