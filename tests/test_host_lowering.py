@@ -181,6 +181,42 @@ def test_no_fma_contraction_in_generated_kernel(tmp_path, monkeypatch):
         assert ".vgpr_spill_count: 0" in notes and ".private_segment_fixed_size: 0" in notes
 
 
+def test_wave_split_kernels_in_the_isa(tmp_path, monkeypatch):
+    """the wave-split / I/O-wave code objects, disassembled: no contraction, no scratch, no waterfall loop around a buffer access
+    (a descriptor built from a VGPR would cost one per load), the cut wire moves as 16-byte LDS accesses, one s_barrier per round
+    body, and a part of the 6-biquad cascade issues 18 arithmetic instructions per step instead of the 27 of the whole graph."""
+    import subprocess
+    monkeypatch.setenv("FLOWZ_HIP_CACHE", str(tmp_path))
+    p = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    for fl in (F.C.FZ_VF_WAVES(2), F.C.FZ_VF_WAVES(3), F.C.FZ_VF_IO_WAVE, F.C.FZ_VF_WAVES(2) | F.C.FZ_VF_IO_WAVE):
+        p.build(F.make_variant(1, 16, 0, fl))
+    objs = list(tmp_path.glob("*.hsaco"))
+    assert len(objs) == 4
+    for obj in objs:
+        dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", str(obj)], text=True)
+        notes = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(obj)], text=True)
+        assert not re.search(r"v_(pk_)?(fma|fmac|mad|mac)_", dis)
+        assert ".vgpr_spill_count: 0" in notes and ".private_segment_fixed_size: 0" in notes
+        assert "v_cmp_eq_u64" not in dis and dis.count("v_readfirstlane_b32") < 16            # no waterfall loops (readfirstlane x 4 + 64-bit compares per access)
+        assert "ds_write_b128" in dis and "ds_read_b128" in dis and "s_barrier" in dis
+        assert "scratch_" not in dis and "flat_load" not in dis and "flat_store" not in dis
+    # instruction count of an unmasked round of a two-part wave: between two barriers with no v_cndmask in between
+    dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", str(
+        [o for o in objs if "w2f1024" in subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(o)], text=True)][0])], text=True)
+    ops = [ln.split()[0] for ln in dis.splitlines() if ln.startswith("\t")]
+    rounds, cur = [], []
+    for op in ops:
+        if op == "s_barrier":
+            rounds.append(cur)
+            cur = []
+        else:
+            cur.append(op)
+    plain = [r for r in rounds if r and not any(o.startswith("v_cndmask") for o in r) and sum(o.startswith("v_pk_") for o in r) >= 16 * 9]
+    assert plain, "no unmasked round found"
+    arith = min(sum(o.startswith(("v_pk_mul", "v_pk_add", "v_mul_f32", "v_add_f32", "v_sub_f32")) for o in r) for r in plain)
+    assert arith == 16 * 18, arith                                        # 9 packed + 9 scalar per step, 16 steps per round
+
+
 def test_product_fails_loudly_without_gpu():
     if F.device_count() > 0:
         pytest.skip("GPU present")
