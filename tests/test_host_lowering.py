@@ -424,7 +424,7 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
     suffix, per-stream coefficients, several wires, an odd or a single pair of segments."""
     from zignal_amd.workloads import BASELINE_GRAPHS
     p = F.compile(F.from_sexpr(G.df1_cascade(6)))
-    assert p.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u16b128w2f1024"             # two compute waves per 64 streams
+    assert p.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u32b128w2f1024"             # two compute waves per 64 streams
     assert p.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w3f2048"              # 256 workgroups of three waves: two biquads each
     assert p.kernel_name(None, 65536, 4096).startswith("fz_block_kernel_p1u16b256s6f")       # one wave per SIMD already
     assert p.kernel_name(F.make_variant(0, 0, 0, F.C.FZ_VF_IO_WAVE), 65536, 4096) == "fz_block_kernel_p1u16b256w1iof32768"   # ... or an I/O wave next to it
@@ -450,7 +450,7 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
         with pytest.raises(F.FlowzError):
             q.kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT), 32768, 4096)
     q = F.compile(F.from_sexpr(BASELINE_GRAPHS["osc_chain6"]()))          # scalar prefix + per-stream coefficients: they go with part 0
-    assert q.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u16b128w2f1024" and q.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w3f2048"
+    assert q.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u32b128w2f1024" and q.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w3f2048"
     assert [q.wave_part(3, k).n_ops for k in range(3)] == [21, 18, 18] and q.wave_part(3, 0).n_param == q.n_param
     for bad in (G.df1_cascade(2), G.df1_cascade(3), G.par4_sum()):
         with pytest.raises(F.FlowzError):

@@ -331,7 +331,8 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       if (v.flags & (FZ_VF_STREAM_MAJOR | FZ_VF_OUT_F64 | FZ_VF_PREFETCH3))
          fail(FZ_E_UNSUPPORTED, "wave split: time-major / tiled float32 frames, double buffering only");
       v.P = 1;
-      v.U = reqU ? reqU : (W <= 2 ? 16 : 32);           // (one barrier per round: three and four waves in lockstep do better with longer rounds)
+      v.U = reqU ? reqU : (W == 1 ? 16 : 32);           // (one barrier per round: waves in lockstep do better with longer rounds -- two parts +1.5 %, three +8 %;
+                                                        //  the lone compute wave next to an I/O wave keeps 16: its rings fill the LDS at 32)
       // the waves of a workgroup go to consecutive SIMDs of a CU: pairs come two to a workgroup (one wave on each of the
       // four SIMDs), triples and quadruples one
       // (with I/O waves: one compute wave on each SIMD and the I/O waves next to them -- 4 tuples for one part, 2 for two)
@@ -760,7 +761,7 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
    if (const uint32_t W = ws_parts(d.flags)) {            // few streams: wave splits, with and without an I/O wave, against the single stage-packed wave
       const uint32_t wbits = (W - 1) << 10;
       cands.push_back(fz_variant{1, 0, 0, wbits | FZ_VF_IO_WAVE});
-      cands.push_back(fz_variant{1, W == 2 ? 32u : 16u, 0, wbits});
+      cands.push_back(fz_variant{1, 16, 0, wbits});
       if (W > 2 && g.wave_roles(2)) cands.push_back(fz_variant{1, 16, 0, FZ_VF_WAVE_SPLIT});
       cands.push_back(fz_variant{1, 16, 0, FZ_VF_STAGE_PACK});
    } else if (d.flags & FZ_VF_STAGE_PACK) {
