@@ -320,7 +320,7 @@ def main():
     ap.add_argument("--no-config2", action="store_true", help="skip the 65 536-stream measurement (BASELINE configs[1])")
     ap.add_argument("--no-config34", action="store_true", help="skip BASELINE configs[2] and [3] (4-parallel sum, oscillator chain)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s back-to-back run")
-    ap.add_argument("--only", default="", help="profiling aid: run ONLY this secondary config (config2|config2h|config3|config3f|config4) "
+    ap.add_argument("--only", default="", help="profiling aid: run ONLY this secondary config (config2|config2h|config2q|config3|config3f|config4) "
                                                "with the forced / default variant and print its object")
     ap.add_argument("--no-autotune", action="store_true",
                     help="do not try the alternative kernel variants during warm-up (the pool's boxes differ by a few %%)")
@@ -399,7 +399,7 @@ def main():
         from oracle import coracle, flowz_oracle as O
         want = coracle.df1_cascade([W.STABLE] * 6, O.synth_input(SEED, ids, T))
         res["parity"] = parity_string(ndiff_bits(gather_streams(torch, y2, ids, t2), want), len(ids), T)
-        res["workload"] = (f"6-stage DF1 cascade, {ns2} streams x {T}-sample block " + ("(BASELINE configs[1]), " if ns2 == 65536 else "(half of configs[1]: fewer streams than lanes), ")
+        res["workload"] = (f"6-stage DF1 cascade, {ns2} streams x {T}-sample block " + ("(BASELINE configs[1]), " if ns2 == 65536 else "(configs[1] with fewer streams than lanes), ")
                            + (f"tiled:{t2}" if t2 else "time-major"))
         # compatibility with round 1's keys: the best plan's figures at top level
         res.update({k: res[res["best_plan"]][k] for k in ("avg_launch_ms", "Msamples_per_s", "achieved_GBs", "kernel")})
@@ -462,7 +462,7 @@ def main():
 
     ns3 = args.streams
     if args.only:
-        fn = {"config2": config2, "config2h": lambda: config2(32768), "config3": lambda: config3(False), "config3f": lambda: config3(True),
+        fn = {"config2": config2, "config2h": lambda: config2(32768), "config2q": lambda: config2(16384), "config3": lambda: config3(False), "config3f": lambda: config3(True),
               "config4": config4}[args.only]
         print(json.dumps({args.only: fn()}), flush=True)
         return
@@ -549,7 +549,9 @@ def main():
         if not args.no_config2 and ns != 65536:
             secondary["config2_65536_streams"] = config2()
             torch.cuda.empty_cache()
-            secondary["cascade6_32768_streams"] = config2(32768)    # below one wave per SIMD: the wave-split kernel
+            secondary["cascade6_32768_streams"] = config2(32768)    # below one wave per SIMD: the wave-split kernel (two parts)
+            torch.cuda.empty_cache()
+            secondary["cascade6_16384_streams"] = config2(16384)    # a quarter of a wave per SIMD: three parts
             torch.cuda.empty_cache()
         if not args.no_config34:
             secondary["config3_par4_sum"] = config3(False)

@@ -31,7 +31,7 @@ def test_bench_json_contract_small_workload():
     assert d["parity"].startswith("bitwise-equal")
     assert d["roofline"]["sustained"]["seconds"] >= 1.9 and d["roofline"]["sustained"]["frac"] > 0
     assert "traffic_kernel" in d["roofline"]
-    for k in ("config2_65536_streams", "cascade6_32768_streams", "config3_par4_sum", "config3_par4_sum_fanout", "config4_osc_chain"):
+    for k in ("config2_65536_streams", "cascade6_32768_streams", "cascade6_16384_streams", "config3_par4_sum", "config3_par4_sum_fanout", "config4_osc_chain"):
         assert d[k]["parity"].startswith("bitwise-equal"), (k, d[k]["parity"])
         assert d[k]["library_default"]["frac"] > 0 and d[k]["tuned"]["kernel"].startswith("fz_block_kernel_p")
     assert c["Msamples_per_s_per_core"] > 0 and c["physical_cores"] >= 1 and c["logical_cpus"] >= c["physical_cores"]

@@ -33,6 +33,8 @@ pass c2_io         --only config2 --lanes 1 --unroll 16 --flags 32768
 pass c2h_default   --only config2h
 pass c2h_io        --only config2h --lanes 1 --flags 33792
 pass c2h_u32       --only config2h --lanes 1 --unroll 32 --flags 1024
+pass c2q_default   --only config2q
+pass c2q_io        --only config2q --lanes 1 --flags 34816
 pass c3_default    --only config3
 pass c3_u16wg1     --only config3 --lanes 1 --unroll 16 --block 256 --flags 1048576
 pass c3_u8wg1      --only config3 --lanes 1 --unroll 8 --block 256 --flags 1048576
