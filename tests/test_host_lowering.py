@@ -424,8 +424,8 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
     suffix, per-stream coefficients, several wires, an odd or a single pair of segments."""
     from zignal_amd.workloads import BASELINE_GRAPHS
     p = F.compile(F.from_sexpr(G.df1_cascade(6)))
-    assert p.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u32b128w2f1024"             # two compute waves per 64 streams
-    assert p.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w3f2048"              # 256 workgroups of three waves: two biquads each
+    assert p.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u32b128w2iof33792"          # two compute waves + an I/O wave per 64 streams
+    assert p.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w3iof34816"           # 256 workgroups: three compute waves of two biquads each + an I/O wave
     assert p.kernel_name(None, 65536, 4096).startswith("fz_block_kernel_p1u16b256s6f")       # one wave per SIMD already
     assert p.kernel_name(F.make_variant(0, 0, 0, F.C.FZ_VF_IO_WAVE), 65536, 4096) == "fz_block_kernel_p1u16b256w1iof32768"   # ... or an I/O wave next to it
     assert p.kernel_name(None, 32768, 200).startswith("fz_block_kernel_p1u16b256s6f")        # short blocks: the ends would dominate
@@ -437,8 +437,8 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
     IO = F.C.FZ_VF_IO_WAVE
     r = p.kernel_resources(F.make_variant(0, 0, 0, IO), 65536, 4096)
     assert r["scratch_bytes"] == 0 and r["lds_bytes"] == 4 * 2 * 16 * 64 * 16                   # four (compute, I/O) pairs x two rings of 16 groups
-    assert [v.flags for v in p.tune_candidates(32768, 4096)][:4] == [0, F.C.FZ_VF_WAVES(2) | IO, F.C.FZ_VF_WAVES(2), 8]
-    assert [v.flags for v in p.tune_candidates(16384, 4096)][:4] == [0, F.C.FZ_VF_WAVES(3) | IO, F.C.FZ_VF_WAVES(3), F.C.FZ_VF_WAVES(2)]
+    assert [v.flags for v in p.tune_candidates(32768, 4096)][:4] == [0, F.C.FZ_VF_WAVES(2), F.C.FZ_VF_WAVES(2) | IO, 8]
+    assert [v.flags for v in p.tune_candidates(16384, 4096)][:4] == [0, F.C.FZ_VF_WAVES(3), F.C.FZ_VF_WAVES(3) | IO, F.C.FZ_VF_WAVES(2)]
     assert IO in [v.flags for v in p.tune_candidates(65536, 4096)]
     q = F.compile(F.from_sexpr(G.df1_cascade(8)))
     assert q.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w4f3072" and "#define FZ_WS_W 4" in q.source(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVES(4)))
@@ -450,7 +450,7 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
         with pytest.raises(F.FlowzError):
             q.kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT), 32768, 4096)
     q = F.compile(F.from_sexpr(BASELINE_GRAPHS["osc_chain6"]()))          # scalar prefix + per-stream coefficients: they go with part 0
-    assert q.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u32b128w2f1024" and q.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w3f2048"
+    assert q.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u32b128w2iof33792" and q.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w3iof34816"
     assert [q.wave_part(3, k).n_ops for k in range(3)] == [21, 18, 18] and q.wave_part(3, 0).n_param == q.n_param
     for bad in (G.df1_cascade(2), G.df1_cascade(3), G.par4_sum()):
         with pytest.raises(F.FlowzError):

@@ -391,11 +391,13 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       uint32_t W = 0;
       if (n_streams <= 16384) W = g.wave_roles(4) ? 4 : g.wave_roles(3) ? 3 : 0;
       if (!W && n_streams <= 32768 && g.wave_roles(2)) W = 2;
-      // (an I/O wave next to the compute waves, FZ_VF_IO_WAVE, is not a default: it measured +3 % on one board -- 0.374 ms
-      //  against 0.387 ms per 4096 samples at 65 536 streams, 97 % of what a plain copy gets there -- and -4 % on the next;
-      //  fz_program_tune tries it: profiles/r02/sweep_io_wave.txt)
+      // The splits come with an I/O wave (FZ_VF_IO_WAVE): +2-4 % on every board measured (three parts at 16 384 streams:
+      // 0.397 / 0.406 / 0.397 / 0.428 of peak against 0.387 / 0.394 / 0.384 / 0.410; two parts at 32 768: 0.596 / 0.593 against
+      // 0.580 / 0.574).  The lone compute wave with an I/O wave at 65 536 streams is NOT a default: +3 % on one board -- 0.374 ms
+      // against 0.387 ms per 4096 samples, 97 % of what a plain copy gets there -- and -4 % on the next; fz_program_tune tries
+      // it (profiles/r02/sweep_io_wave.txt)
       if (W) {
-         fz_variant q{1, reqU, 0, v.flags | (W - 1) << 10};
+         fz_variant q{1, reqU, 0, v.flags | (W - 1) << 10 | (W < 4 ? (uint32_t)FZ_VF_IO_WAVE : 0u)};
          return resolve_variant(g, &q, n_streams, n_samples);
       }
    }
@@ -760,8 +762,8 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
    std::vector<fz_variant> cands{fz_variant{0, 0, 0, 0}};
    if (const uint32_t W = ws_parts(d.flags)) {            // few streams: wave splits, with and without an I/O wave, against the single stage-packed wave
       const uint32_t wbits = (W - 1) << 10;
-      cands.push_back(fz_variant{1, 0, 0, wbits | FZ_VF_IO_WAVE});
-      cands.push_back(fz_variant{1, 16, 0, wbits});
+      cands.push_back(fz_variant{1, 0, 0, wbits | (ws_io(d.flags) ? 0u : (uint32_t)FZ_VF_IO_WAVE)});   // the same split without / with the I/O wave
+      cands.push_back(fz_variant{1, 16, 0, wbits | (d.flags & FZ_VF_IO_WAVE)});
       if (W > 2 && g.wave_roles(2)) cands.push_back(fz_variant{1, 16, 0, FZ_VF_WAVE_SPLIT});
       cands.push_back(fz_variant{1, 16, 0, FZ_VF_STAGE_PACK});
    } else if (d.flags & FZ_VF_STAGE_PACK) {
