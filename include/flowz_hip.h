@@ -244,6 +244,9 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
                                    hands them to the compute wave(s) through LDS, and stores the rows they hand back; the compute
                                    wave is left with arithmetic and LDS accesses.  Alone (a stage-packable graph: one compute wave
                                    + one I/O wave, 4 such pairs per workgroup) or together with FZ_VF_WAVES(n)                   */
+       FZ_VF_LOCKSTEP = 524288u, /* time-major / tiled frames: the waves of a workgroup meet at a barrier after every chunk and so walk the
+                                   same rows at the same time -- with plain time-major frames of many streams (rows megabytes apart)
+                                   that keeps the pages a CU has in flight few; chosen automatically there                        */
        FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
                                    float*): the results of graphs with double literals leave un-narrowed, float
                                    wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */

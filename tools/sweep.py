@@ -59,8 +59,15 @@ def main():
         t += [0] * (4 - len(t))
         vs.append((s, F.make_variant(*t)))
     times = {s: [] for s, _ in vs}
-    for s, v in vs:                              # warm (JIT + first touch)
-        prog.run_block(x, state=state, params=params, out=y, variant=v)
+    ok = []
+    for s, v in vs:                              # warm (JIT + first touch); a variant the graph / shape refuses is reported and skipped
+        try:
+            prog.run_block(x, state=state, params=params, out=y, variant=v)
+            ok.append((s + " " + prog.kernel_name(v, ns, T).replace("fz_block_kernel_", ""), v))
+        except F.FlowzError as e:
+            print(f"# {s}: refused: {str(e)[:120]}")
+    vs = ok
+    times = {s: [] for s, _ in vs}
     torch.cuda.synchronize()
     for _ in range(a.rounds):
         for s, v in vs:

@@ -28,6 +28,7 @@ FZ_VF_NO_NT, FZ_VF_NO_XCD_REMAP, FZ_VF_SLP, FZ_VF_STAGE_PACK, FZ_VF_NO_STAGE_PAC
 FZ_VF_PREFETCH3 = 32
 FZ_VF_STREAM_MAJOR = 128
 FZ_VF_SM_LONG, FZ_VF_SM_SHORT, FZ_VF_WAVE_SPLIT, FZ_VF_IO_WAVE = 256, 512, 1024, 32768
+FZ_VF_LOCKSTEP = 524288
 
 
 def FZ_VF_WAVES(n):

@@ -182,7 +182,7 @@ struct Kernel {
    std::string cache_path;        // on-disk cache file it came from / went to ("" = none)
    std::vector<Loaded> loaded;    // one module per device the kernel ran on
    void* function_on_current_device(const std::string& symbol);   // loads on first use (caller holds the program mutex)
-   ~Kernel();                     // unloads the modules (fz_runtime.hip)
+   ~Kernel();                     // unloads the modules (fz_kernel_cache.cpp)
 };
 
 }  // namespace fz

@@ -1,0 +1,291 @@
+// hiprtc build of the fused block kernel + on-disk code-object cache, module loading, and the register-budget rule
+// (no kernel runs from scratch memory).  gfx950 only.
+#include <hip/hiprtc.h>
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "fz_runtime.hpp"
+
+namespace fz {
+
+int device_count()
+{
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+   }
+   return n;
+}
+
+void require_device()
+{
+   if (device_count() <= 0)
+      fail(FZ_E_NO_DEVICE, "no HIP device visible: libflowz_hip evaluates flow-graphs on an MI355X only "
+                           "(there is no CPU fallback in the product path)");
+}
+
+Kernel::~Kernel()
+{
+   if (loaded.empty()) return;
+   int cur = 0;
+   (void)hipGetDevice(&cur);
+   for (const Loaded& l : loaded) {
+      (void)hipSetDevice(l.device);
+      (void)hipDeviceSynchronize();          // launches are asynchronous: never unload code that may still run
+      (void)hipModuleUnload((hipModule_t)l.module);
+   }
+   (void)hipSetDevice(cur);
+}
+
+void* Kernel::function_on_current_device(const std::string& symbol)
+{
+   int dev = 0;
+   FZ_HIP(hipGetDevice(&dev));
+   for (const Loaded& l : loaded)
+      if (l.device == dev) return l.function;
+   hipModule_t mod;
+   FZ_HIP(hipModuleLoadData(&mod, code.data()));
+   hipFunction_t fn;
+   FZ_HIP(hipModuleGetFunction(&fn, mod, symbol.c_str()));
+   loaded.push_back(Loaded{dev, mod, fn});
+   return fn;
+}
+
+// ---- kernel cache -----------------------------------------------------------------------------------
+static std::vector<const char*> build_options(const Variant& v)
+{
+   // -ffp-contract=off: one rounding per graph node (no v_fma/v_fmac); IEEE division.
+   // The SLP vectoriser is off by default: with one stream per lane it pairs unrelated scalar
+   // mul/add into v_pk_* at the price of v_mov shuffles, a net VALU loss on gfx950.
+   std::vector<const char*> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                                 "-fhip-fp32-correctly-rounded-divide-sqrt"};
+   if (!(v.flags & FZ_VF_SLP)) o.push_back("-fno-slp-vectorize");
+   // developer hook (kernel experiments: -DFZ_DBG_NOLOAD ... and compiler flags); part of the cache key like every option
+   static const std::vector<std::string> extra = [] {
+      std::vector<std::string> e;
+      if (const char* env = std::getenv("FLOWZ_HIP_EXTRA_OPTS")) {
+         std::istringstream is(env);
+         for (std::string t; is >> t;) e.push_back(t);
+      }
+      return e;
+   }();
+   for (const std::string& e : extra) o.push_back(e.c_str());
+   return o;
+}
+
+
+// Where code objects are cached: FLOWZ_HIP_CACHE, else <package>/_kcache next to the library when that is
+// writable (build() pre-fills it), else a PER-USER directory under /tmp (mode 0700, owner checked: another
+// local user must not be able to plant a code object there).
+std::string cache_dir()
+{
+   if (const char* env = std::getenv("FLOWZ_HIP_CACHE")) return env;
+   Dl_info info;
+   if (dladdr((const void*)&cache_dir, &info) && info.dli_fname) {
+      std::string p = info.dli_fname;                // .../zignal_amd/lib/libflowz_hip.so
+      size_t s = p.rfind('/');
+      if (s != std::string::npos) p = p.substr(0, s);
+      s = p.rfind('/');
+      if (s != std::string::npos) p = p.substr(0, s);
+      const std::string d = p + "/_kcache";
+      ::mkdir(d.c_str(), 0755);
+      if (::access(d.c_str(), W_OK | X_OK) == 0) return d;
+   }
+   const std::string d = "/tmp/flowz_hip_kcache-" + std::to_string((long)getuid());
+   ::mkdir(d.c_str(), 0700);
+   struct stat st;
+   if (::lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0) return "";   // no cache
+   return d;
+}
+
+// cache file = code object (an ELF: llvm-objdump / readelf still read the file) + trailer {magic, payload bytes, fnv1a of the payload}
+struct CacheHeader {
+   char magic[8];
+   uint64_t size;
+   uint64_t hash;
+};
+static const char kCacheMagic[8] = {'F', 'Z', 'K', 'C', '0', '0', '0', '2'};
+
+static uint64_t fnv1a_bytes(const char* d, size_t n)
+{
+   uint64_t h = 1469598103934665603ull;
+   for (size_t i = 0; i < n; ++i) {
+      h ^= (unsigned char)d[i];
+      h *= 1099511628211ull;
+   }
+   return h;
+}
+
+static bool cache_load(const std::string& path, std::vector<char>& code)
+{
+   std::ifstream f(path, std::ios::binary);
+   if (!f) return false;
+   std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+   CacheHeader h;
+   bool ok = raw.size() > sizeof h;
+   if (ok) {
+      std::memcpy(&h, raw.data() + raw.size() - sizeof h, sizeof h);
+      ok = std::memcmp(h.magic, kCacheMagic, 8) == 0 && h.size == raw.size() - sizeof h && h.size > 64 &&
+           h.hash == fnv1a_bytes(raw.data(), (size_t)h.size) && std::memcmp(raw.data(), "\x7f" "ELF", 4) == 0;
+   }
+   if (!ok) {
+      ::unlink(path.c_str());                        // truncated / foreign / stale: never try it again
+      return false;
+   }
+   raw.resize((size_t)h.size);
+   code.swap(raw);
+   return true;
+}
+
+static void cache_store(const std::string& dir, const std::string& path, const std::vector<char>& code)
+{
+   if (dir.empty()) return;
+   ::mkdir(dir.c_str(), 0755);
+   const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+   CacheHeader h;
+   std::memcpy(h.magic, kCacheMagic, 8);
+   h.size = code.size();
+   h.hash = fnv1a_bytes(code.data(), code.size());
+   bool ok = false;
+   {
+      std::ofstream f(tmp, std::ios::binary);
+      if (f) {
+         f.write(code.data(), (std::streamsize)code.size());
+         f.write(reinterpret_cast<const char*>(&h), sizeof h);
+         f.close();
+         ok = f.good();                              // a short write (ENOSPC ...) must not be installed
+      }
+   }
+   if (!ok || ::rename(tmp.c_str(), path.c_str()) != 0) ::unlink(tmp.c_str());
+}
+
+static std::vector<char> jit_compile(const Graph& g, const Variant& v)
+{
+   const std::string cfg = gen_config(g, v), body = gen_body(g, v);
+   const char* headers[2] = {cfg.c_str(), body.c_str()};
+   const char* names[2] = {"fz_graph_config.h", "fz_graph_body.h"};
+   hiprtcProgram prog;
+   if (hiprtcCreateProgram(&prog, skeleton_source(), "fz_block_kernel.hip", 2, headers, names) != HIPRTC_SUCCESS)
+      fail(FZ_E_COMPILE, "hiprtcCreateProgram failed");
+   std::vector<const char*> opts = build_options(v);
+   hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+   if (r != HIPRTC_SUCCESS) {
+      size_t n = 0;
+      hiprtcGetProgramLogSize(prog, &n);
+      std::string log(n, ' ');
+      if (n) hiprtcGetProgramLog(prog, &log[0]);
+      hiprtcDestroyProgram(&prog);
+      fail(FZ_E_COMPILE, std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log);
+   }
+   size_t n = 0;
+   hiprtcGetCodeSize(prog, &n);
+   std::vector<char> code(n);
+   hiprtcGetCode(prog, code.data());
+   hiprtcDestroyProgram(&prog);
+   return code;
+}
+
+// One field of the kernel's metadata map (code object v3+: an ELF note holding msgpack; one kernel per code object here).
+// The key is a msgpack string, the value the msgpack unsigned integer right behind it.
+static uint32_t note_uint(const std::vector<char>& code, const char* key)
+{
+   const size_t kl = std::strlen(key);
+   const unsigned char* b = reinterpret_cast<const unsigned char*>(code.data());
+   for (size_t i = 1; i + kl + 1 <= code.size(); ++i) {
+      if (std::memcmp(b + i, key, kl) != 0) continue;
+      const bool fixstr = b[i - 1] == (0xa0u | kl), str8 = i >= 2 && b[i - 2] == 0xd9 && b[i - 1] == kl;
+      if (!fixstr && !str8) continue;                         // (the text inside a longer key or a value)
+      const unsigned char* v = b + i + kl;
+      const size_t left = code.size() - (i + kl);
+      if (v[0] <= 0x7f) return v[0];
+      if (v[0] == 0xcc && left >= 2) return v[1];
+      if (v[0] == 0xcd && left >= 3) return (uint32_t)v[1] << 8 | v[2];
+      if (v[0] == 0xce && left >= 5) return (uint32_t)v[1] << 24 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 8 | v[4];
+      return 0xFFFFFFFFu;
+   }
+   return 0;
+}
+
+static KernelResources read_resources(const std::vector<char>& code)
+{
+   KernelResources r;
+   r.vgprs = note_uint(code, ".vgpr_count");
+   r.agprs = note_uint(code, ".agpr_count");
+   r.sgprs = note_uint(code, ".sgpr_count");
+   r.scratch_bytes = note_uint(code, ".private_segment_fixed_size");
+   r.lds_bytes = note_uint(code, ".group_segment_fixed_size");
+   r.vgpr_spills = note_uint(code, ".vgpr_spill_count");
+   r.sgpr_spills = note_uint(code, ".sgpr_spill_count");
+   return r;
+}
+
+// A frame kernel that spills keeps part of its prefetch buffers / delay lines in scratch memory.  There the unroll is only
+// the prefetch depth, so it is an UPPER bound: halved until nothing spills.  A graph that spills even at unroll 1 runs as it
+// is.  Stream-major kernels are left alone: their unroll is also the length of a stream's run in memory, and the 4-wire sum
+// measured 0.98 ms with 32-sample chunks and 64 spilled registers against 1.33 ms with 16-sample chunks and none.
+Variant settle_variant(fz_program* p, Variant v)
+{
+   static const bool off = std::getenv("FLOWZ_HIP_KEEP_SPILLS") != nullptr;   // (developer switch: measure the spilling kernel itself)
+   if (off) return v;
+   for (;;) {
+      const auto k = get_kernel(p, v, nullptr);
+      if (k->res.scratch_bytes == 0) return v;
+      if (v.flags & FZ_VF_STREAM_MAJOR) return v;
+      if (ws_parts(v.flags) && v.block * ws_waves(v.flags) > 256 && v.block > 64) {
+         v.block /= 2;                                   // more than four waves per workgroup cap the registers of a lane at 256: fewer tuples per workgroup first
+         continue;
+      }
+      if (v.U <= (ws_parts(v.flags) ? 8u : 1u)) return v;
+      v.U /= 2;
+   }
+}
+
+std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out)
+{
+   std::lock_guard<std::mutex> lock(p->mu);
+   auto& slot = p->kernels[v];
+   if (!slot) {
+      auto k = std::make_shared<Kernel>();
+      std::string key_src = full_source(p->g, v);
+      for (const char* o : build_options(v)) key_src += o;
+      int rtc_major = 0, rtc_minor = 0;
+      hiprtcVersion(&rtc_major, &rtc_minor);
+      key_src += "hiprtc" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor);
+      char name[64];
+      std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)fnv1a(key_src));
+      const std::string dir = cache_dir(), path = dir + name;
+      const bool use_cache = !std::getenv("FLOWZ_HIP_NO_CACHE") && !dir.empty();
+      k->cache_path = use_cache ? path : std::string();
+      if (!(use_cache && cache_load(path, k->code))) {
+         k->code = jit_compile(p->g, v);
+         if (use_cache) cache_store(dir, path, k->code);
+      }
+      k->res = read_resources(k->code);
+      slot = k;
+   }
+   if (fn_out) {
+      require_device();
+      try {
+         *fn_out = slot->function_on_current_device(kernel_name(p->g, v));
+      } catch (const Error&) {
+         // a cached code object the driver refuses: delete it, build afresh, try once more
+         if (slot->cache_path.empty()) throw;
+         ::unlink(slot->cache_path.c_str());
+         slot->cache_path.clear();
+         slot->code = jit_compile(p->g, v);
+         *fn_out = slot->function_on_current_device(kernel_name(p->g, v));
+      }
+   }
+   return slot;
+}
+
+}  // namespace fz

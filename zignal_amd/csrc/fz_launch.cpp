@@ -1,0 +1,195 @@
+// The launch of the fused block kernel: argument checks, plan lookup / first-launch measurement, kernarg image.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "fz_runtime.hpp"
+
+namespace fz {
+
+// ---- launch ------------------------------------------------------------------------------------------------
+struct ArgsHeader {
+   const float* in;
+   float* out;
+   float* state;
+   const float* params;
+   const float* mod;
+   unsigned long long n_streams;
+   unsigned int n_samples;
+   unsigned int n_groups;
+   unsigned int tile_streams;
+   unsigned int tile_blocks;
+   unsigned int rows_total;
+   unsigned int row0;
+   unsigned int mod_stride;
+   unsigned int pad_;
+};
+static_assert(sizeof(ArgsHeader) % 8 == 0 && sizeof(ArgsHeader) == 5 * 8 + 8 + 8 * 4, "ArgsHeader must match the head of the kernel's fz_args without padding");
+
+int launch(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+           uint32_t n_samples, const fz_variant* uv, void* stream, uint32_t tile_streams, uint32_t rows_total, uint32_t row0)
+{
+   if (rows_total == 0) rows_total = n_samples;             // the block is the whole buffer
+   if ((uint64_t)row0 + n_samples > rows_total) fail(FZ_E_INVALID, "row0 + n_samples exceeds rows_total");
+   const bool stream_major = uv && (uv->flags & FZ_VF_STREAM_MAJOR);
+   if (stream_major) {
+      if (tile_streams) fail(FZ_E_INVALID, "stream-major frames are not tiled");
+      if ((uint64_t)rows_total * std::max(p->g.n_in, p->g.n_out) >= (1ull << 24))
+         fail(FZ_E_UNSUPPORTED, "stream-major frames: more than 2^24 floats per stream buffer (a wave's 64 rows are addressed through one 4 GiB descriptor): use a window");
+      if (((uint64_t)rows_total * p->g.n_in) % 4 || ((uint64_t)row0 * p->g.n_in) % 4 || ((uint64_t)rows_total * p->g.n_out) % 4 ||
+          ((uint64_t)row0 * p->g.n_out) % 4)
+         fail(FZ_E_INVALID, "stream-major frames: rows_total and row0 times the wires per frame must be multiples of 4 floats");
+   }
+   const Graph& g = p->g;
+   if (n_streams == 0 || n_samples == 0) return FZ_OK;      // an empty block: nothing to evaluate, state unchanged
+   if (n_samples == 0xFFFFFFFFu) fail(FZ_E_INVALID, "n_samples must be below 2^32 - 1");
+   if (!out) fail(FZ_E_INVALID, "out is null");
+   if (g.n_in && !in) fail(FZ_E_INVALID, "in is null but the graph has input wires");
+   if (g.n_state && !state) fail(FZ_E_INVALID, "state is null but the graph has delay lines");
+   if (g.n_param && !params) fail(FZ_E_INVALID, "params is null but the graph has per-stream coefficients");
+   auto mis = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
+   if (mis(in) || mis(out) || mis(state) || mis(params)) fail(FZ_E_INVALID, "device pointers must be 16-byte aligned");
+   const uint64_t wmax = std::max<uint64_t>(std::max(g.n_in, g.n_out), 1);
+   if (tile_streams == 0 || tile_streams >= n_streams) tile_streams = 0;    // one tile == plain time-major
+   const uint64_t row_streams = tile_streams ? tile_streams : n_streams;
+   const uint64_t out_w = (uint64_t)std::max<uint32_t>(g.n_out, 1) * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 2 : 1);
+   if (!stream_major && row_streams * std::max(wmax, out_w) >= (1ull << 30)) fail(FZ_E_UNSUPPORTED, "row longer than 4 GiB: shard or tile the streams");
+   if (n_streams >= (1ull << 32)) fail(FZ_E_UNSUPPORTED, "more than 2^32 streams per launch: shard the streams");
+   if (tile_streams && n_streams % tile_streams) fail(FZ_E_INVALID, "n_streams must be a multiple of tile_streams");
+   require_device();
+   fz_variant planned;
+   if (!uv) {                                               // a measured plan for this shape on this device?
+      int dev = 0;
+      FZ_HIP(hipGetDevice(&dev));
+      const auto key = std::make_tuple(n_streams, tile_streams, dev);
+      bool known = false;
+      (void)planned_variant(p, n_streams, tile_streams);      // first launch of this shape: a plan persisted by an earlier process?
+      {
+         std::lock_guard<std::mutex> lock(p->mu);
+         auto it = p->plans.find(key);
+         known = it != p->plans.end() || p->tuned_default.count(key) != 0;
+         if (it != p->plans.end()) {
+            planned = it->second;
+            uv = &planned;
+         }
+      }
+      // FLOWZ_HIP_AUTOTUNE=1: the first big block of a shape measures the plan by itself (on the caller's
+      // buffers; the state is saved and restored around the measurement, `out` is recomputed below)
+      static const bool autotune = [] { const char* e = std::getenv("FLOWZ_HIP_AUTOTUNE"); return e && *e && *e != '0'; }();
+      bool can_tune = autotune && !known && rows_total == n_samples && row0 == 0 && n_streams * (uint64_t)n_samples >= (1ull << 26);
+      if (can_tune) {
+         // not while the stream is being captured into a hipGraph (the measurement allocates and synchronises), and not
+         // in place: the candidates run on the caller's buffers, an aliased `in` would be overwritten before the real launch
+         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) (void)hipGetLastError();
+         const char* ib = reinterpret_cast<const char*>(in);
+         const char* ob = reinterpret_cast<const char*>(out);
+         const size_t ibytes = (size_t)n_streams * n_samples * g.n_in * 4, obytes = (size_t)n_streams * n_samples * out_w * 4;
+         const bool overlap = in && ib < ob + obytes && ob < ib + ibytes;
+         can_tune = cap == hipStreamCaptureStatusNone && !overlap;
+      }
+      if (can_tune) {
+         {
+            std::lock_guard<std::mutex> lock(p->mu);
+            p->tuned_default.insert(key);                   // (also stops the recursion through tune -> launch)
+         }
+         const size_t sb = (size_t)g.n_state * n_streams * 4;
+         // the state is saved before and restored after the measurement ON EVERY EXIT PATH
+         struct Saved {
+            float* copy = nullptr;
+            float* state;
+            size_t bytes;
+            hipStream_t st;
+            ~Saved()
+            {
+               if (!copy) return;
+               (void)hipMemcpyAsync(state, copy, bytes, hipMemcpyDeviceToDevice, st);
+               (void)hipStreamSynchronize(st);
+               (void)hipFree(copy);
+            }
+         } saved{nullptr, state, sb, (hipStream_t)stream};
+         bool have_copy = true;
+         if (sb) {
+            if (hipMalloc((void**)&saved.copy, sb) != hipSuccess) {      // no room for the snapshot (multi-GiB state): do not tune
+               (void)hipGetLastError();
+               saved.copy = nullptr;
+               have_copy = false;
+            } else {
+               FZ_HIP(hipMemcpyAsync(saved.copy, state, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            }
+         }
+         if (have_copy) {
+            fz_variant chosen{0, 0, 0, 0};
+            const int rc = tune(p, in, out, state, params, n_streams, n_samples, tile_streams, stream, &chosen, nullptr);
+            if (rc != FZ_OK) return rc;
+            if (chosen.streams_per_lane || chosen.unroll || chosen.block_threads || chosen.flags) {
+               planned = chosen;
+               uv = &planned;
+            }
+         }
+      }
+   }
+   Variant v = resolve_variant(g, uv, n_streams, n_samples);
+   // time-major frames of many streams: the rows are megabytes apart, every row in flight is another page, and 16 rows per
+   // lane do better than 32 (1 M streams: 6.46 ms against 6.88 ms; stream-tiled frames keep 32: tools/slab_probe.py)
+   if (!tile_streams && !(v.flags & FZ_VF_STREAM_MAJOR) && !(uv && uv->unroll) && v.P == 2 && v.U == 32 && n_streams >= (1u << 19)) v.U = 16;
+   if (tile_streams) {
+      // a workgroup must not straddle tiles: shrink the lane packing / block until it divides
+      const bool fixedP = uv && uv->streams_per_lane, fixedB = uv && uv->block_threads;
+      while (tile_streams % (v.P * v.block) && !fixedP && v.P > 1) v.P /= 2;
+      while (tile_streams % (v.P * v.block) && !fixedB && v.block > 64) v.block /= 2;
+      if (tile_streams % (v.P * v.block))
+         fail(FZ_E_INVALID, "tile_streams must be a multiple of streams_per_lane * block_threads");
+   }
+   {  // a chunk of U rows is addressed through ONE buffer descriptor: it must stay below 4 GiB
+      const uint64_t row_bytes = stream_major ? 0 : row_streams * std::max(wmax, out_w) * 4;
+      while (row_bytes * v.U >= (1ull << 32) && v.U > 1) {
+         if (uv && uv->unroll) fail(FZ_E_INVALID, "unroll x row bytes must stay below 4 GiB: lower the unroll or tile the streams");
+         v.U /= 2;
+      }
+   }
+   v = settle_variant(p, v);
+   void* fn = nullptr;
+   auto k = get_kernel(p, v, &fn);
+
+   // kernarg image of `struct fz_args` (8-byte aligned: pad the coefficient tail)
+   // (built on the stack for ordinary graphs: no allocation on the launch path)
+   const size_t off64 = (sizeof(ArgsHeader) + sizeof(float) * std::max<size_t>(g.consts.size(), 1) + 7) & ~size_t(7);
+   const size_t kbytes = off64 + sizeof(double) * std::max<size_t>(g.consts64.size(), 1);
+   alignas(8) char small[1024];
+   std::vector<char> big;
+   char* const kbuf = kbytes <= sizeof small ? small : (big.resize(kbytes), big.data());
+   const float* mod_dev = nullptr;
+   uint32_t mod_stride = 0;
+   if (g.n_mod) {
+      std::lock_guard<std::mutex> lock(p->mu);
+      mod_dev = p->mod_dev;
+      mod_stride = p->mod_stride;
+      if (!mod_dev) fail(FZ_E_INVALID, "the graph has sample-rate modulators: call fz_program_set_modulation first");
+      if (mod_stride < rows_total) fail(FZ_E_INVALID, "fz_program_set_modulation: stride is shorter than the rows of this launch");
+   }
+   ArgsHeader h{in, out, state, params, mod_dev, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
+                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0, mod_stride, 0u};
+   std::memcpy(kbuf, &h, sizeof h);
+   {
+      std::lock_guard<std::mutex> lock(p->mu);
+      if (!g.consts.empty()) std::memcpy(kbuf + sizeof h, g.consts.data(), sizeof(float) * g.consts.size());
+      if (!g.consts64.empty()) std::memcpy(kbuf + off64, g.consts64.data(), sizeof(double) * g.consts64.size());
+   }
+   size_t size = kbytes;
+   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, kbuf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+   const unsigned grid = (unsigned)((h.n_groups + v.block - 1) / v.block);
+   // (wave split: v.block counts the 64 streams of a workgroup; two waves evaluate them)
+   const unsigned threads = ws_parts(v.flags) ? v.block * ws_waves(v.flags) : v.block;
+   FZ_HIP(hipModuleLaunchKernel((hipFunction_t)fn, grid, 1, 1, threads, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
+   static const bool debug = std::getenv("FLOWZ_HIP_DEBUG") != nullptr;
+   if (debug) {
+      FZ_HIP(hipStreamSynchronize((hipStream_t)stream));
+      std::fprintf(stderr, "[flowz_hip] launched grid=%u block=%u P=%u U=%u flags=%u n_streams=%llu n_samples=%u kernarg=%zu B vgprs=%u scratch=%u B/lane\n",
+                   grid, v.block, v.P, v.U, v.flags, (unsigned long long)n_streams, n_samples, size, k->res.vgprs + k->res.agprs, k->res.scratch_bytes);
+   }
+   return FZ_OK;
+}
+
+}  // namespace fz

@@ -1,0 +1,398 @@
+// Which kernel variant runs: the library defaults (resolve_variant), the plans fz_program_tune measured and their
+// persistence per board, and the measurement itself.
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "fz_runtime.hpp"
+
+namespace fz {
+
+// ---- variant selection ---------------------------------------------------------------------------------
+constexpr uint64_t kMaxLdsBytes = 160 * 1024;
+
+Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples)
+{
+   Variant v;
+   const uint32_t reqP = uv ? uv->streams_per_lane : 0, reqU = uv ? uv->unroll : 0, reqB = uv ? uv->block_threads : 0;
+   v.flags = uv ? uv->flags : 0;
+   if (reqP != 0 && reqP != 1 && reqP != 2 && reqP != 4) fail(FZ_E_INVALID, "streams_per_lane must be 0, 1, 2 or 4");
+   if (g.typed && (v.flags & FZ_VF_OUT_F64))
+      fail(FZ_E_INVALID, "FZ_VF_OUT_F64 does not apply to fz_compile_typed programs: their frames carry every wire in its own type");
+   if (reqU > 32 && !((v.flags & FZ_VF_SM_LONG) && (reqU == 64 || reqU == 128))) fail(FZ_E_INVALID, "unroll must be <= 32");
+   if (reqB != 0 && (reqB % 64 != 0 || reqB > 1024)) fail(FZ_E_INVALID, "block_threads must be a multiple of 64, <= 1024");
+   if (const uint32_t W = ws_parts(v.flags)) {
+      // W compute waves per 64 streams, each evaluating one part of the serial graph (fz_split.cpp: find_wave_roles), and with
+      // FZ_VF_IO_WAVE one more wave for the frame I/O
+      const uint32_t waves = ws_waves(v.flags);
+      if (!g.wave_roles(W))
+         fail(FZ_E_UNSUPPORTED, W == 1 ? "FZ_VF_IO_WAVE: the graph is not stage-packable (1 in, 1 out, register delay lines)"
+                                       : "wave split: the graph is not that many groups of isomorphic segments in series (1 in, 1 out, register delay lines)");
+      if (reqP > 1) fail(FZ_E_INVALID, "wave split needs streams_per_lane == 1");
+      if (reqB && (reqB % 64 || reqB * waves > 1024)) fail(FZ_E_INVALID, "wave split: block_threads counts the streams of a workgroup: a multiple of 64, at most 1024 / waves per tuple");
+      if (reqU && reqU != 8 && reqU != 16 && reqU != 32) fail(FZ_E_INVALID, "wave split: unroll must be 8, 16 or 32");
+      if (v.flags & (FZ_VF_STREAM_MAJOR | FZ_VF_OUT_F64 | FZ_VF_PREFETCH3))
+         fail(FZ_E_UNSUPPORTED, "wave split: time-major / tiled float32 frames, double buffering only");
+      v.P = 1;
+      v.U = reqU ? reqU : (W == 1 ? 16 : 32);           // (one barrier per round: waves in lockstep do better with longer rounds -- two parts +1.5 %, three +8 %;
+                                                        //  the lone compute wave next to an I/O wave keeps 16: its rings fill the LDS at 32)
+      // the waves of a workgroup go to consecutive SIMDs of a CU: pairs come two to a workgroup (one wave on each of the
+      // four SIMDs), triples and quadruples one
+      // (with I/O waves: one compute wave on each SIMD and the I/O waves next to them -- 4 tuples for one part, 2 for two)
+      v.block = reqB ? reqB : (ws_io(v.flags) ? (W == 1 ? 256 : W == 2 ? 128 : 64) : (W == 2 ? 128 : 64));
+      {  // the rings of a workgroup must fit the CU's LDS: tuples x hand-offs x ring x 1 KiB
+         const uint32_t K0 = (*g.wave_roles(W))[0].split.K, ring = (K0 - 1 > 4 ? v.U : v.U / 2), nring = W - 1 + 2 * ws_io(v.flags);
+         while ((uint64_t)(v.block / 64) * nring * ring * 1024 > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
+         if ((uint64_t)(v.block / 64) * nring * ring * 1024 > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "wave split: the hand-off rings do not fit the LDS with this unroll and block size");
+      }
+      v.flags &= ~(uint32_t)(FZ_VF_STAGE_PACK | FZ_VF_NO_STAGE_PACK | FZ_VF_SLP);   // (each part is stage-packed by itself)
+      return v;
+   }
+   if (reqP) {
+      if (n_streams % reqP) fail(FZ_E_INVALID, "n_streams must be a multiple of streams_per_lane");
+      v.P = reqP;
+   } else {
+      // fill the chip first (256 CUs x 4 SIMDs, several waves each), then pack two streams per lane
+      // (v_pk_* issue at the scalar rate on gfx950: twice the lane-ops per cycle)
+      // -- unless the frames are already wide (>= 3 wires: 12+ bytes per lane with one stream)
+      // (measured crossover on the 6-biquad cascade: 2^18 streams, profiles/r01/sweep_stream_counts.txt)
+      v.P = (n_streams >= (1u << 18) && n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) ? 2 : 1;
+   }
+   // deep graphs: keep the register-resident delay lines + prefetch buffers inside the 512-entry
+   // VGPR/AGPR file (measured: a 24-stage cascade needs ~300 VGPRs at 2 streams per lane)
+   uint32_t reg_state = 0;
+   for (const Line& l : g.lines)
+      if (!l.in_lds) reg_state += l.depth;
+   if (!reqP && v.P == 2 && reg_state > 36) v.P = 1;
+   // prefetch depth in time steps: 16 rows in flight per lane; 32 once the chip is oversubscribed
+   // with packed lanes (fewer, fatter waves: 2 per SIMD)
+   // (per-stream coefficients sit in VGPRs too: with 31 of them the deep prefetch costs 10 %)
+   const uint32_t reg_values = (reg_state + g.n_param) * v.P;
+   v.U = reqU ? reqU : ((v.P == 2 && n_streams >= (1u << 19) && g.n_in == 1 && g.n_out == 1 && reg_values <= 40) ? 32 : 16);
+   // wide frames, one stream per lane, chip oversubscribed: 32 rows in flight per lane (measured on three boards, 4-wire
+   // frames at 1 M streams: 13.4-14.1 ms against 14.4-14.6 ms with 16; profiles/r02/tune_logs.txt)
+   if (!reqU && v.P == 1 && g.n_in >= 3 && n_streams >= (1u << 19) && !(v.flags & FZ_VF_STAGE_PACK)) v.U = 32;
+   // (few streams, one stream per lane, no stage packing: 16 against 32 rows is board-dependent -- the fan-out 4-biquad sum at
+   //  65 536 streams measured 0.65 / 0.74 of peak on one board and 0.79 / 0.69 on the next; fz_program_tune tries both)
+   if (!reqU && reg_state * v.P > 60) v.U = 8;
+   if (!g.far_lines.empty()) {
+      // far (HBM ring) reads are prefetched one chunk ahead: a read must be two chunks old, so the chunk
+      // is at most half the youngest ring read (16 steps from kFarMinDelay = 32 on, 4 for a 9-sample read)
+      const uint32_t cap = std::min(16u, std::max(1u, g.far_min_read ? g.far_min_read / 2 : 16u));
+      if (reqU > cap) fail(FZ_E_INVALID, "graphs with delays beyond LDS need unroll <= " + std::to_string(cap));
+      if (v.flags & FZ_VF_PREFETCH3) fail(FZ_E_INVALID, "FZ_VF_PREFETCH3 is not available with delays beyond LDS");
+      v.U = std::min(v.U, cap);
+   }
+   // wave split: fewer streams than 128 per CU -- W waves per 64 streams, each one part of the serial graph (measured,
+   // 6-biquad cascade, ms per 4096 samples: 32 768 streams 0.23 with two parts against 0.31-0.33 with the single wave;
+   // 16 384 streams 0.17 with three parts, 0.22 with two, 0.30 single; at 49 152 streams the 384 workgroups of pairs no
+   // longer spread evenly over 256 CUs and the single-wave kernel wins again; profiles/r02/sweep_wave_split.txt)
+   if (!reqP && !reqB && n_samples >= 256 && (reqU == 0 || reqU == 8 || reqU == 16 || reqU == 32) &&
+       !(v.flags & (FZ_VF_STAGE_PACK | FZ_VF_NO_STAGE_PACK | FZ_VF_OUT_F64 | FZ_VF_PREFETCH3 | FZ_VF_STREAM_MAJOR | FZ_VF_SLP))) {
+      // the most parts whose waves still find a SIMD each: W waves per 64 streams on 1024 SIMDs, whole workgroups per CU
+      // (pairs: two to a workgroup, 128 streams per CU; triples / quadruples: one workgroup of 64 streams per CU)
+      uint32_t W = 0;
+      if (n_streams <= 16384) W = g.wave_roles(4) ? 4 : g.wave_roles(3) ? 3 : 0;
+      if (!W && n_streams <= 32768 && g.wave_roles(2)) W = 2;
+      // The splits come with an I/O wave (FZ_VF_IO_WAVE): +2-4 % on every board measured (three parts at 16 384 streams:
+      // 0.397 / 0.406 / 0.397 / 0.428 of peak against 0.387 / 0.394 / 0.384 / 0.410; two parts at 32 768: 0.596 / 0.593 against
+      // 0.580 / 0.574).  The lone compute wave with an I/O wave at 65 536 streams is NOT a default: +3 % on one board -- 0.374 ms
+      // against 0.387 ms per 4096 samples, 97 % of what a plain copy gets there -- and -4 % on the next; fz_program_tune tries
+      // it (profiles/r02/sweep_io_wave.txt)
+      if (W) {
+         fz_variant q{1, reqU, 0, v.flags | (W - 1) << 10 | (W < 4 ? (uint32_t)FZ_VF_IO_WAVE : 0u)};
+         return resolve_variant(g, &q, n_streams, n_samples);
+      }
+   }
+   // stage packing: one stream per lane, pairs of isomorphic graph segments in one v_pk_* (fz_split.cpp)
+   if (v.flags & FZ_VF_STAGE_PACK) {
+      if (!g.split.ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_STAGE_PACK: the graph is not a series of isomorphic segments");
+      if (v.P != 1) fail(FZ_E_INVALID, "FZ_VF_STAGE_PACK needs streams_per_lane == 1");
+   } else if (!reqP && v.P == 1 && g.split.ok && !(v.flags & FZ_VF_NO_STAGE_PACK) &&
+              n_samples >= 32u * (g.split.K - 1)) {
+      // automatic below 2^18 streams, unless the block is so short that the K-1 masked steps at
+      // either end would dominate
+      v.flags |= FZ_VF_STAGE_PACK;
+   }
+   v.flags &= ~(uint32_t)FZ_VF_NO_STAGE_PACK;
+   v.block = reqB ? reqB : 256;
+   if (v.flags & FZ_VF_STREAM_MAJOR) {
+      // stream-major frames (fz_run_block_stream_major): one stream per lane, chunks of whole float4 pieces
+      if (reqP > 2) fail(FZ_E_INVALID, "stream-major frames take one or two streams per lane");
+      if (reqU % 4) fail(FZ_E_INVALID, "stream-major frames need unroll % 4 == 0");
+      if (!g.far_lines.empty()) fail(FZ_E_UNSUPPORTED, "stream-major frames: delay lines beyond 256 samples are not supported");
+      if (v.flags & (FZ_VF_OUT_F64 | FZ_VF_PREFETCH3)) fail(FZ_E_UNSUPPORTED, "stream-major frames: float32 frames, double buffering only");
+      // one stream per lane: two (packed FP32) are possible but measured slower everywhere -- twice the
+      // patch traffic per wave and 360 VGPRs (profiles/r01/stream_major_kernel.txt)
+      v.P = reqP ? reqP : 1u;
+      // stage packing (one stream per lane) carries over: the skew only shifts which output chunk a step completes.
+      // It is what lifts deep serial graphs off the VALU floor here, whatever the stream count.
+      if (v.P != 1 || !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
+      // (automatic only for graphs deep enough to be VALU-bound with one stream per lane: packing takes the in-runs of
+      //  the long-run body off the 512-byte grid, which costs ~10 % of the read rate -- measured: a 2-stage cascade runs
+      //  5.3-5.9 TB/s unpacked against 4.6-5.5 packed, a 6-stage one 4.6 against 5.3)
+      else if (!(uv && (uv->flags & FZ_VF_NO_STAGE_PACK)) && n_samples >= 32u * (g.split.K - 1) && g.n_ops > 27) v.flags |= FZ_VF_STAGE_PACK;
+      const uint32_t nw = std::max<uint32_t>(std::max(g.n_in, g.n_out), 1);
+      // long-run body (512-byte runs per stream): 1-in/1-out graphs with register-resident state, blocks of at least two phases
+      const bool long_ok = g.n_in == 1 && g.n_out == 1 && v.P == 1 && g.n_lds_slots == 0 && (!g.split.ok || g.split.K <= 8);
+      const bool want_short = uv && (uv->flags & FZ_VF_SM_SHORT);
+      v.flags &= ~(uint32_t)FZ_VF_SM_SHORT;
+      if (v.flags & FZ_VF_SM_LONG) {
+         if (!long_ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: needs a 1-in/1-out graph, one stream per lane, no delay lines beyond 8 samples");
+         if (reqU && reqU != 64 && reqU != 128) fail(FZ_E_INVALID, "FZ_VF_SM_LONG: unroll must be 64 or 128");
+      } else if (long_ok && !want_short && !reqU && n_samples >= 256) {
+         v.flags |= FZ_VF_SM_LONG;
+      }
+      if (v.flags & FZ_VF_SM_LONG) {
+         v.U = reqU ? reqU : 128;
+         // stage packing rides along when the block is long enough for the masked ends not to matter
+         if ((v.flags & FZ_VF_STAGE_PACK) && !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
+         auto lds_long = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (w.U + 12) * 4; };
+         while (lds_long(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
+         if (lds_long(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: the LDS patches do not fit this block size");
+         return v;
+      }
+      auto lds = [&](const Variant& w) { return (uint64_t)w.block * w.P * (w.U * nw + 4) * 4 + (uint64_t)g.n_lds_slots * w.block * 4 * w.P; };
+      if (!reqU) {
+         // the longer the run of one stream inside a chunk the better it streams (measured: 128 B per
+         // stream and wire 2x faster than 64 B): the deepest chunk whose patches fit the CU's LDS
+         v.U = 32;
+         while (v.U > 4 && lds(v) > kMaxLdsBytes) v.U /= 2;
+      }
+      if ((v.flags & FZ_VF_STAGE_PACK) && v.U <= g.split.K - 1) {
+         if (uv && (uv->flags & FZ_VF_STAGE_PACK)) fail(FZ_E_INVALID, "stage-packed stream-major frames need unroll > number of segments - 1");
+         v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
+      }
+      while (lds(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
+      if (lds(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "stream-major frames: the LDS patches do not fit (too many wires per frame)");
+      // two streams per lane with patches so large that a single wave fills the CU's LDS: measured 20 x slower than one
+      // stream per lane (4-wire frames, 32-sample chunks: 10.3 ms against 0.95 ms) -- refuse instead of crawling
+      if (v.P == 2 && (uint64_t)64 * v.P * (v.U * nw + 4) * 4 > kMaxLdsBytes / 4)   // the PATCH of one wave: fewer than one wave per SIMD fit
+         fail(FZ_E_UNSUPPORTED, "stream-major frames: two streams per lane leave one wave per CU with this many wires per frame and this "
+                                "unroll; use one stream per lane or a shorter unroll");
+      return v;
+   }
+   if (g.n_lds_slots) {
+      // LDS rings: slots * block * 4P bytes must fit the CU's 160 KiB of LDS (one workgroup may take it all)
+      auto bytes = [&](const Variant& w) { return (uint64_t)g.n_lds_slots * w.block * 4u * w.P; };
+      while (bytes(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
+      while (bytes(v) > kMaxLdsBytes && !reqP && v.P > 1) v.P /= 2;
+      if (bytes(v) > kMaxLdsBytes)
+         fail(FZ_E_UNSUPPORTED, "delay lines too long for the LDS ring buffers of this build (" +
+                                   std::to_string(g.n_lds_slots) + " slots)");
+   }
+   return v;
+}
+
+// ---- persisted plans ---------------------------------------------------------------------------------------------
+// fz_program_tune's winner is remembered across processes: <kernel cache>/plans.txt, one line per
+// (graph structure, n_streams, tile_streams, board) -- the board by its UUID, because the winner differs from board to
+// board.  A launch without a variant consults it once per shape.  FLOWZ_HIP_NO_PLAN_CACHE=1 turns it off.
+uint64_t graph_structure_hash(const Graph& g)
+{
+   std::ostringstream o;
+   o << g.n_in << ' ' << g.n_out << ' ' << g.n_param << ' ' << (g.typed ? 1 : 0) << '|';
+   for (const Node& n : g.nodes) o << n.kind << ',' << n.a << ',' << n.b << ',' << n.c << ',' << (n.f64 ? 1 : 0) << ';';
+   o << '|';
+   for (uint32_t v : g.outputs) o << v << ',';
+   o << '|';
+   for (const Line& l : g.lines) o << l.src << ':' << l.depth << ':' << (l.f64 ? 1 : 0) << ',';
+   return fnv1a(o.str());
+}
+
+static std::string board_id()
+{
+   int dev = 0;
+   if (hipGetDevice(&dev) != hipSuccess) return "";
+   hipUUID uuid;
+   if (hipDeviceGetUuid(&uuid, dev) == hipSuccess) {
+      char buf[40];
+      for (int i = 0; i < 16; ++i) std::snprintf(buf + 2 * i, 3, "%02x", (unsigned)(unsigned char)uuid.bytes[i]);
+      return buf;
+   }
+   (void)hipGetLastError();
+   return "dev" + std::to_string(dev);
+}
+
+static bool plan_cache_on() { return !std::getenv("FLOWZ_HIP_NO_PLAN_CACHE") && !std::getenv("FLOWZ_HIP_NO_CACHE"); }
+
+static void plan_store(const fz_program* p, uint64_t n_streams, uint32_t tile, const fz_variant& v, float ms)
+{
+   const std::string dir = cache_dir(), id = board_id();
+   if (!plan_cache_on() || dir.empty() || id.empty()) return;
+   ::mkdir(dir.c_str(), 0755);
+   char line[256];
+   const int n = std::snprintf(line, sizeof line, "%016llx %llu %u %s %u %u %u %u %.5f\n", (unsigned long long)p->graph_hash,
+                               (unsigned long long)n_streams, tile, id.c_str(), v.streams_per_lane, v.unroll, v.block_threads, v.flags, ms);
+   if (n <= 0 || n >= (int)sizeof line) return;
+   if (FILE* f = std::fopen((dir + "/plans.txt").c_str(), "a")) {     // one short append per tune: later lines win
+      std::fwrite(line, 1, (size_t)n, f);
+      std::fclose(f);
+   }
+}
+
+static bool plan_load(const fz_program* p, uint64_t n_streams, uint32_t tile, fz_variant* out)
+{
+   const std::string dir = cache_dir(), id = board_id();
+   if (!plan_cache_on() || dir.empty() || id.empty()) return false;
+   std::ifstream f(dir + "/plans.txt");
+   if (!f) return false;
+   bool found = false;
+   std::string ln;
+   while (std::getline(f, ln)) {
+      unsigned long long h = 0, ns = 0;
+      unsigned t = 0, P = 0, U = 0, B = 0, fl = 0;
+      char idbuf[64] = {0};
+      float ms = 0.f;
+      if (std::sscanf(ln.c_str(), "%llx %llu %u %63s %u %u %u %u %f", &h, &ns, &t, idbuf, &P, &U, &B, &fl, &ms) != 9) continue;
+      if (h != p->graph_hash || ns != n_streams || t != tile || id != idbuf) continue;
+      if ((P != 0 && P != 1 && P != 2 && P != 4) || U > 128 || B > 1024 || (B % 64)) continue;   // (a damaged line)
+      *out = fz_variant{P, U, B, fl};
+      found = true;
+   }
+   return found;
+}
+
+fz_variant planned_variant(fz_program* p, uint64_t n_streams, uint32_t tile_streams)
+{
+   int dev = 0;
+   FZ_HIP(hipGetDevice(&dev));
+   if (tile_streams >= n_streams) tile_streams = 0;
+   const auto key = std::make_tuple(n_streams, tile_streams, dev);
+   {
+      std::lock_guard<std::mutex> lock(p->mu);
+      auto it = p->plans.find(key);
+      if (it != p->plans.end()) return it->second;
+      if (!p->plan_looked_up.insert(key).second) return fz_variant{0, 0, 0, 0};
+   }
+   fz_variant v{0, 0, 0, 0};
+   if (plan_load(p, n_streams, tile_streams, &v) && (v.streams_per_lane || v.unroll || v.block_threads || v.flags)) {
+      std::lock_guard<std::mutex> lock(p->mu);
+      p->plans[key] = v;
+      return v;
+   }
+   return fz_variant{0, 0, 0, 0};
+}
+
+// the variants fz_program_tune measures for a shape (the first one is the library default)
+std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint32_t n_samples)
+{
+   const Variant d = resolve_variant(g, nullptr, n_streams, n_samples);
+   std::vector<fz_variant> cands{fz_variant{0, 0, 0, 0}};
+   if (const uint32_t W = ws_parts(d.flags)) {            // few streams: wave splits, with and without an I/O wave, against the single stage-packed wave
+      const uint32_t wbits = (W - 1) << 10;
+      cands.push_back(fz_variant{1, 0, 0, wbits | (ws_io(d.flags) ? 0u : (uint32_t)FZ_VF_IO_WAVE)});   // the same split without / with the I/O wave
+      cands.push_back(fz_variant{1, 16, 0, wbits | (d.flags & FZ_VF_IO_WAVE)});
+      if (W > 2 && g.wave_roles(2)) cands.push_back(fz_variant{1, 16, 0, FZ_VF_WAVE_SPLIT});
+      cands.push_back(fz_variant{1, 16, 0, FZ_VF_STAGE_PACK});
+   } else if (d.flags & FZ_VF_STAGE_PACK) {
+      if (n_streams <= 65536 && g.wave_roles(1)) cands.push_back(fz_variant{1, 16, 0, FZ_VF_IO_WAVE});   // one compute + one I/O wave per 64 streams
+      cands.push_back(fz_variant{1, 24, 0, FZ_VF_STAGE_PACK});
+      cands.push_back(fz_variant{1, 32, 0, FZ_VF_STAGE_PACK});
+   } else if (d.P == 2) {            // many streams, narrow frames: lane packing x prefetch depth x workgroups per CU
+      cands.push_back(fz_variant{2, 16, 0, 0});
+      cands.push_back(fz_variant{4, 8, 0, 0});
+      cands.push_back(fz_variant{2, 16, 256, FZ_VF_MAX_WG(2)});
+      cands.push_back(fz_variant{2, 32, 256, FZ_VF_MAX_WG(2)});
+      cands.push_back(fz_variant{4, 8, 256, FZ_VF_MAX_WG(1)});
+      cands.push_back(fz_variant{4, 12, 256, FZ_VF_MAX_WG(1)});
+      cands.push_back(fz_variant{4, 16, 256, FZ_VF_MAX_WG(1)});
+      cands.push_back(fz_variant{4, 8, 128, FZ_VF_MAX_WG(2)});
+      cands.push_back(fz_variant{4, 4, 256, FZ_VF_MAX_WG(2)});
+   } else {
+      cands.push_back(fz_variant{1, 32, 0, 0});
+   }
+   if (!(d.flags & FZ_VF_STAGE_PACK) && d.P != 2 && n_streams >= (1u << 17)) {
+      cands.push_back(fz_variant{1, 16, 256, FZ_VF_MAX_WG(1)});
+      cands.push_back(fz_variant{1, 8, 256, FZ_VF_MAX_WG(1)});
+      cands.push_back(fz_variant{1, 16, 256, FZ_VF_MAX_WG(2)});
+      if (n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) cands.push_back(fz_variant{2, 16, 0, 0});
+   }
+   return cands;
+}
+
+// ---- plan selection ------------------------------------------------------------------------------------------
+// The variants differ by a few percent, and which one wins depends on the board (measured: the same
+// variant is +5 % on one MI355X of the pool and -3 % on the next), so -- like FFTW_MEASURE -- time the
+// candidates on the caller's own buffers once and remember the winner for this shape.
+int tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
+         uint32_t n_samples, uint32_t tile_streams, void* stream, fz_variant* chosen, float* chosen_ms)
+{
+   const Graph& g = p->g;
+   if (!n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_tune: empty block");
+   require_device();
+   if (tile_streams == 0 || tile_streams >= n_streams) tile_streams = 0;
+   std::vector<fz_variant> cands = tune_candidates(g, n_streams, n_samples);
+   hipEvent_t e0, e1;
+   FZ_HIP(hipEventCreate(&e0));
+   FZ_HIP(hipEventCreate(&e1));
+   float best_ms = 0.f, default_ms = 0.f;
+   int best = -1;
+   std::string first_error;
+   // the default is measured twice: the first pass only brings the clocks and the memory system up to
+   // speed (whoever runs first would otherwise look slower than it is)
+   for (size_t cc = 0; cc <= cands.size(); ++cc) {
+      const bool warmup = cc == 0;
+      const size_t c = warmup ? 0 : cc - 1;
+      try {
+         launch(p, in, out, state, params, n_streams, n_samples, &cands[c], stream, tile_streams);   // build, load, first touch
+         // one launch to size the measurement (>= ~25 ms of kernel time: sub-millisecond kernels need
+         // dozens of launches before their timing settles), then the measurement proper
+         float ms = 0.f;
+         int reps = 1;
+         for (int pass = 0; pass < 2; ++pass) {
+            FZ_HIP(hipEventRecord(e0, (hipStream_t)stream));
+            for (int r = 0; r < reps; ++r) launch(p, in, out, state, params, n_streams, n_samples, &cands[c], stream, tile_streams);
+            FZ_HIP(hipEventRecord(e1, (hipStream_t)stream));
+            FZ_HIP(hipEventSynchronize(e1));
+            FZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+            ms /= (float)reps;
+            if (pass == 0) reps = std::max(3, std::min(100, (int)(25.f / std::max(ms, 1e-3f))));
+         }
+         if (std::getenv("FLOWZ_HIP_DEBUG") || std::getenv("FLOWZ_HIP_TUNE_LOG"))
+            std::fprintf(stderr, "[flowz_hip] tune %s n_streams=%llu tile=%u: P=%u U=%u block=%u flags=%u: %.4f ms%s\n",
+                         kernel_name(g, resolve_variant(g, &cands[c], n_streams, n_samples)).c_str(), (unsigned long long)n_streams,
+                         tile_streams, cands[c].streams_per_lane, cands[c].unroll, cands[c].block_threads, cands[c].flags, ms,
+                         warmup ? " (warm-up pass)" : "");
+         if (!warmup && c == 0) default_ms = ms;
+         if (!warmup && (best < 0 || ms < best_ms)) {
+            best = (int)c;
+            best_ms = ms;
+         }
+      } catch (const Error& er) {                          // a candidate this graph / shape does not allow
+         if (er.code == FZ_E_HIP || er.code == FZ_E_NO_DEVICE) {
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            throw;
+         }
+         if (first_error.empty()) first_error = er.msg;
+      }
+   }
+   (void)hipEventDestroy(e0);
+   (void)hipEventDestroy(e1);
+   if (best < 0) fail(FZ_E_INVALID, "fz_program_tune: no variant could run: " + first_error);
+   // repeated measurements of one variant scatter by 1-2 %: a candidate replaces the library default only when it wins by more
+   if (best > 0 && default_ms > 0.f && best_ms > 0.985f * default_ms) {
+      best = 0;
+      best_ms = default_ms;
+   }
+   int dev = 0;
+   FZ_HIP(hipGetDevice(&dev));
+   {
+      std::lock_guard<std::mutex> lock(p->mu);
+      if (best == 0) p->plans.erase(std::make_tuple(n_streams, tile_streams, dev));
+      else p->plans[std::make_tuple(n_streams, tile_streams, dev)] = cands[(size_t)best];
+      p->plan_looked_up.insert(std::make_tuple(n_streams, tile_streams, dev));
+   }
+   plan_store(p, n_streams, tile_streams, cands[(size_t)best], best_ms);
+   if (chosen) *chosen = cands[(size_t)best];
+   if (chosen_ms) *chosen_ms = best_ms;
+   return FZ_OK;
+}
+
+}  // namespace fz
