@@ -181,12 +181,16 @@ def cpu_baseline(n_samples, seed, coefs):
                        "streams": len(cpus) * per_thread, "passes": r}
     best = max(runs, key=lambda k: runs[k]["Msamples_per_s"])
     b = runs[best]
-    base = {"value": b["Msamples_per_s"], "unit": "Msamples/s", "cores": b["threads"], "kind": "port",
-            "Msamples_per_s_per_core": b["Msamples_per_s_per_thread"],
+    # `cores` = the cores the reported run could actually OCCUPY: its threads, capped by the CPU-seconds per second the cgroup
+    # grants (256 logical CPUs under a quota of 16 are 16 cores' worth of work however many threads are runnable); the per-core
+    # rate is the aggregate over those, so that it stays comparable with the single-thread calibration
+    cores = b["threads"] if quota is None else max(1, min(b["threads"], int(round(quota))))
+    base = {"value": b["Msamples_per_s"], "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "Msamples_per_s_per_core": round(b["Msamples_per_s"] / cores, 3), "threads": b["threads"],
             "single_thread_calibration_Msamples_per_s": round(rate1 / 1e6, 3),
             "physical_cores": len(physical), "logical_cpus": len(logical), "cgroup_cpu_quota": quota, "thread_scaling_probe_Msamples_per_s": scaling,
             "threads_pinned": True, "runs": runs,
-            "sample": f"{b['streams']} streams x {n_samples} samples x {b['passes']} passes ({best}: {b['threads']} pinned threads), 6-stage DF1 cascade, "
+            "sample": f"{b['streams']} streams x {n_samples} samples x {b['passes']} passes ({best}: {b['threads']} pinned threads on {cores} cores' worth of CPU time), 6-stage DF1 cascade, "
                       f"scalar closure per stream, one call per sample (oracle/flowz_oracle.c, gcc -O3 -ffp-contract=off), "
                       f"buffers allocated and first-touched by their thread before the timed region, {b['wall_s']:.2f} s wall"}
     # "Mode B" (SURVEY 8d): the same closures vectorised ACROSS streams by the compiler (SoA state, avx2/avx512
@@ -199,7 +203,8 @@ def cpu_baseline(n_samples, seed, coefs):
         reps = max(1, int(reps_v * min(1.0, n_eff / len(cpus))))
         wall_v, _ = _cpu_threads_run(coracle, coefs, cpus, vec_streams, n_samples, seed, reps=reps, soa=True)
         base["vectorised_across_streams"] = {
-            "value": round(len(cpus) * vec_streams * reps * n_samples / wall_v / 1e6, 1), "unit": "Msamples/s", "cores": len(cpus),
+            "value": round(len(cpus) * vec_streams * reps * n_samples / wall_v / 1e6, 1), "unit": "Msamples/s",
+            "cores": len(cpus) if quota is None else max(1, min(len(cpus), int(round(quota)))), "threads": len(cpus),
             "bitwise_equal_to_scalar": ok_vec,
             "note": "same arithmetic per stream, SoA state, compiler-vectorised (stronger than the reference's scalar closure)"}
     except Exception as e:                                  # never let the extra figure break the bench line
@@ -279,12 +284,14 @@ def measure_config(torch, F, prog, x, y, state, params, ns, T, tile, steps, work
             run(v)
         torch.cuda.synchronize()
         ms = event_ms(torch, lambda: run(v), steps)
-        k = prog.kernel_name(v, ns, T)
+        k = prog.kernel_name(v if v is not None else prog.plan(ns, tile), ns, T, tile)
         out[label] = {"kernel": k, "avg_launch_ms": round(ms, 4), "Msamples_per_s": round(ns * T / ms / 1e3, 1),
                       "achieved_GBs": round(b / ms / 1e6, 1), "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4),
                       "traffic": traffic_of(k, workload_key)}
 
-    timed("library_default", None)              # before any plan is recorded for this shape: what a caller who never tunes gets
+    # what a caller who never tunes gets: no variant.  The first big launch of a shape measures the candidates at hand by itself
+    # (the warm-up launches above the timed ones; FLOWZ_HIP_AUTOTUNE=0 / --no-autotune: the static choice)
+    timed("library_default", None)
     tv = None
     if do_tune:
         tv, _ = prog.tune(x, state=state, params=params, out=y)
@@ -324,9 +331,12 @@ def main():
                                                "with the forced / default variant and print its object")
     ap.add_argument("--no-autotune", action="store_true",
                     help="do not try the alternative kernel variants during warm-up (the pool's boxes differ by a few %%)")
-    ap.add_argument("--time-major-too", action="store_true",
-                    help="also time the same workload on plain time-major frames (secondary figure)")
+    ap.add_argument("--no-layout-legs", action="store_true",
+                    help="skip the same workload on the two contract layouts: plain time-major frames [t][stream] (SURVEY 8d) and "
+                         "stream-major buffers [stream][t] (the reference's calling convention, test/benchmark.cpp:137-147)")
     args = ap.parse_args()
+    if args.no_autotune:
+        os.environ["FLOWZ_HIP_AUTOTUNE"] = "0"               # library_default = the static choice, nothing measured on first use
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started by hand without a launcher: become `torch.distributed.run` with one rank per GPU
@@ -389,7 +399,7 @@ def main():
             for _ in range(20):
                 prog.run_block(x2, state=st2, out=y2, variant=variant)
             ms = event_ms(torch, lambda: prog.run_block(x2, state=st2, out=y2, variant=variant), 200)
-            return {"kernel": prog.kernel_name(variant, ns2, T), "avg_launch_ms": round(ms, 4)}
+            return {"kernel": prog.kernel_name(variant, ns2, T, t2), "avg_launch_ms": round(ms, 4)}
         for _ in range(20):
             prog.run_block(x2, state=st2, out=y2)
         res, tv = measure_config(torch, F, prog, x2, y2, st2, None, ns2, T, t2, 200, key, do_tune=not args.no_autotune)
@@ -417,7 +427,7 @@ def main():
             for _ in range(3):
                 p3.run_block(x3, state=st3, out=y3, variant=variant)
             ms = event_ms(torch, lambda: p3.run_block(x3, state=st3, out=y3, variant=variant), 5)
-            return {"kernel": p3.kernel_name(variant, ns3, T), "avg_launch_ms": round(ms, 4)}
+            return {"kernel": p3.kernel_name(variant, ns3, T, t3), "avg_launch_ms": round(ms, 4)}
         res, tv = measure_config(torch, F, p3, x3, y3, st3, None, ns3, T, t3, 10, key, do_tune=not args.no_autotune)
         st3.zero_()
         p3.run_block(x3, state=st3, out=y3, variant=tv)
@@ -446,7 +456,7 @@ def main():
             for _ in range(3):
                 p4.run_block(x4, state=st4, params=pd, out=y4, variant=variant)
             ms = event_ms(torch, lambda: p4.run_block(x4, state=st4, params=pd, out=y4, variant=variant), 10)
-            return {"kernel": p4.kernel_name(variant, ns3, T), "avg_launch_ms": round(ms, 4)}
+            return {"kernel": p4.kernel_name(variant, ns3, T, t4), "avg_launch_ms": round(ms, 4)}
         res, tv = measure_config(torch, F, p4, x4, y4, st4, pd, ns3, T, t4, 20, key, do_tune=not args.no_autotune)
         st4.zero_()
         p4.run_block(x4, state=st4, params=pd, out=y4, variant=tv)
@@ -460,10 +470,81 @@ def main():
                            f"(BASELINE configs[3]), " + (f"tiled:{t4}" if t4 else "time-major"))
         return res
 
+    def time_major_leg():
+        """The headline workload on plain time-major frames [t][stream] (SURVEY 8d's device layout): library default and tuned."""
+        x2, y2 = frames(torch, dev, ns, T, 1, 0), frames(torch, dev, ns, T, 1, 0)
+        st2 = torch.zeros((prog.n_state, ns), dtype=torch.float32, device=dev)
+        F.synth_fill(x2, SEED)
+        res, tv = measure_config(torch, F, prog, x2, y2, st2, None, ns, T, 0, max(5, args.steps // 2), f"cascade6_{ns}x{T}_timemajor",
+                                 do_tune=not args.no_autotune)
+        st2.zero_()
+        prog.run_block(x2, state=st2, out=y2, variant=tv)
+        ids = sample_ids(ns, PARITY_STREAMS, 15)
+        from oracle import coracle, flowz_oracle as O
+        want = coracle.df1_cascade([W.STABLE] * 6, O.synth_input(SEED, ids, T))
+        res["parity"] = parity_string(ndiff_bits(gather_streams(torch, y2, ids, 0), want), len(ids), T)
+        res["workload"] = f"6-stage DF1 cascade, {ns} streams x {T}-sample block, plain time-major frames [t][stream] (SURVEY 8d)"
+        return res
+
+    def stream_major_leg():
+        """The headline workload on stream-major buffers [stream][t] -- one contiguous sample buffer per closure, the reference's
+        calling convention (test/benchmark.cpp:137-147): fz_run_block_stream_major, library default and the best of SM_CANDIDATES."""
+        xf = frames(torch, dev, ns, T, 1, tile)
+        F.synth_fill(xf, SEED)
+        xs = torch.empty((ns, T, 1), dtype=torch.float32, device=dev)
+        F.frames_to_stream_major(xf, out=xs)
+        del xf
+        ys = torch.empty((ns, T, 1), dtype=torch.float32, device=dev)
+        st2 = torch.zeros((prog.n_state, ns), dtype=torch.float32, device=dev)
+        b = b_alg_of(prog, ns, T)
+        reps = max(5, args.steps // 2)
+        SMF = F.C.FZ_VF_STREAM_MAJOR
+
+        def one(v):
+            vv = None if v is None else F.make_variant(v[0], v[1], v[2], v[3])
+            for _ in range(2):
+                prog.run_block_stream_major(xs, state=st2, out=ys, variant=vv)
+            torch.cuda.synchronize()
+            ms = event_ms(torch, lambda: prog.run_block_stream_major(xs, state=st2, out=ys, variant=vv), reps)
+            q = v or (0, 0, 0, 0)
+            k = prog.kernel_name(F.make_variant(q[0], q[1], q[2], q[3] | SMF), ns, T)
+            return {"kernel": k, "avg_launch_ms": round(ms, 4), "Msamples_per_s": round(ns * T / ms / 1e3, 1),
+                    "achieved_GBs": round(b / ms / 1e6, 1), "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+        res = {"library_default": one(None)}
+        best_v = None
+        if not args.no_autotune:
+            cands = {}
+            for v in W.SM_CANDIDATES:
+                try:
+                    cands[v] = one(v)
+                except F.FlowzError:
+                    pass
+            best_v = min(cands, key=lambda v: cands[v]["avg_launch_ms"])
+            # (as in fz_program_tune: a candidate replaces the default only when it wins by more than the scatter of repeats)
+            if cands[best_v]["avg_launch_ms"] > 0.985 * res["library_default"]["avg_launch_ms"]:
+                best_v = (0, 0, 0, 0)
+            res["tuned"] = one(best_v)
+            res["candidates_ms"] = {f"{v[0]},{v[1]},{v[2]},{v[3]}": c["avg_launch_ms"] for v, c in cands.items()}
+        st2.zero_()
+        prog.run_block_stream_major(xs, state=st2, out=ys, variant=None if best_v is None else F.make_variant(*best_v))
+        ids = sample_ids(ns, PARITY_STREAMS, 16)
+        idt = torch.as_tensor(ids, device=dev, dtype=torch.long)
+        got = ys[idt].permute(1, 0, 2).contiguous().cpu().numpy()
+        from oracle import coracle, flowz_oracle as O
+        want = coracle.df1_cascade([W.STABLE] * 6, O.synth_input(SEED, ids, T))
+        res["parity"] = parity_string(ndiff_bits(got, want), len(ids), T)
+        res["algorithmic_bytes_per_launch"] = b
+        best = max((k for k in ("library_default", "tuned") if k in res), key=lambda k: res[k]["frac"])
+        res["frac"], res["best_plan"] = res[best]["frac"], best
+        res["workload"] = (f"6-stage DF1 cascade, {ns} streams x {T}-sample block, stream-major buffers [stream][t] "
+                           f"(the reference's calling convention, test/benchmark.cpp:137-147), no layout pass")
+        return res
+
     ns3 = args.streams
     if args.only:
         fn = {"config2": config2, "config2h": lambda: config2(32768), "config2q": lambda: config2(16384), "config3": lambda: config3(False), "config3f": lambda: config3(True),
-              "config4": config4}[args.only]
+              "config4": config4, "timemajor": time_major_leg, "streammajor": stream_major_leg}[args.only]
         print(json.dumps({args.only: fn()}), flush=True)
         return
 
@@ -479,7 +560,7 @@ def main():
     tuned = None
     if not args.no_autotune and not forced:
         variant, _ = prog.tune(x, state=state, out=y)
-        tuned = prog.kernel_name(variant, ns, T)
+        tuned = prog.kernel_name(variant, ns, T, tile)
         state.zero_()
 
     # first block from zero state: kept for the parity check (>= 1024 random streams across all tiles)
@@ -520,21 +601,6 @@ def main():
         sustained = {"launches": n_sus, "seconds": round(ms_tot / 1e3, 3), "avg_launch_ms": round(ms_sus, 4),
                      "achieved_GBs": round(b_alg / ms_sus / 1e6, 1), "frac": round(b_alg / ms_sus / 1e6 / HBM_PEAK_GBS, 4)}
 
-    # the same workload on plain time-major frames [t][stream] (secondary figure, rank 0, N == 1)
-    tm = None
-    if args.time_major_too and tile and rank == 0 and world == 1:
-        x2, y2 = frames(torch, dev, ns, T, 1, 0), frames(torch, dev, ns, T, 1, 0)
-        st2 = torch.zeros((prog.n_state, ns), dtype=torch.float32, device=dev)
-        F.synth_fill(x2, SEED, stream0=begin)
-        vtm = variant
-        if tuned is not None:
-            vtm, _ = prog.tune(x2, state=st2, out=y2)               # its own plan: the layouts prefer different ones
-        prog.run_block(x2, state=st2, out=y2, variant=vtm)
-        torch.cuda.synchronize()
-        tm_ms = event_ms(torch, lambda: prog.run_block(x2, state=st2, out=y2, variant=vtm), 5)
-        tm = {"avg_launch_ms": round(tm_ms, 4), "Msamples_per_s": round(ns * T / tm_ms / 1e3, 1)}
-        del x2, y2, st2
-
     # copy-kernel yardstick (same bytes in + out), rank 0 only
     copy_gbs = None
     if rank == 0:
@@ -546,6 +612,11 @@ def main():
     if rank == 0 and world == 1:
         del x, y, state
         torch.cuda.empty_cache()
+        if not args.no_layout_legs:
+            secondary["time_major_layout"] = time_major_leg()
+            torch.cuda.empty_cache()
+            secondary["stream_major_layout"] = stream_major_leg()
+            torch.cuda.empty_cache()
         if not args.no_config2 and ns != 65536:
             secondary["config2_65536_streams"] = config2()
             torch.cuda.empty_cache()
@@ -563,7 +634,7 @@ def main():
 
     if rank == 0:
         achieved = b_alg / kern_avg_s / 1e9
-        kname = prog.kernel_name(variant, ns, T)
+        kname = prog.kernel_name(variant if variant is not None else prog.plan(ns, tile), ns, T, tile)
         traffic = traffic_of(kname, f"cascade6_{ns}x{T}_{lay}")
         line = {
             "metric": "Msamples/sec/GPU + achieved HBM GB/s, 6-biquad cascade, 1M streams",
@@ -596,10 +667,6 @@ def main():
         if sustained is not None:
             line["roofline"]["sustained"] = sustained
         line.update(secondary)
-        if tm is not None:
-            tm["achieved_GBs"] = round(b_alg / (tm["avg_launch_ms"] / 1e3) / 1e9, 1)
-            tm["frac"] = round(tm["achieved_GBs"] / HBM_PEAK_GBS, 4)
-            line["time_major_layout"] = tm
         if world == 1 and not args.no_cpu_baseline:
             from oracle import coracle, flowz_oracle as O
             coefs = [W.STABLE] * 6

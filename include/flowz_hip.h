@@ -259,8 +259,10 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
 /* bits 12..14 / 16..18: cache policy of frame loads / stores (experiment knob, see the kernel source) */
 
 int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */
-/* the same with the variant's automatic fields resolved as fz_run_block would for this block shape */
-int fz_program_build_for(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples);
+/* the same with the variant's automatic fields resolved as a launch of this block shape would: the shape of a launch is
+ * (n_streams, n_samples, tile_streams) -- tile_streams as for fz_run_block_tiled, 0 = plain time-major rows (the library's choice
+ * depends on the layout: see FZ_VF_LOCKSTEP); stream-major frames are named by FZ_VF_STREAM_MAJOR in v->flags            */
+int fz_program_build_for(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams);
 /* Part k of the wave split into n_parts (FZ_VF_WAVES(n_parts); n_parts = 1: the graph itself next to an I/O wave) as a
  * program of its own, for inspection (fz_program_ir, fz_program_lines, fz_program_info): input = the cut wire before the
  * part (the graph input for k = 0), output = the cut wire behind it; constant slots are the parent's.  FZ_E_UNSUPPORTED when
@@ -278,11 +280,11 @@ typedef struct fz_kernel_resources {
    uint32_t vgpr_spills, sgpr_spills;
    uint32_t unroll;
 } fz_kernel_resources;
-int fz_program_kernel_resources(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, int as_launched,
-                                fz_kernel_resources* out);
-/* symbol of the variant's kernel as profilers show it, e.g. "fz_block_kernel_p2u32b256f0"; the
- * variant is resolved as fz_run_block would for (n_streams, n_samples) -- unroll lowered as above; returns length */
-long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples,
+int fz_program_kernel_resources(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
+                                int as_launched, fz_kernel_resources* out);
+/* symbol of the variant's kernel as profilers show it, e.g. "fz_block_kernel_p2u16b256f2097152": exactly the kernel a launch of
+ * the shape (n_streams, n_samples, tile_streams) runs -- one resolution shared with the launch path; returns length */
+long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
                             char* buf, size_t cap);
 /* generated HIP source of a variant (skeleton + graph body); returns length, writes <= cap    */
 long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap);
@@ -355,7 +357,7 @@ int fz_program_plan(fz_program* p, uint64_t n_streams, uint32_t tile_streams, fz
 
 /* the variants fz_program_tune would measure for this shape (the first entry is the library default {0,0,0,0});
  * writes min(n, cap) entries, returns n.  Pure host work: lets a build step pre-compile them (fz_program_build). */
-int fz_program_tune_candidates(fz_program* p, uint64_t n_streams, uint32_t n_samples, fz_variant* out, uint32_t cap);
+int fz_program_tune_candidates(fz_program* p, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, fz_variant* out, uint32_t cap);
 
 /* ------------------------------------------------------------------------------------------
  * fz_bank -- device-resident closure state for n_streams streams: the `state_` member of

@@ -34,12 +34,17 @@ def test_bench_json_contract_small_workload():
     for k in ("config2_65536_streams", "cascade6_32768_streams", "cascade6_16384_streams", "config3_par4_sum", "config3_par4_sum_fanout", "config4_osc_chain"):
         assert d[k]["parity"].startswith("bitwise-equal"), (k, d[k]["parity"])
         assert d[k]["library_default"]["frac"] > 0 and d[k]["tuned"]["kernel"].startswith("fz_block_kernel_p")
+    for k in ("time_major_layout", "stream_major_layout"):            # the two contract layouts on the driver line (round 3)
+        assert d[k]["parity"].startswith("bitwise-equal"), (k, d[k]["parity"])
+        assert d[k]["library_default"]["frac"] > 0 and d[k]["tuned"]["kernel"].startswith("fz_block_kernel_p") and 0 < d[k]["frac"] < 1
     assert c["Msamples_per_s_per_core"] > 0 and c["physical_cores"] >= 1 and c["logical_cpus"] >= c["physical_cores"]
+    assert c["cores"] <= c["threads"] and (c["cgroup_cpu_quota"] is None or c["cores"] <= max(1, round(c["cgroup_cpu_quota"])))
+    assert 0.5 < c["Msamples_per_s_per_core"] * c["cores"] / c["value"] < 2.0
     assert abs(d["value"] - 16384 * 512 * 3 / (d["ms_per_step"] * 3 / 1e3) / 1e6) / d["value"] < 1e-2
 
 
-def _run_bench(args, nproc=1, timeout=900):
-    if nproc > 1:
+def _run_bench(args, nproc=1, timeout=900, launcher=False):
+    if nproc > 1 or launcher:
         import socket
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
@@ -61,7 +66,8 @@ def test_bench_two_ranks_on_one_gpu_rehearse_the_sharded_path():
     """The N > 1 path of bench.py (launcher env, shard_range, per-rank generator offset, barrier, max-over-ranks time,
     the statistics all-reduce) with 2 ranks that share device 0 and reduce over gloo: the integer checksum of the two
     shards must equal a single-process run over the union of the global stream ids.  Weak and strong scaling modes."""
-    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-autotune", "--no-config2", "--no-config34", "--no-sustained"]
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-autotune", "--no-config2", "--no-config34", "--no-sustained",
+              "--no-layout-legs"]
     one = _run_bench(["--gpus", "1", "--streams", "262144"] + common)
     weak = _run_bench(["--gpus", "2", "--streams", "131072", "--dist-backend", "gloo"] + common, nproc=2)
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak"
@@ -71,3 +77,19 @@ def test_bench_two_ranks_on_one_gpu_rehearse_the_sharded_path():
     strong = _run_bench(["--gpus", "2", "--scaling", "strong", "--streams-total", "262144", "--dist-backend", "gloo"] + common, nproc=2)
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["config"]["streams_total"] == 262144
     assert strong["checksum"] == one["checksum"]
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_reduces_its_statistics_over_rccl():
+    """The `nccl` (= RCCL) branch of bench.py on real hardware: one rank under torch.distributed.run, process group on the GPU,
+    the three statistics reduced by RCCL all-reduces on device tensors (zignal_amd/dist.py).  Same checksum and stream count
+    as the plain single-process run."""
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-autotune", "--no-config2", "--no-config34", "--no-sustained",
+              "--no-layout-legs"]
+    one = _run_bench(["--gpus", "1", "--streams", "131072"] + common)
+    rccl = _run_bench(["--gpus", "1", "--streams", "131072", "--dist-backend", "nccl"] + common, launcher=True)
+    assert rccl["n_gpus"] == 1 and rccl["config"]["streams_total"] == 131072
+    assert "statistics reduced over nccl" in rccl["config"]["parallelism"]
+    assert "reduced over" not in one["config"]["parallelism"]
+    assert rccl["checksum"] == one["checksum"] and isinstance(rccl["checksum"], int)
+    assert abs(rccl["value"] - 131072 * 4096 * 2 / (rccl["ms_per_step"] * 2 / 1e3) / 1e6) / rccl["value"] < 1e-2

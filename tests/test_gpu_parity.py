@@ -1442,6 +1442,33 @@ def test_host_stream_major_buffers(torch_cuda, F, pinned):
     assert np.array_equal(np.transpose(y2, (1, 0, 2)), want2.cpu().numpy())
 
 
+def test_sample_rate_modulators_through_the_chunked_host_paths(torch_cuda, F):
+    """the host-frames pipelines cut a long block into time chunks and launch every chunk on a buffer of its own
+    (row 0 of the buffer = sample t0 of the block); the modulator rows must follow the chunk, not start over at 0."""
+    torch = torch_cuda
+    ns, T = 16384, 2304                                   # 144 MiB of frames each way: 5 time chunks (ragged last one)
+    g = G.modulated_mix()
+    prog = F.compile(F.from_sexpr(g))
+    rng = np.random.default_rng(15)
+    md = torch.from_numpy(rng.uniform(-0.9, 0.9, (2, T)).astype(np.float32)).cuda()
+    prog.set_modulation(md)
+    xd = torch.empty((T, ns, 2), dtype=torch.float32, device="cuda")
+    F.synth_fill(xd, SEED + 54)
+    want, st = prog.run_block(xd)                          # one launch over the whole block
+    ids = np.array([0, 1, 63, 64, 777, ns - 1])
+    ref = O.compile(g, len(ids)).run(O.synth_input(SEED + 54, ids, T, n_wires=2), mod=md.cpu().numpy())
+    assert ndiff(want[:, torch.as_tensor(ids, device="cuda")].cpu().numpy(), ref) == 0
+    y = prog.bank(ns).process_host(xd.cpu().numpy())
+    assert np.array_equal(y.view(np.uint32), want.cpu().numpy().view(np.uint32))
+    ys = prog.bank(ns).process_host_stream_major(np.ascontiguousarray(xd.permute(1, 0, 2).cpu().numpy()))
+    assert np.array_equal(np.transpose(ys, (1, 0, 2)).view(np.uint32), want.cpu().numpy().view(np.uint32))
+    with pytest.raises(F.FlowzError):
+        prog.set_modulation(md.cpu())                      # (a host tensor is refused, not dereferenced)
+    prog.set_modulation(md[:, :T - 8].contiguous())       # an array shorter than the block: refused by the chunk that would overrun it
+    with pytest.raises(F.FlowzError):
+        prog.bank(ns).process_host(xd.cpu().numpy())
+
+
 def test_autotune_env_measures_the_plan_on_first_use(torch_cuda):
     """FLOWZ_HIP_AUTOTUNE=1: the first big block of a shape selects its plan by itself; state and results are
     what a plain launch gives (own process: the knob is read once per process)."""

@@ -108,10 +108,10 @@ def _load():
         "fz_program_get_const": (ctypes.c_int, [P, u32, ctypes.POINTER(f32)]),
         "fz_program_set_const": (ctypes.c_int, [P, u32, f32]),
         "fz_program_build": (ctypes.c_int, [P, ctypes.POINTER(Variant)]),
-        "fz_program_build_for": (ctypes.c_int, [P, ctypes.POINTER(Variant), u64, u32]),
+        "fz_program_build_for": (ctypes.c_int, [P, ctypes.POINTER(Variant), u64, u32, u32]),
         "fz_program_wave_part": (ctypes.c_int, [P, u32, u32, ctypes.POINTER(P)]),
-        "fz_program_kernel_resources": (ctypes.c_int, [P, ctypes.POINTER(Variant), u64, u32, ctypes.c_int, ctypes.POINTER(KernelResources)]),
-        "fz_program_kernel_name": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, ctypes.c_char_p, ctypes.c_size_t]),
+        "fz_program_kernel_resources": (ctypes.c_int, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_int, ctypes.POINTER(KernelResources)]),
+        "fz_program_kernel_name": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_char_p, ctypes.c_size_t]),
         "fz_program_source": (ctypes.c_long, [P, ctypes.POINTER(Variant), ctypes.c_char_p, ctypes.c_size_t]),
         "fz_run_block": (ctypes.c_int, [P, P, P, P, P, u64, u32, ctypes.POINTER(Variant), P]),
         "fz_run_block_tiled": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, ctypes.POINTER(Variant), P]),
@@ -121,7 +121,7 @@ def _load():
         "fz_bank_process_blocks": (ctypes.c_int, [P, P, P, u32, u32, P, u32, ctypes.POINTER(Variant), P]),
         "fz_program_tune": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, P, ctypes.POINTER(Variant), ctypes.POINTER(f32)]),
         "fz_program_plan": (ctypes.c_int, [P, u64, u32, ctypes.POINTER(Variant)]),
-        "fz_program_tune_candidates": (ctypes.c_int, [P, u64, u32, ctypes.POINTER(Variant), u32]),
+        "fz_program_tune_candidates": (ctypes.c_int, [P, u64, u32, u32, ctypes.POINTER(Variant), u32]),
         "fz_recommended_tile_streams": (u32, [P]),
         "fz_bank_create": (ctypes.c_int, [P, u64, ctypes.POINTER(P)]),
         "fz_bank_clone": (ctypes.c_int, [P, ctypes.POINTER(P)]),

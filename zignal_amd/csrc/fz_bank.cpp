@@ -259,7 +259,7 @@ static int bank_process_host(fz_bank* b, const float* in_host, void* out_host, u
          int rc = FZ_OK;
          try {
             rc = fz::launch(b->prog, g.n_in ? din : nullptr, dout, g.n_state ? b->state : nullptr, b->params, b->n_streams, nt, uv,
-                            b->s_run, 0);
+                            b->s_run, 0, 0, 0, t0);              // (sample-rate modulators: this chunk starts at sample t0)
          } catch (...) {                                    // chunks already in flight still write into the caller's memory
             drain_pipeline(b);
             throw;
@@ -332,7 +332,7 @@ int fz_bank_process_host_stream_major(fz_bank* b, const float* in_host, float* o
          int rc = FZ_OK;
          try {
             rc = fz::launch(b->prog, g.n_in ? din : nullptr, dout, g.n_state ? b->state : nullptr, b->params, b->n_streams, nt, &sm,
-                            b->s_run, 0, chunk_t, 0);
+                            b->s_run, 0, chunk_t, 0, t0);
          } catch (...) {
             drain_pipeline(b);
             throw;

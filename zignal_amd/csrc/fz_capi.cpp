@@ -203,32 +203,32 @@ int fz_program_build(fz_program* p, const fz_variant* v)
       return FZ_OK;)
 }
 
-int fz_program_build_for(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples)
+int fz_program_build_for(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams)
 {
    FZ_GUARD(
       if (!p || !n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_build_for: bad arguments");
-      (void)get_kernel(p, settle_variant(p, resolve_variant(p->g, v, n_streams, n_samples)), nullptr);
+      (void)get_kernel(p, finalize_variant(p, v, n_streams, n_samples, tile_streams), nullptr);
       return FZ_OK;)
 }
 
-int fz_program_kernel_resources(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, int as_launched,
-                                fz_kernel_resources* out)
+int fz_program_kernel_resources(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
+                                int as_launched, fz_kernel_resources* out)
 {
    FZ_GUARD(
       if (!p || !out || !n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_kernel_resources: bad arguments");
-      Variant rv = resolve_variant(p->g, v, n_streams, n_samples);
-      if (as_launched) rv = settle_variant(p, rv);
+      const Variant rv = finalize_variant(p, v, n_streams, n_samples, tile_streams, as_launched != 0);
       const auto k = get_kernel(p, rv, nullptr);
       *out = fz_kernel_resources{k->res.vgprs, k->res.agprs, k->res.sgprs, k->res.scratch_bytes, k->res.lds_bytes, k->res.vgpr_spills,
                                  k->res.sgpr_spills, rv.U};
       return FZ_OK;)
 }
 
-long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, char* buf, size_t cap)
+long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
+                            char* buf, size_t cap)
 {
    try {
       if (!p) fail(FZ_E_INVALID, "null program");
-      const std::string s = kernel_name(p->g, settle_variant(p, resolve_variant(p->g, v, n_streams ? n_streams : (1ull << 20), n_samples ? n_samples : (1u << 20))));
+      const std::string s = kernel_name(p->g, finalize_variant(p, v, n_streams ? n_streams : (1ull << 20), n_samples ? n_samples : (1u << 20), tile_streams));
       if (buf && cap) {
          const size_t n = std::min(cap - 1, s.size());
          std::memcpy(buf, s.data(), n);
@@ -324,11 +324,11 @@ int fz_program_plan(fz_program* p, uint64_t n_streams, uint32_t tile_streams, fz
       return FZ_OK;)
 }
 
-int fz_program_tune_candidates(fz_program* p, uint64_t n_streams, uint32_t n_samples, fz_variant* out, uint32_t cap)
+int fz_program_tune_candidates(fz_program* p, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, fz_variant* out, uint32_t cap)
 {
    FZ_GUARD(
       if (!p || !n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_tune_candidates: bad arguments");
-      const std::vector<fz_variant> c = tune_candidates(p->g, n_streams, n_samples);
+      const std::vector<fz_variant> c = tune_candidates(p->g, n_streams, n_samples, tile_streams);
       for (size_t i = 0; i < c.size() && i < cap && out; ++i) out[i] = c[i];
       return (int)c.size();)
 }

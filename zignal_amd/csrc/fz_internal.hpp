@@ -202,7 +202,11 @@ struct fz_program {
 };
 
 namespace fz {
-Variant resolve_variant(const Graph& g, const fz_variant* v, uint64_t n_streams, uint32_t n_samples = 1u << 20);
+// the library's choice for a block shape; tile_streams 0 = plain time-major rows (stream-major frames: FZ_VF_STREAM_MAJOR in v->flags)
+Variant resolve_variant(const Graph& g, const fz_variant* v, uint64_t n_streams, uint32_t n_samples = 1u << 20, uint32_t tile_streams = 0,
+                        bool allow_lockstep = true);
+// the kernel a launch of that shape runs: resolved, fitted to the tile / the 4 GiB chunk limit, unroll lowered until nothing spills
+Variant finalize_variant(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, bool settle = true);
 // builds (or fetches from the caches) the kernel of variant v; fn_out != null: also load it on the
 // current device and return its hipFunction_t
 std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out);
@@ -210,12 +214,15 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
 Variant settle_variant(fz_program* p, Variant v);
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params,
            uint64_t n_streams, uint32_t n_samples, const fz_variant* v, void* stream, uint32_t tile_streams = 0,
-           uint32_t rows_total = 0, uint32_t row0 = 0);
+           uint32_t rows_total = 0, uint32_t row0 = 0, uint32_t mod_row0 = 0);   // mod_row0: row of the modulator arrays that goes with row 0 of the frame buffers
 int tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
-         uint32_t n_samples, uint32_t tile_streams, void* stream, fz_variant* chosen, float* chosen_ms);
-std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint32_t n_samples);
+         uint32_t n_samples, uint32_t tile_streams, void* stream, fz_variant* chosen, float* chosen_ms, bool implicit = false);
+std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams);
 int device_count();
 uint64_t graph_structure_hash(const Graph& g);
 // the plan a launch without a variant would use for this shape on the current device: in memory, else persisted, else {0,0,0,0}
 fz_variant planned_variant(fz_program* p, uint64_t n_streams, uint32_t tile_streams);
+void drop_plan(fz_program* p, uint64_t n_streams, uint32_t tile_streams);
+// is the kernel's code object at hand (in memory or in the on-disk cache), i.e. can it run without a hiprtc build?
+bool kernel_at_hand(fz_program* p, const Variant& v);
 }  // namespace fz

@@ -86,19 +86,26 @@ static std::vector<const char*> build_options(const Variant& v)
 // Where code objects are cached: FLOWZ_HIP_CACHE, else <package>/_kcache next to the library when that is
 // writable (build() pre-fills it), else a PER-USER directory under /tmp (mode 0700, owner checked: another
 // local user must not be able to plant a code object there).
+// <package>/_kcache next to the library (build() pre-fills it); "" when the library's path is unknown
+static std::string package_cache_dir()
+{
+   Dl_info info;
+   if (!dladdr((const void*)&package_cache_dir, &info) || !info.dli_fname) return "";
+   std::string p = info.dli_fname;                   // .../zignal_amd/lib/libflowz_hip.so
+   size_t s = p.rfind('/');
+   if (s != std::string::npos) p = p.substr(0, s);
+   s = p.rfind('/');
+   if (s != std::string::npos) p = p.substr(0, s);
+   return p + "/_kcache";
+}
+
 std::string cache_dir()
 {
    if (const char* env = std::getenv("FLOWZ_HIP_CACHE")) return env;
-   Dl_info info;
-   if (dladdr((const void*)&cache_dir, &info) && info.dli_fname) {
-      std::string p = info.dli_fname;                // .../zignal_amd/lib/libflowz_hip.so
-      size_t s = p.rfind('/');
-      if (s != std::string::npos) p = p.substr(0, s);
-      s = p.rfind('/');
-      if (s != std::string::npos) p = p.substr(0, s);
-      const std::string d = p + "/_kcache";
-      ::mkdir(d.c_str(), 0755);
-      if (::access(d.c_str(), W_OK | X_OK) == 0) return d;
+   const std::string pkg = package_cache_dir();
+   if (!pkg.empty()) {
+      ::mkdir(pkg.c_str(), 0755);
+      if (::access(pkg.c_str(), W_OK | X_OK) == 0) return pkg;
    }
    const std::string d = "/tmp/flowz_hip_kcache-" + std::to_string((long)getuid());
    ::mkdir(d.c_str(), 0700);
@@ -125,7 +132,7 @@ static uint64_t fnv1a_bytes(const char* d, size_t n)
    return h;
 }
 
-static bool cache_load(const std::string& path, std::vector<char>& code)
+static bool cache_load(const std::string& path, std::vector<char>& code, bool may_delete = true)
 {
    std::ifstream f(path, std::ios::binary);
    if (!f) return false;
@@ -138,7 +145,7 @@ static bool cache_load(const std::string& path, std::vector<char>& code)
            h.hash == fnv1a_bytes(raw.data(), (size_t)h.size) && std::memcmp(raw.data(), "\x7f" "ELF", 4) == 0;
    }
    if (!ok) {
-      ::unlink(path.c_str());                        // truncated / foreign / stale: never try it again
+      if (may_delete) ::unlink(path.c_str());        // truncated / foreign / stale: never try it again
       return false;
    }
    raw.resize((size_t)h.size);
@@ -249,23 +256,46 @@ Variant settle_variant(fz_program* p, Variant v)
    }
 }
 
+// file name of a variant's code object: a hash of (generated source, build options, hiprtc version)
+static std::string cache_file_of(const fz_program* p, const Variant& v)
+{
+   std::string key_src = full_source(p->g, v);
+   for (const char* o : build_options(v)) key_src += o;
+   int rtc_major = 0, rtc_minor = 0;
+   hiprtcVersion(&rtc_major, &rtc_minor);
+   key_src += "hiprtc" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor);
+   char name[64];
+   std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)fnv1a(key_src));
+   return name;
+}
+
+static bool cache_in_use(const std::string& dir) { return !std::getenv("FLOWZ_HIP_NO_CACHE") && !dir.empty(); }
+
+bool kernel_at_hand(fz_program* p, const Variant& v)
+{
+   {
+      std::lock_guard<std::mutex> lock(p->mu);
+      auto it = p->kernels.find(v);
+      if (it != p->kernels.end() && it->second) return true;
+   }
+   const std::string dir = cache_dir(), pkg = package_cache_dir();
+   if (!cache_in_use(dir)) return false;
+   const std::string name = cache_file_of(p, v);
+   return ::access((dir + name).c_str(), R_OK) == 0 || (!pkg.empty() && pkg != dir && !std::getenv("FLOWZ_HIP_CACHE") && ::access((pkg + name).c_str(), R_OK) == 0);
+}
+
 std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out)
 {
    std::lock_guard<std::mutex> lock(p->mu);
    auto& slot = p->kernels[v];
    if (!slot) {
       auto k = std::make_shared<Kernel>();
-      std::string key_src = full_source(p->g, v);
-      for (const char* o : build_options(v)) key_src += o;
-      int rtc_major = 0, rtc_minor = 0;
-      hiprtcVersion(&rtc_major, &rtc_minor);
-      key_src += "hiprtc" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor);
-      char name[64];
-      std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)fnv1a(key_src));
-      const std::string dir = cache_dir(), path = dir + name;
-      const bool use_cache = !std::getenv("FLOWZ_HIP_NO_CACHE") && !dir.empty();
+      const std::string name = cache_file_of(p, v), dir = cache_dir(), path = dir + name, pkg = package_cache_dir();
+      const bool use_cache = cache_in_use(dir);
       k->cache_path = use_cache ? path : std::string();
-      if (!(use_cache && cache_load(path, k->code))) {
+      // (a package cache this user cannot write to -- installed by root, pre-filled by build() -- is still read)
+      const bool ro_pkg = use_cache && !pkg.empty() && pkg != dir && !std::getenv("FLOWZ_HIP_CACHE");
+      if (!(use_cache && (cache_load(path, k->code) || (ro_pkg && cache_load(pkg + name, k->code, false))))) {
          k->code = jit_compile(p->g, v);
          if (use_cache) cache_store(dir, path, k->code);
       }
@@ -276,12 +306,19 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
       require_device();
       try {
          *fn_out = slot->function_on_current_device(kernel_name(p->g, v));
-      } catch (const Error&) {
-         // a cached code object the driver refuses: delete it, build afresh, try once more
-         if (slot->cache_path.empty()) throw;
-         ::unlink(slot->cache_path.c_str());
-         slot->cache_path.clear();
+      } catch (const Error& er) {
+         // a cached code object the DRIVER refuses to load (built for another code-object version, damaged in a way the trailer
+         // does not see): delete it, build afresh, store that, try once more.  Anything else -- out of memory, no device, a
+         // missing symbol -- is not the file's fault and is passed on.
+         const bool image = er.msg.find("hipModuleLoadData") != std::string::npos &&
+                            (er.msg.find("invalid") != std::string::npos || er.msg.find("binary") != std::string::npos ||
+                             er.msg.find("image") != std::string::npos || er.msg.find("shared object") != std::string::npos);
+         if (slot->cache_path.empty() || !image) throw;
+         const std::string path = slot->cache_path;
+         ::unlink(path.c_str());
          slot->code = jit_compile(p->g, v);
+         slot->res = read_resources(slot->code);
+         cache_store(cache_dir(), path, slot->code);
          *fn_out = slot->function_on_current_device(kernel_name(p->g, v));
       }
    }

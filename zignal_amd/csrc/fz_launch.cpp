@@ -28,7 +28,8 @@ struct ArgsHeader {
 static_assert(sizeof(ArgsHeader) % 8 == 0 && sizeof(ArgsHeader) == 5 * 8 + 8 + 8 * 4, "ArgsHeader must match the head of the kernel's fz_args without padding");
 
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
-           uint32_t n_samples, const fz_variant* uv, void* stream, uint32_t tile_streams, uint32_t rows_total, uint32_t row0)
+           uint32_t n_samples, const fz_variant* uv, void* stream, uint32_t tile_streams, uint32_t rows_total, uint32_t row0,
+           uint32_t mod_row0)
 {
    if (rows_total == 0) rows_total = n_samples;             // the block is the whole buffer
    if ((uint64_t)row0 + n_samples > rows_total) fail(FZ_E_INVALID, "row0 + n_samples exceeds rows_total");
@@ -59,6 +60,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    if (tile_streams && n_streams % tile_streams) fail(FZ_E_INVALID, "n_streams must be a multiple of tile_streams");
    require_device();
    fz_variant planned;
+   bool from_plan = false;
    if (!uv) {                                               // a measured plan for this shape on this device?
       int dev = 0;
       FZ_HIP(hipGetDevice(&dev));
@@ -69,14 +71,21 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
          std::lock_guard<std::mutex> lock(p->mu);
          auto it = p->plans.find(key);
          known = it != p->plans.end() || p->tuned_default.count(key) != 0;
-         if (it != p->plans.end()) {
+         // (a plan is measured on blocks of thousands of samples: the wave-split kernels pay several masked rounds per launch and
+         //  are not what a short block -- the per-sample call protocol -- should run, whatever was tuned for the shape)
+         if (it != p->plans.end() && !(ws_parts(it->second.flags) && n_samples < 256)) {
             planned = it->second;
             uv = &planned;
+            from_plan = true;
          }
       }
-      // FLOWZ_HIP_AUTOTUNE=1: the first big block of a shape measures the plan by itself (on the caller's
-      // buffers; the state is saved and restored around the measurement, `out` is recomputed below)
-      static const bool autotune = [] { const char* e = std::getenv("FLOWZ_HIP_AUTOTUNE"); return e && *e && *e != '0'; }();
+      // The first BIG block of a shape measures the plan by itself (round 3: on by default; FLOWZ_HIP_AUTOTUNE=0 turns it off):
+      // which variant streams fastest differs from board to board by more than the variants differ on one board (the same
+      // kernel: +5 % here, -13 % there), so the library's static choice is only the first candidate.  The measurement runs on the
+      // caller's buffers (the state is saved and restored around it, `out` is recomputed below), takes the candidates whose
+      // code objects are at hand (build() pre-builds them for the BASELINE graphs; nothing is JIT-compiled for it) and
+      // costs about ten launches each; blocks below 2^26 stream-samples (a few hundred microseconds) never trigger it.
+      static const bool autotune = [] { const char* e = std::getenv("FLOWZ_HIP_AUTOTUNE"); return !(e && *e == '0'); }();
       bool can_tune = autotune && !known && rows_total == n_samples && row0 == 0 && n_streams * (uint64_t)n_samples >= (1ull << 26);
       if (can_tune) {
          // not while the stream is being captured into a hipGraph (the measurement allocates and synchronises), and not
@@ -121,35 +130,27 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
          }
          if (have_copy) {
             fz_variant chosen{0, 0, 0, 0};
-            const int rc = tune(p, in, out, state, params, n_streams, n_samples, tile_streams, stream, &chosen, nullptr);
+            const int rc = tune(p, in, out, state, params, n_streams, n_samples, tile_streams, stream, &chosen, nullptr, true);
             if (rc != FZ_OK) return rc;
             if (chosen.streams_per_lane || chosen.unroll || chosen.block_threads || chosen.flags) {
                planned = chosen;
                uv = &planned;
+               from_plan = true;
             }
          }
       }
    }
-   Variant v = resolve_variant(g, uv, n_streams, n_samples);
-   // time-major frames of many streams: the rows are megabytes apart, every row in flight is another page, and 16 rows per
-   // lane do better than 32 (1 M streams: 6.46 ms against 6.88 ms; stream-tiled frames keep 32: tools/slab_probe.py)
-   if (!tile_streams && !(v.flags & FZ_VF_STREAM_MAJOR) && !(uv && uv->unroll) && v.P == 2 && v.U == 32 && n_streams >= (1u << 19)) v.U = 16;
-   if (tile_streams) {
-      // a workgroup must not straddle tiles: shrink the lane packing / block until it divides
-      const bool fixedP = uv && uv->streams_per_lane, fixedB = uv && uv->block_threads;
-      while (tile_streams % (v.P * v.block) && !fixedP && v.P > 1) v.P /= 2;
-      while (tile_streams % (v.P * v.block) && !fixedB && v.block > 64) v.block /= 2;
-      if (tile_streams % (v.P * v.block))
-         fail(FZ_E_INVALID, "tile_streams must be a multiple of streams_per_lane * block_threads");
+   Variant v;
+   try {
+      v = finalize_variant(p, uv, n_streams, n_samples, tile_streams);
+   } catch (const Error&) {
+      // a remembered plan that does not resolve any more (persisted by another build of the library, a damaged line that passed the
+      // range checks): forget it and run the library's own choice instead of failing every default launch of this shape
+      if (!from_plan) throw;
+      drop_plan(p, n_streams, tile_streams);
+      uv = nullptr;
+      v = finalize_variant(p, nullptr, n_streams, n_samples, tile_streams);
    }
-   {  // a chunk of U rows is addressed through ONE buffer descriptor: it must stay below 4 GiB
-      const uint64_t row_bytes = stream_major ? 0 : row_streams * std::max(wmax, out_w) * 4;
-      while (row_bytes * v.U >= (1ull << 32) && v.U > 1) {
-         if (uv && uv->unroll) fail(FZ_E_INVALID, "unroll x row bytes must stay below 4 GiB: lower the unroll or tile the streams");
-         v.U /= 2;
-      }
-   }
-   v = settle_variant(p, v);
    void* fn = nullptr;
    auto k = get_kernel(p, v, &fn);
 
@@ -167,7 +168,10 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       mod_dev = p->mod_dev;
       mod_stride = p->mod_stride;
       if (!mod_dev) fail(FZ_E_INVALID, "the graph has sample-rate modulators: call fz_program_set_modulation first");
-      if (mod_stride < rows_total) fail(FZ_E_INVALID, "fz_program_set_modulation: stride is shorter than the rows of this launch");
+      // (the host-frames pipelines hand time chunks of a long block to the kernel as buffers of their own: row 0 of such a
+      //  buffer is sample mod_row0 of the block, and the modulator rows must follow)
+      if ((uint64_t)mod_row0 + row0 + n_samples > mod_stride) fail(FZ_E_INVALID, "fz_program_set_modulation: stride is shorter than the rows of this launch");
+      mod_dev += mod_row0;
    }
    ArgsHeader h{in, out, state, params, mod_dev, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
                 (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0, mod_stride, 0u};

@@ -16,8 +16,11 @@ namespace fz {
 // ---- variant selection ---------------------------------------------------------------------------------
 constexpr uint64_t kMaxLdsBytes = 160 * 1024;
 
-Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples)
+// tile_streams: the frame layout the variant is for -- 0 (or >= n_streams) plain time-major rows, else stream tiles (stream-major
+// frames are named by FZ_VF_STREAM_MAJOR in the variant's flags).  allow_lockstep: see the time-major rule below.
+Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, bool allow_lockstep)
 {
+   if (tile_streams >= n_streams) tile_streams = 0;
    Variant v;
    const uint32_t reqP = uv ? uv->streams_per_lane : 0, reqU = uv ? uv->unroll : 0, reqB = uv ? uv->block_threads : 0;
    v.flags = uv ? uv->flags : 0;
@@ -26,6 +29,8 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       fail(FZ_E_INVALID, "FZ_VF_OUT_F64 does not apply to fz_compile_typed programs: their frames carry every wire in its own type");
    if (reqU > 32 && !((v.flags & FZ_VF_SM_LONG) && (reqU == 64 || reqU == 128))) fail(FZ_E_INVALID, "unroll must be <= 32");
    if (reqB != 0 && (reqB % 64 != 0 || reqB > 1024)) fail(FZ_E_INVALID, "block_threads must be a multiple of 64, <= 1024");
+   if ((v.flags & FZ_VF_LOCKSTEP) && (ws_parts(v.flags) || (v.flags & (FZ_VF_STREAM_MAJOR | FZ_VF_STAGE_PACK))))
+      fail(FZ_E_INVALID, "FZ_VF_LOCKSTEP applies to the plain frame kernel (time-major / tiled frames, no stage packing, no wave split)");
    if (const uint32_t W = ws_parts(v.flags)) {
       // W compute waves per 64 streams, each evaluating one part of the serial graph (fz_split.cpp: find_wave_roles), and with
       // FZ_VF_IO_WAVE one more wave for the frame I/O
@@ -45,8 +50,11 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // four SIMDs), triples and quadruples one
       // (with I/O waves: one compute wave on each SIMD and the I/O waves next to them -- 4 tuples for one part, 2 for two)
       v.block = reqB ? reqB : (ws_io(v.flags) ? (W == 1 ? 256 : W == 2 ? 128 : 64) : (W == 2 ? 128 : 64));
-      {  // the rings of a workgroup must fit the CU's LDS: tuples x hand-offs x ring x 1 KiB
-         const uint32_t K0 = (*g.wave_roles(W))[0].split.K, ring = (K0 - 1 > 4 ? v.U : v.U / 2), nring = W - 1 + 2 * ws_io(v.flags);
+      {  // the rings of a workgroup must fit the CU's LDS: tuples x hand-offs x ring x 1 KiB (the kernel sizes every ring of a
+         // tuple for the widest hand-off: U groups behind a part that lags by more than 4 samples, else U / 2)
+         uint32_t kmax = 0;
+         for (const Graph& r : *g.wave_roles(W)) kmax = std::max(kmax, r.split.K);
+         const uint32_t ring = (kmax - 1 > 4 ? v.U : v.U / 2), nring = W - 1 + 2 * ws_io(v.flags);
          while ((uint64_t)(v.block / 64) * nring * ring * 1024 > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
          if ((uint64_t)(v.block / 64) * nring * ring * 1024 > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "wave split: the hand-off rings do not fit the LDS with this unroll and block size");
       }
@@ -72,8 +80,10 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    // prefetch depth in time steps: 16 rows in flight per lane; 32 once the chip is oversubscribed
    // with packed lanes (fewer, fatter waves: 2 per SIMD)
    // (per-stream coefficients sit in VGPRs too: with 31 of them the deep prefetch costs 10 %)
-   const uint32_t reg_values = (reg_state + g.n_param) * v.P;
-   v.U = reqU ? reqU : ((v.P == 2 && n_streams >= (1u << 19) && g.n_in == 1 && g.n_out == 1 && reg_values <= 40) ? 32 : 16);
+   // (round 3: 16 rows for packed lanes too.  32 rows in flight measured level with 16 on the boards of rounds 1-2 and 13 % SLOWER
+   //  on two boards of round 3 -- 6.54 / 6.56 ms against 5.76 / 5.79 ms for the headline workload, gpurun_out/r03a-b -- so the
+   //  deeper prefetch is left to fz_program_tune)
+   v.U = reqU ? reqU : 16;
    // wide frames, one stream per lane, chip oversubscribed: 32 rows in flight per lane (measured on three boards, 4-wire
    // frames at 1 M streams: 13.4-14.1 ms against 14.4-14.6 ms with 16; profiles/r02/tune_logs.txt)
    if (!reqU && v.P == 1 && g.n_in >= 3 && n_streams >= (1u << 19) && !(v.flags & FZ_VF_STAGE_PACK)) v.U = 32;
@@ -106,7 +116,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // it (profiles/r02/sweep_io_wave.txt)
       if (W) {
          fz_variant q{1, reqU, 0, v.flags | (W - 1) << 10 | (W < 4 ? (uint32_t)FZ_VF_IO_WAVE : 0u)};
-         return resolve_variant(g, &q, n_streams, n_samples);
+         return resolve_variant(g, &q, n_streams, n_samples, tile_streams, allow_lockstep);
       }
    }
    // stage packing: one stream per lane, pairs of isomorphic graph segments in one v_pk_* (fz_split.cpp)
@@ -177,6 +187,31 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
                                 "unroll; use one stream per lane or a shorter unroll");
       return v;
    }
+   const bool plain_auto = !reqP && !reqU && !reqB && !(v.flags & ~(uint32_t)FZ_VF_OUT_F64);   // nothing asked for: the library's choice
+   // PLAIN TIME-MAJOR frames of many streams (round 3): consecutive rows are n_streams * wires * 4 bytes apart -- megabytes,
+   // i.e. every row a wave has in flight is another 2 MiB page, and waves that drift apart in time multiply the pages a CU
+   // touches (160 x the L1-TLB misses of tiled frames, profiles/r01/pmc_tlb_tiled_vs_timemajor.txt).  So the whole CU walks
+   // the rows together: ONE workgroup of 1024 lanes per CU that meets at a barrier after every chunk (FZ_VF_LOCKSTEP), few
+   // rows in flight per lane, and its sixteen waves read one contiguous 8-16 KiB piece of each row.  Measured on three boards,
+   // 6-biquad cascade, 1 M streams x 4096: 6.06 / 6.06 / 6.85 ms against 6.43 / 6.49 / 7.02 ms for four-wave workgroups that
+   // run free (0.71 / 0.71 / 0.63 of peak against 0.67 / 0.66 / 0.61); 262 144 streams: 1.53 ms against 1.79 ms
+   // (gpurun_out/r03a-c -> profiles/r03/sweep_time_major_lockstep.txt).  Needs >= 256 such workgroups (else CUs idle: 4 streams
+   // per lane at 262 144 streams ran 2.2 x slower), narrow frames (4-wire frames gain nothing: their rows are wide already)
+   // and a graph whose registers fit the 128 a lane of a 1024-lane workgroup gets (fz_finalize_variant falls back otherwise).
+   if (allow_lockstep && plain_auto && !tile_streams && n_streams >= (1u << 18) && g.n_in <= 2 && g.n_out <= 2 && g.far_lines.empty() &&
+       g.n_lds_slots == 0 && !(v.flags & FZ_VF_STAGE_PACK)) {
+      const uint32_t P = (n_streams >= (1u << 19) && n_streams % 2 == 0 && (reg_state + g.n_param) * 2 <= 40) ? 2 : 1;
+      if ((reg_state + g.n_param) * P <= 48) {
+         v.P = P;
+         v.U = P == 2 ? 2 : 8;
+         v.block = 1024;
+         v.flags |= FZ_VF_LOCKSTEP;
+         return v;
+      }
+   }
+   // stream-tiled frames, packed lanes, chip oversubscribed: two workgroups per CU (262 144 streams in flight keep fewer tiles
+   // open in DRAM: +2 % on the boards of round 3, level on those of round 2; profiles/r01/sweep_occupancy_cap.txt)
+   if (plain_auto && tile_streams && v.P == 2 && n_streams >= (1u << 19) && !g.n_lds_slots) v.flags |= FZ_VF_MAX_WG(2);
    if (g.n_lds_slots) {
       // LDS rings: slots * block * 4P bytes must fit the CU's 160 KiB of LDS (one workgroup may take it all)
       auto bytes = [&](const Variant& w) { return (uint64_t)g.n_lds_slots * w.block * 4u * w.P; };
@@ -185,6 +220,47 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       if (bytes(v) > kMaxLdsBytes)
          fail(FZ_E_UNSUPPORTED, "delay lines too long for the LDS ring buffers of this build (" +
                                    std::to_string(g.n_lds_slots) + " slots)");
+   }
+   return v;
+}
+
+// The kernel a launch of this shape runs: the variant resolved for the layout, fitted to the tile size and the 4 GiB chunk limit,
+// its unroll lowered until nothing spills.  ONE function for fz_run_block, fz_program_kernel_name, fz_program_build_for and
+// fz_program_kernel_resources, so that what is reported and pre-built is what is launched.
+// (settle = false: resolved and fitted only -- nothing is built; what the implicit tune uses to ask whether a candidate is at hand)
+Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, bool settle)
+{
+   const Graph& g = p->g;
+   if (tile_streams >= n_streams) tile_streams = 0;
+   const bool stream_major = uv && (uv->flags & FZ_VF_STREAM_MAJOR);
+   auto fit = [&](Variant v) {
+      if (tile_streams) {
+         // a workgroup must not straddle tiles: shrink the lane packing / block until it divides
+         const bool fixedP = uv && uv->streams_per_lane, fixedB = uv && uv->block_threads;
+         while (tile_streams % (v.P * v.block) && !fixedP && v.P > 1) v.P /= 2;
+         while (tile_streams % (v.P * v.block) && !fixedB && v.block > 64) v.block /= 2;
+         if (tile_streams % (v.P * v.block)) fail(FZ_E_INVALID, "tile_streams must be a multiple of streams_per_lane * block_threads");
+      }
+      if (!stream_major) {   // a chunk of U rows is addressed through ONE buffer descriptor: it must stay below 4 GiB
+         const uint64_t wmax = std::max<uint64_t>(std::max(g.n_in, g.n_out), 1);
+         const uint64_t out_w = (uint64_t)std::max<uint32_t>(g.n_out, 1) * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 2 : 1);
+         const uint64_t row_bytes = (tile_streams ? tile_streams : n_streams) * std::max(wmax, out_w) * 4;
+         const uint32_t umin = ws_parts(v.flags) ? 8u : 1u;            // (the wave-split kernels run rounds of 8 / 16 / 32 steps)
+         while (row_bytes * v.U >= (1ull << 32) && v.U > umin) {
+            if (uv && uv->unroll) fail(FZ_E_INVALID, "unroll x row bytes must stay below 4 GiB: lower the unroll or tile the streams");
+            v.U /= 2;
+         }
+         if (row_bytes * v.U >= (1ull << 32)) fail(FZ_E_UNSUPPORTED, "rows too wide for this kernel variant (unroll x row bytes must stay below 4 GiB): tile the streams");
+      }
+      return settle ? settle_variant(p, v) : v;
+   };
+   const Variant want = resolve_variant(g, uv, n_streams, n_samples, tile_streams);
+   Variant v = fit(want);
+   if (settle && (v.flags & FZ_VF_LOCKSTEP) && !(uv && (uv->flags & FZ_VF_LOCKSTEP))) {
+      // the library's own lockstep choice needs its kernel in the 128 registers of a 1024-lane workgroup with the rows in flight
+      // it was chosen for; a graph that does not fit runs the ordinary four-wave workgroups
+      const auto k = get_kernel(p, v, nullptr);
+      if (k->res.scratch_bytes != 0 || v.U < want.U) v = fit(resolve_variant(g, uv, n_streams, n_samples, tile_streams, false));
    }
    return v;
 }
@@ -221,14 +297,18 @@ static std::string board_id()
 
 static bool plan_cache_on() { return !std::getenv("FLOWZ_HIP_NO_PLAN_CACHE") && !std::getenv("FLOWZ_HIP_NO_CACHE"); }
 
-static void plan_store(const fz_program* p, uint64_t n_streams, uint32_t tile, const fz_variant& v, float ms)
+// One line per tune: "<format tag> <graph hash> <n_streams> <tile> <board> <P> <U> <block> <flags> <ms> <n_samples>".  The tag names
+// the layout of the line AND of the flag bits (they were re-assigned between rounds): lines with another tag are not ours to read.
+static const char kPlanTag[] = "fzplan3";
+
+static void plan_store(const fz_program* p, uint64_t n_streams, uint32_t n_samples, uint32_t tile, const fz_variant& v, float ms)
 {
    const std::string dir = cache_dir(), id = board_id();
    if (!plan_cache_on() || dir.empty() || id.empty()) return;
    ::mkdir(dir.c_str(), 0755);
    char line[256];
-   const int n = std::snprintf(line, sizeof line, "%016llx %llu %u %s %u %u %u %u %.5f\n", (unsigned long long)p->graph_hash,
-                               (unsigned long long)n_streams, tile, id.c_str(), v.streams_per_lane, v.unroll, v.block_threads, v.flags, ms);
+   const int n = std::snprintf(line, sizeof line, "%s %016llx %llu %u %s %u %u %u %u %.5f %u\n", kPlanTag, (unsigned long long)p->graph_hash,
+                               (unsigned long long)n_streams, tile, id.c_str(), v.streams_per_lane, v.unroll, v.block_threads, v.flags, ms, n_samples);
    if (n <= 0 || n >= (int)sizeof line) return;
    if (FILE* f = std::fopen((dir + "/plans.txt").c_str(), "a")) {     // one short append per tune: later lines win
       std::fwrite(line, 1, (size_t)n, f);
@@ -246,16 +326,26 @@ static bool plan_load(const fz_program* p, uint64_t n_streams, uint32_t tile, fz
    std::string ln;
    while (std::getline(f, ln)) {
       unsigned long long h = 0, ns = 0;
-      unsigned t = 0, P = 0, U = 0, B = 0, fl = 0;
-      char idbuf[64] = {0};
+      unsigned t = 0, P = 0, U = 0, B = 0, fl = 0, T = 0;
+      char idbuf[64] = {0}, tag[16] = {0};
       float ms = 0.f;
-      if (std::sscanf(ln.c_str(), "%llx %llu %u %63s %u %u %u %u %f", &h, &ns, &t, idbuf, &P, &U, &B, &fl, &ms) != 9) continue;
-      if (h != p->graph_hash || ns != n_streams || t != tile || id != idbuf) continue;
+      if (std::sscanf(ln.c_str(), "%15s %llx %llu %u %63s %u %u %u %u %f %u", tag, &h, &ns, &t, idbuf, &P, &U, &B, &fl, &ms, &T) != 11) continue;
+      if (std::strcmp(tag, kPlanTag) != 0 || h != p->graph_hash || ns != n_streams || t != tile || id != idbuf) continue;
       if ((P != 0 && P != 1 && P != 2 && P != 4) || U > 128 || B > 1024 || (B % 64)) continue;   // (a damaged line)
       *out = fz_variant{P, U, B, fl};
       found = true;
    }
    return found;
+}
+
+// a plan that no longer resolves (a stale or damaged line that passed the range checks): forget it for this process
+void drop_plan(fz_program* p, uint64_t n_streams, uint32_t tile_streams)
+{
+   int dev = 0;
+   if (hipGetDevice(&dev) != hipSuccess) return;
+   if (tile_streams >= n_streams) tile_streams = 0;
+   std::lock_guard<std::mutex> lock(p->mu);
+   p->plans.erase(std::make_tuple(n_streams, tile_streams, dev));
 }
 
 fz_variant planned_variant(fz_program* p, uint64_t n_streams, uint32_t tile_streams)
@@ -280,9 +370,10 @@ fz_variant planned_variant(fz_program* p, uint64_t n_streams, uint32_t tile_stre
 }
 
 // the variants fz_program_tune measures for a shape (the first one is the library default)
-std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint32_t n_samples)
+std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams)
 {
-   const Variant d = resolve_variant(g, nullptr, n_streams, n_samples);
+   if (tile_streams >= n_streams) tile_streams = 0;
+   const Variant d = resolve_variant(g, nullptr, n_streams, n_samples, tile_streams);
    std::vector<fz_variant> cands{fz_variant{0, 0, 0, 0}};
    if (const uint32_t W = ws_parts(d.flags)) {            // few streams: wave splits, with and without an I/O wave, against the single stage-packed wave
       const uint32_t wbits = (W - 1) << 10;
@@ -292,12 +383,26 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
       cands.push_back(fz_variant{1, 16, 0, FZ_VF_STAGE_PACK});
    } else if (d.flags & FZ_VF_STAGE_PACK) {
       if (n_streams <= 65536 && g.wave_roles(1)) cands.push_back(fz_variant{1, 16, 0, FZ_VF_IO_WAVE});   // one compute + one I/O wave per 64 streams
+      // one packed pair of segments per wave, four tuples to a workgroup (every SIMD of the CU gets one wave of every part):
+      // level with the single wave on some boards, +3 % on others (gpurun_out/r03b-c)
+      const uint32_t Wp = g.split.K / 2;
+      if (n_streams <= 65536 && n_streams % 256 == 0 && Wp >= 2 && Wp <= 4 && g.wave_roles(Wp)) {
+         cands.push_back(fz_variant{1, 16, 256, FZ_VF_WAVES(Wp)});
+         if (Wp <= 3) cands.push_back(fz_variant{1, 16, 256, FZ_VF_WAVES(Wp) | FZ_VF_IO_WAVE});
+      }
       cands.push_back(fz_variant{1, 24, 0, FZ_VF_STAGE_PACK});
       cands.push_back(fz_variant{1, 32, 0, FZ_VF_STAGE_PACK});
+   } else if (d.flags & FZ_VF_LOCKSTEP) {   // plain time-major frames, many streams: the CU-wide workgroups in lockstep against four-wave workgroups running free
+      cands.push_back(fz_variant{d.P, 16, 256, 0});
+      cands.push_back(fz_variant{d.P, d.P == 2 ? 4u : 4u, 1024, FZ_VF_LOCKSTEP});
+      if (d.P == 2) cands.push_back(fz_variant{1, 8, 1024, FZ_VF_LOCKSTEP});
+      if (d.P == 2) cands.push_back(fz_variant{4, 8, 512, FZ_VF_LOCKSTEP});
+      if (d.P == 2) cands.push_back(fz_variant{4, 8, 256, 0});
+      if (d.P == 1) cands.push_back(fz_variant{1, 16, 1024, FZ_VF_LOCKSTEP});
    } else if (d.P == 2) {            // many streams, narrow frames: lane packing x prefetch depth x workgroups per CU
-      cands.push_back(fz_variant{2, 16, 0, 0});
+      cands.push_back(fz_variant{2, 16, 256, (d.flags & FZ_VF_MAX_WG(7)) ? 0u : FZ_VF_MAX_WG(2)});
+      cands.push_back(fz_variant{2, 32, 256, 0});
       cands.push_back(fz_variant{4, 8, 0, 0});
-      cands.push_back(fz_variant{2, 16, 256, FZ_VF_MAX_WG(2)});
       cands.push_back(fz_variant{2, 32, 256, FZ_VF_MAX_WG(2)});
       cands.push_back(fz_variant{4, 8, 256, FZ_VF_MAX_WG(1)});
       cands.push_back(fz_variant{4, 12, 256, FZ_VF_MAX_WG(1)});
@@ -305,9 +410,9 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
       cands.push_back(fz_variant{4, 8, 128, FZ_VF_MAX_WG(2)});
       cands.push_back(fz_variant{4, 4, 256, FZ_VF_MAX_WG(2)});
    } else {
-      cands.push_back(fz_variant{1, 32, 0, 0});
+      cands.push_back(fz_variant{1, d.U == 32 ? 16u : 32u, 0, 0});
    }
-   if (!(d.flags & FZ_VF_STAGE_PACK) && d.P != 2 && n_streams >= (1u << 17)) {
+   if (!(d.flags & (FZ_VF_STAGE_PACK | FZ_VF_LOCKSTEP)) && d.P != 2 && n_streams >= (1u << 17)) {
       cands.push_back(fz_variant{1, 16, 256, FZ_VF_MAX_WG(1)});
       cands.push_back(fz_variant{1, 8, 256, FZ_VF_MAX_WG(1)});
       cands.push_back(fz_variant{1, 16, 256, FZ_VF_MAX_WG(2)});
@@ -320,14 +425,16 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
 // The variants differ by a few percent, and which one wins depends on the board (measured: the same
 // variant is +5 % on one MI355X of the pool and -3 % on the next), so -- like FFTW_MEASURE -- time the
 // candidates on the caller's own buffers once and remember the winner for this shape.
+// implicit: the measurement a first big launch makes by itself -- only candidates whose code object is at hand (in memory or in
+// the on-disk cache) take part: a launch never waits for hiprtc builds of kernels nobody asked for (fz_program_tune builds them all)
 int tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
-         uint32_t n_samples, uint32_t tile_streams, void* stream, fz_variant* chosen, float* chosen_ms)
+         uint32_t n_samples, uint32_t tile_streams, void* stream, fz_variant* chosen, float* chosen_ms, bool implicit)
 {
    const Graph& g = p->g;
    if (!n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_tune: empty block");
    require_device();
    if (tile_streams == 0 || tile_streams >= n_streams) tile_streams = 0;
-   std::vector<fz_variant> cands = tune_candidates(g, n_streams, n_samples);
+   std::vector<fz_variant> cands = tune_candidates(g, n_streams, n_samples, tile_streams);
    hipEvent_t e0, e1;
    FZ_HIP(hipEventCreate(&e0));
    FZ_HIP(hipEventCreate(&e1));
@@ -340,6 +447,7 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
       const bool warmup = cc == 0;
       const size_t c = warmup ? 0 : cc - 1;
       try {
+         if (implicit && c != 0 && !kernel_at_hand(p, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams, false))) continue;
          launch(p, in, out, state, params, n_streams, n_samples, &cands[c], stream, tile_streams);   // build, load, first touch
          // one launch to size the measurement (>= ~25 ms of kernel time: sub-millisecond kernels need
          // dozens of launches before their timing settles), then the measurement proper
@@ -356,7 +464,7 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
          }
          if (std::getenv("FLOWZ_HIP_DEBUG") || std::getenv("FLOWZ_HIP_TUNE_LOG"))
             std::fprintf(stderr, "[flowz_hip] tune %s n_streams=%llu tile=%u: P=%u U=%u block=%u flags=%u: %.4f ms%s\n",
-                         kernel_name(g, resolve_variant(g, &cands[c], n_streams, n_samples)).c_str(), (unsigned long long)n_streams,
+                         kernel_name(g, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams)).c_str(), (unsigned long long)n_streams,
                          tile_streams, cands[c].streams_per_lane, cands[c].unroll, cands[c].block_threads, cands[c].flags, ms,
                          warmup ? " (warm-up pass)" : "");
          if (!warmup && c == 0) default_ms = ms;
@@ -389,7 +497,7 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
       else p->plans[std::make_tuple(n_streams, tile_streams, dev)] = cands[(size_t)best];
       p->plan_looked_up.insert(std::make_tuple(n_streams, tile_streams, dev));
    }
-   plan_store(p, n_streams, tile_streams, cands[(size_t)best], best_ms);
+   plan_store(p, n_streams, n_samples, tile_streams, cands[(size_t)best], best_ms);
    if (chosen) *chosen = cands[(size_t)best];
    if (chosen_ms) *chosen_ms = best_ms;
    return FZ_OK;

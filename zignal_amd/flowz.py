@@ -337,7 +337,9 @@ class Program:
         reads modulator k at mod[k, row0 + t].  The tensor must stay alive until those launches have run."""
         import torch
 
-        assert mod.is_cuda and mod.dtype == torch.float32 and mod.is_contiguous() and mod.dim() == 2 and mod.shape[0] >= self.n_mod
+        if not (hasattr(mod, "is_cuda") and mod.is_cuda and mod.dtype == torch.float32 and mod.is_contiguous() and mod.dim() == 2
+                and mod.shape[0] >= self.n_mod):
+            raise FlowzError(C.FZ_E_INVALID, f"set_modulation: need a contiguous CUDA float32 tensor [>= {self.n_mod}, rows]")
         self._mod_keepalive = mod
         C.check(C.lib.fz_program_set_modulation(self._h, mod.data_ptr(), int(mod.shape[1])))
 
@@ -345,11 +347,12 @@ class Program:
         """Streams per frame tile that gives ~32 KiB row segments (see fz_run_block_tiled)."""
         return int(C.lib.fz_recommended_tile_streams(self._h))
 
-    def kernel_name(self, variant: Optional[Variant] = None, n_streams: int = 0, n_samples: int = 0) -> str:
-        """Symbol of the kernel that run_block would launch for this variant and size."""
+    def kernel_name(self, variant: Optional[Variant] = None, n_streams: int = 0, n_samples: int = 0, tile_streams: int = 0) -> str:
+        """Symbol of the kernel that a launch of this shape runs for this variant.  tile_streams: the frame layout (0 = plain
+        time-major rows, as for run_block on a 3-D tensor); stream-major frames: FZ_VF_STREAM_MAJOR in the variant's flags."""
         vp = ctypes.byref(variant) if variant is not None else None
         buf = ctypes.create_string_buffer(128)
-        C.check(C.lib.fz_program_kernel_name(self._h, vp, int(n_streams), int(n_samples), buf, 128))
+        C.check(C.lib.fz_program_kernel_name(self._h, vp, int(n_streams), int(n_samples), int(tile_streams), buf, 128))
         return buf.value.decode()
 
     def source(self, variant: Optional[Variant] = None) -> str:
@@ -366,30 +369,30 @@ class Program:
         C.check(C.lib.fz_program_plan(self._h, int(n_streams), int(tile_streams), ctypes.byref(v)))
         return v
 
-    def tune_candidates(self, n_streams: int, n_samples: int):
+    def tune_candidates(self, n_streams: int, n_samples: int, tile_streams: int = 0):
         """The variants Program.tune would measure for this shape (the first one is the library default)."""
-        n = C.check(C.lib.fz_program_tune_candidates(self._h, int(n_streams), int(n_samples), None, 0))
+        n = C.check(C.lib.fz_program_tune_candidates(self._h, int(n_streams), int(n_samples), int(tile_streams), None, 0))
         buf = (Variant * max(n, 1))()
-        C.check(C.lib.fz_program_tune_candidates(self._h, int(n_streams), int(n_samples), buf, n))
+        C.check(C.lib.fz_program_tune_candidates(self._h, int(n_streams), int(n_samples), int(tile_streams), buf, n))
         return [Variant(buf[i].streams_per_lane, buf[i].unroll, buf[i].block_threads, buf[i].flags) for i in range(n)]
 
-    def build(self, variant: Optional[Variant] = None, n_streams: int = 0, n_samples: int = 0):
+    def build(self, variant: Optional[Variant] = None, n_streams: int = 0, n_samples: int = 0, tile_streams: int = 0):
         """JIT-compile (or fetch from the on-disk cache) the kernel of `variant`; needs no GPU.  With a block shape the
-        variant's automatic fields resolve as run_block would for it (else as for a large stream count)."""
+        variant's automatic fields resolve as a launch of that shape would (else as for a large stream count)."""
         vp = ctypes.byref(variant) if variant is not None else None
         if n_streams:
-            C.check(C.lib.fz_program_build_for(self._h, vp, int(n_streams), int(n_samples or 4096)))
+            C.check(C.lib.fz_program_build_for(self._h, vp, int(n_streams), int(n_samples or 4096), int(tile_streams)))
         else:
             C.check(C.lib.fz_program_build(self._h, vp))
         return self
 
     def kernel_resources(self, variant: Optional[Variant] = None, n_streams: int = 1 << 20, n_samples: int = 4096,
-                         as_launched: bool = True) -> dict:
+                         as_launched: bool = True, tile_streams: int = 0) -> dict:
         """registers / LDS / scratch bytes per lane of a variant's kernel (JITs it; needs no GPU).  as_launched: with the
         unroll lowered until nothing spills, as run_block does ('unroll' = what runs); False: the variant exactly as given."""
         vp = ctypes.byref(variant) if variant is not None else None
         r = C.KernelResources()
-        C.check(C.lib.fz_program_kernel_resources(self._h, vp, int(n_streams), int(n_samples), int(as_launched), ctypes.byref(r)))
+        C.check(C.lib.fz_program_kernel_resources(self._h, vp, int(n_streams), int(n_samples), int(tile_streams), int(as_launched), ctypes.byref(r)))
         return {n: getattr(r, n) for n, _ in C.KernelResources._fields_}
 
     # -- the hot path ----------------------------------------------------------------------

@@ -224,3 +224,9 @@ BASELINE_GRAPHS = {
     "par4_sum_fanout": par4_sum_fanout,
     "osc_chain6": lambda: osc_chain(6),
 }
+
+
+# Stream-major frames ([stream][t][wire], the reference's calling convention): kernel variants (P, U, block, flags without
+# FZ_VF_STREAM_MAJOR) a caller may want to measure -- the library default, the long-run body with and without stage packing,
+# short chunks.  fz_program_tune measures frame layouts only; bench.py's stream-major leg times these (build() pre-builds them).
+SM_CANDIDATES = [(0, 0, 0, 0), (1, 128, 0, 256), (1, 128, 0, 256 | 16), (1, 32, 0, 512 | 16), (0, 0, 0, 512)]
