@@ -77,6 +77,23 @@ def test_cross_wire_vs_x_wire(drive):
     assert np.array_equal(y[:, 0, 1].view(np.uint32), bits(REF["outputs"][drive]["xwire1"]).view(np.uint32))
 
 
+MODEL = json.load(open(os.path.join(HERE, "golden", "model_derived_vectors.json")))
+
+
+@pytest.mark.parametrize("name", ["one_quad", "cross_wire_output1"])
+def test_model_derived_vectors(name):
+    """dirac responses computed by the survey's own model of flowz.hpp -- an independent reading of the
+    evaluator, NOT reference output (the fixture says so).  one_quad and nested feedback have no reference-built vector at all."""
+    want = np.array([float.fromhex(h) for h in MODEL[name]["h_hexfloat"]], np.float32)
+    x = np.zeros((len(want), 1, 1), np.float32)
+    x[0] = 1.0
+    if name == "one_quad":
+        got = O.compile(G.one_quad()).run(x)[:, 0, 0]
+    else:
+        got = O.compile(G.cross_wire()).run(x)[:, 0, 1]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (got, want)
+
+
 def test_dirac_sums_like_sum_dirac():
     for form in ("df1", "df2", "df1t"):
         y = O.compile(FORMS[form]()).run(bits(REF["inputs"]["dirac"])[:, None])[:, 0, 0]

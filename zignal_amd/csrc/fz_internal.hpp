@@ -53,12 +53,22 @@ namespace fz {
 struct PackedLine {
    std::vector<uint32_t> srcs;   // per segment: the source node of this delay line
    uint32_t depth;
+   uint32_t frame = 0;           // the sub-atom in whose time frame this copy of the line lives (its readers' sub-atom)
 };
 struct StageSplit {
    bool ok = false;
    uint32_t K = 0;                                  // number of segments (even)
    std::vector<uint32_t> cuts;                      // c_0 = input node ... c_K = output node
    std::vector<std::vector<uint32_t>> tuples;       // per node of segment 0: its partner in every segment, evaluation order
+   // Sub-atoms (round 3): every segment is itself cut at m - 1 internal wires into m ATOMS in series (a DF1 biquad: its
+   // feed-forward sum and its recursion), and atom a of segment j runs at time t - (j * m + a).  The atoms of a step are then
+   // independent of each other: twice the instruction-level parallelism, dependent chains half as long -- what a wave that
+   // carries a single packed pair of segments (the parts of a wave split) needs to stop waiting for its own results.
+   // The packed value of an internal cut travels to the next atom through a carry register, one step later.
+   uint32_t m = 1;                                  // atoms per segment
+   std::vector<uint32_t> sub;                       // per tuple: its atom (0 .. m-1); leaves (constants, parameters): the reader's
+   std::vector<std::vector<uint32_t>> icuts;        // icuts[a-1]: the tuple whose value crosses from atom a-1 into atom a (a = 1 .. m-1)
+   uint32_t atoms() const { return K * m; }         // skewed units in series = masked steps at either end of a block + 1
    std::vector<PackedLine> lines;
    std::vector<uint32_t> prefix;                    // scalar prefix (nodes cuts[0] depends on), evaluation order
    std::vector<uint32_t> prefix_lines;              // delay lines private to the prefix (indices into Graph::lines)
@@ -123,7 +133,8 @@ struct Graph {
    const std::vector<Graph>* wave_roles(uint32_t W) const { return W && W < wave_splits.size() && wave_splits[W].size() == W ? &wave_splits[W] : nullptr; }
 };
 
-StageSplit find_stage_split(const Graph& g, bool plain = false, uint32_t divisor = 0);
+// max_atoms: upper bound for K * m (the wave-split hand-offs and the long-run stream-major body bound the total skew)
+StageSplit find_stage_split(const Graph& g, bool plain = false, uint32_t divisor = 0, uint32_t max_atoms = 13);
 std::vector<Graph> find_wave_roles(const Graph& g, uint32_t W);   // fz_split.cpp; {} or W graphs
 // number of waves per stream tuple a variant asks for (flags bits 10..11: 1024 -> 2, 2048 -> 3, 3072 -> 4), 0 = no wave split
 inline uint32_t wave_split_of(uint32_t flags) { const uint32_t b = (flags >> 10) & 3u; return b ? b + 1 : 0; }

@@ -665,7 +665,8 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
    if (g.split.ok && g.n_in == 1 && g.n_out == 1 && !g.typed && !g.n_lds_slots && g.far_lines.empty()) {
       Graph whole = g;                                   // one part: the compute wave next to an I/O wave (FZ_VF_IO_WAVE)
       whole.wave_splits.clear();
-      g.wave_splits[1] = {whole};
+      if (whole.split.atoms() > 9) whole.split = find_stage_split(whole, false, 0, 9);   // (a hand-off spans at most 8 samples of lag)
+      if (whole.split.ok) g.wave_splits[1] = {whole};
    }
    return g;
 }

@@ -53,7 +53,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       {  // the rings of a workgroup must fit the CU's LDS: tuples x hand-offs x ring x 1 KiB (the kernel sizes every ring of a
          // tuple for the widest hand-off: U groups behind a part that lags by more than 4 samples, else U / 2)
          uint32_t kmax = 0;
-         for (const Graph& r : *g.wave_roles(W)) kmax = std::max(kmax, r.split.K);
+         for (const Graph& r : *g.wave_roles(W)) kmax = std::max(kmax, r.split.atoms());
          const uint32_t ring = (kmax - 1 > 4 ? v.U : v.U / 2), nring = W - 1 + 2 * ws_io(v.flags);
          while ((uint64_t)(v.block / 64) * nring * ring * 1024 > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
          if ((uint64_t)(v.block / 64) * nring * ring * 1024 > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "wave split: the hand-off rings do not fit the LDS with this unroll and block size");
@@ -124,7 +124,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       if (!g.split.ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_STAGE_PACK: the graph is not a series of isomorphic segments");
       if (v.P != 1) fail(FZ_E_INVALID, "FZ_VF_STAGE_PACK needs streams_per_lane == 1");
    } else if (!reqP && v.P == 1 && g.split.ok && !(v.flags & FZ_VF_NO_STAGE_PACK) &&
-              n_samples >= 32u * (g.split.K - 1)) {
+              n_samples >= 16u * (g.split.atoms() - 1)) {
       // automatic below 2^18 streams, unless the block is so short that the K-1 masked steps at
       // either end would dominate
       v.flags |= FZ_VF_STAGE_PACK;
@@ -146,10 +146,10 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // (automatic only for graphs deep enough to be VALU-bound with one stream per lane: packing takes the in-runs of
       //  the long-run body off the 512-byte grid, which costs ~10 % of the read rate -- measured: a 2-stage cascade runs
       //  5.3-5.9 TB/s unpacked against 4.6-5.5 packed, a 6-stage one 4.6 against 5.3)
-      else if (!(uv && (uv->flags & FZ_VF_NO_STAGE_PACK)) && n_samples >= 32u * (g.split.K - 1) && g.n_ops > 27) v.flags |= FZ_VF_STAGE_PACK;
+      else if (!(uv && (uv->flags & FZ_VF_NO_STAGE_PACK)) && n_samples >= 16u * (g.split.atoms() - 1) && g.n_ops > 27) v.flags |= FZ_VF_STAGE_PACK;
       const uint32_t nw = std::max<uint32_t>(std::max(g.n_in, g.n_out), 1);
       // long-run body (512-byte runs per stream): 1-in/1-out graphs with register-resident state, blocks of at least two phases
-      const bool long_ok = g.n_in == 1 && g.n_out == 1 && v.P == 1 && g.n_lds_slots == 0 && (!g.split.ok || g.split.K <= 8);
+      const bool long_ok = g.n_in == 1 && g.n_out == 1 && v.P == 1 && g.n_lds_slots == 0 && (!g.split.ok || g.split.atoms() <= 13);
       const bool want_short = uv && (uv->flags & FZ_VF_SM_SHORT);
       v.flags &= ~(uint32_t)FZ_VF_SM_SHORT;
       if (v.flags & FZ_VF_SM_LONG) {
@@ -162,7 +162,9 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
          v.U = reqU ? reqU : 128;
          // stage packing rides along when the block is long enough for the masked ends not to matter
          if ((v.flags & FZ_VF_STAGE_PACK) && !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
-         auto lds_long = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (w.U + 12) * 4; };
+         // (patch rows: the lag of the in-run (the skew rounded up to whole float4) + the run + one group of slack, stride 4 mod 8 floats)
+         const uint32_t lag = (v.flags & FZ_VF_STAGE_PACK) ? (g.split.atoms() - 1 + 3) / 4 * 4 : 0;
+         auto lds_long = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (w.U + (lag <= 8 ? 12 : 20)) * 4; };
          while (lds_long(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
          if (lds_long(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: the LDS patches do not fit this block size");
          return v;
@@ -174,7 +176,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
          v.U = 32;
          while (v.U > 4 && lds(v) > kMaxLdsBytes) v.U /= 2;
       }
-      if ((v.flags & FZ_VF_STAGE_PACK) && v.U <= g.split.K - 1) {
+      if ((v.flags & FZ_VF_STAGE_PACK) && v.U <= g.split.atoms() - 1) {
          if (uv && (uv->flags & FZ_VF_STAGE_PACK)) fail(FZ_E_INVALID, "stage-packed stream-major frames need unroll > number of segments - 1");
          v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
       }

@@ -15,6 +15,7 @@
 // (segment j+1 consumes the value segment j produced one step earlier), which is a re-timing of
 // the reference's left-then-right evaluation inside one call (sequence, flowz.hpp:960-1001).
 #include <algorithm>
+#include <cmath>
 #include <map>
 #include <set>
 
@@ -91,7 +92,7 @@ struct Matcher {
 
 // plain: the chain runs from the graph input to the graph output (no scalar prefix / suffix); divisor: only segment counts
 // that are multiples of it (both for the wave split, which cuts the chain itself into parts)
-StageSplit find_stage_split(const Graph& g, bool plain, uint32_t divisor)
+StageSplit find_stage_split(const Graph& g, bool plain, uint32_t divisor, uint32_t max_atoms)
 {
    StageSplit none;
    if (g.n_in != 1 || g.n_out != 1 || g.n_lds_slots != 0 || !g.far_lines.empty() || g.n_ops < 2) return none;
@@ -221,22 +222,106 @@ StageSplit find_stage_split(const Graph& g, bool plain, uint32_t divisor)
          if (ax != ay) return !ax;
          return ax ? x[0] < y[0] : false;
       });
-      std::map<Tuple, uint32_t> line_depth;                // tuple of line sources -> depth
-      for (auto& t : s.tuples)
-         if (g.nodes[t[0]].kind == FZ_IR_DELAY) {
-            Tuple src(K);
-            for (uint32_t j = 0; j < K; ++j) src[j] = g.nodes[t[j]].a;
-            line_depth[src] = std::max(line_depth[src], g.nodes[t[0]].b);
+      // ---- sub-atoms: internal single-wire cuts of the segment (checked on segment 0; the others are isomorphic to it) ----
+      // A wire v of the segment is a cut when the rest of the segment sees what v depends on only through v itself, now or
+      // delayed, and does not look at the segment's input wire any more.  Nested cuts compose (each later atom reads the
+      // earlier ones only through the cut in front of it).  Wanted: atoms of 4-5 operations (a biquad: feed-forward sum |
+      // recursion), at most max_atoms skewed units in all.
+      {
+         auto in0 = [&](uint32_t u) { return is_arith(g.nodes[u].kind) && seg_of[u] == 0; };
+         auto ops0 = [&](uint32_t v) {
+            uint32_t n = 0;
+            for (uint32_t u = 0; u < N; ++u) n += in0(u) && closure[v][u];
+            return n;
+         };
+         auto valid_cut = [&](uint32_t v) {
+            for (uint32_t n = 0; n < N; ++n) {
+               if (!in0(n) || closure[v][n]) continue;        // n: a node of the segment behind the cut
+               const Node& nd = g.nodes[n];
+               auto fine = [&](uint32_t o) {
+                  const Node& on = g.nodes[o];
+                  if (on.kind == FZ_IR_CONST || on.kind == FZ_IR_PARAM) return true;
+                  if (o == cuts[0] || on.kind == FZ_IR_INPUT) return false;            // the segment's input: only the first atom reads it
+                  if (on.kind == FZ_IR_DELAY) {
+                     if (on.a == cuts[0]) return false;
+                     if (in0(on.a) && closure[v][on.a]) return on.a == v;              // a delayed read of the cut wire itself
+                     return true;
+                  }
+                  if (in0(o) && closure[v][o]) return o == v;
+                  return true;
+               };
+               if (!fine(nd.a) || (nd.kind != FZ_IR_NEG && !fine(nd.b))) return false;
+            }
+            return true;
+         };
+         uint32_t m = unit >= 8 ? (unit >= 18 ? 3u : 2u) : 1u;
+         while (m > 1 && K * m > max_atoms) --m;
+         std::vector<std::pair<uint32_t, uint32_t>> cand;    // (operations of the segment up to and including v, v)
+         if (m > 1)
+            for (uint32_t v = 0; v < N; ++v)
+               if (in0(v) && v != cuts[1] && valid_cut(v)) cand.push_back({ops0(v), v});
+         std::sort(cand.begin(), cand.end());
+         std::vector<uint32_t> chosen;
+         for (; m > 1 && chosen.empty(); --m) {
+            uint32_t prev = N;
+            for (uint32_t a = 1; a < m; ++a) {
+               const double want = (double)unit * a / m;
+               uint32_t best = N;
+               double bd = 1e9;
+               for (auto& c : cand) {
+                  if (c.first == 0 || c.first >= unit) continue;
+                  if (prev != N && (!closure[c.second][prev] || c.second == prev)) continue;   // nested behind the previous cut
+                  const double d = std::abs((double)c.first - want);
+                  if (d < bd) { bd = d; best = c.second; }
+               }
+               if (best == N || bd > (double)unit / (2.0 * m)) { chosen.clear(); break; }
+               chosen.push_back(best);
+               prev = best;
+            }
+            if (!chosen.empty()) { ++m; break; }              // (undo the loop's decrement: this m worked)
          }
+         s.m = chosen.empty() ? 1u : (uint32_t)chosen.size() + 1u;
+         // the atom of every tuple: how many of the chosen cuts lie strictly in front of its segment-0 node
+         s.sub.assign(s.tuples.size(), 0);
+         for (size_t k = 0; k < s.tuples.size(); ++k) {
+            const uint32_t u = s.tuples[k][0];
+            if (!is_arith(g.nodes[u].kind) || u == cuts[0]) continue;
+            uint32_t a = 0;
+            for (uint32_t c : chosen) a += !closure[c][u];
+            s.sub[k] = a;
+         }
+         s.icuts.clear();
+         for (uint32_t c : chosen)
+            for (auto& t : s.tuples)
+               if (t[0] == c) s.icuts.push_back(t);
+         if (s.icuts.size() != chosen.size()) { s.m = 1; s.icuts.clear(); std::fill(s.sub.begin(), s.sub.end(), 0u); }
+      }
+      // delay lines: one copy per (source tuple, atom that reads it) -- an atom sees a wire's past in its own time frame
+      std::map<Tuple, size_t> tix;
+      for (size_t k = 0; k < s.tuples.size(); ++k) tix[s.tuples[k]] = k;
+      std::map<std::pair<Tuple, uint32_t>, uint32_t> line_depth;   // (tuple of line sources, frame) -> depth
+      for (size_t k = 0; k < s.tuples.size(); ++k) {
+         const auto& t = s.tuples[k];
+         if (!is_arith(g.nodes[t[0]].kind) || t[0] == cuts[0]) continue;
+         for (int side = 0; side < (g.nodes[t[0]].kind == FZ_IR_NEG ? 1 : 2); ++side) {
+            Tuple o(K);
+            for (uint32_t j = 0; j < K; ++j) o[j] = side ? g.nodes[t[j]].b : g.nodes[t[j]].a;
+            if (g.nodes[o[0]].kind != FZ_IR_DELAY) continue;
+            Tuple src(K);
+            for (uint32_t j = 0; j < K; ++j) src[j] = g.nodes[o[j]].a;
+            auto key = std::make_pair(src, s.sub[k]);
+            line_depth[key] = std::max(line_depth[key], g.nodes[o[0]].b);
+         }
+      }
       std::set<uint32_t> covered;
       for (auto& kv : line_depth) {
          PackedLine pl;
-         pl.srcs = kv.first;
-         pl.depth = 0;
+         pl.srcs = kv.first.first;
+         pl.frame = kv.first.second;
+         pl.depth = kv.second;
          for (uint32_t j = 0; j < K && s.ok; ++j) {
             const int l = g.line_of_node[pl.srcs[j]];
             if (l < 0) { s.ok = false; break; }
-            pl.depth = std::max(pl.depth, g.lines[(size_t)l].depth);
             covered.insert(pl.srcs[j]);
          }
          if (pl.depth > kRegMaxDepth) s.ok = false;
@@ -375,7 +460,7 @@ static bool extract_part(const Graph& g, const std::vector<char>* before, const 
       r.max_delay = std::max(r.max_delay, l.depth);
    }
    r.n_state = g.n_state;
-   r.split = find_stage_split(r);
+   r.split = find_stage_split(r, false, 0, 9);            // (a hand-off spans at most 8 samples of lag: at most 9 skewed units per part)
    return r.split.ok;
 }
 
