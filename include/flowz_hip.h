@@ -257,9 +257,6 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
  * on the board -- let fz_program_tune measure it                                                   */
 #define FZ_VF_MAX_WG(n) (((uint32_t)(n) & 7u) << 20)
 /* bits 12..14 / 16..18: cache policy of frame loads / stores (experiment knob, see the kernel source) */
-/* bits 24..26 of flags (plain frame kernel): one wave per chunk reads one dword of the input and of the output row 2 << n rows
- * ahead, so that the CU knows the rows' pages when their turn comes (plain time-major frames: every row is another page)     */
-#define FZ_VF_TOUCH(n) (((uint32_t)(n) & 7u) << 24)
 
 int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */
 /* the same with the variant's automatic fields resolved as a launch of this block shape would: the shape of a launch is

@@ -1308,15 +1308,20 @@ def test_stream_major_stage_packed_kernel_vs_oracle(torch_cuda, F, name, T):
         want = O.compile(g, ns).run(x)                                   # [T, ns, 1]
         xs = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))).cuda()
         _, st_ref = prog.run_block(torch.from_numpy(x).cuda(), variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+        skew = int(prog.source(F.make_variant(1, 16, 256, STAGE_PACK)).split("#define FZ_SKEW ")[1].split()[0])   # skewed units - 1
         for U in (8, 16, 32):
             v = F.make_variant(1, U, 0, STAGE_PACK)
+            if U <= skew:                                                    # a chunk must be longer than the skew (6 biquads = 12 atoms: 11)
+                with pytest.raises(F.FlowzError):
+                    prog.run_block_stream_major(xs, variant=v)
+                continue
             assert prog.kernel_name(F.make_variant(1, U, 0, STAGE_PACK | 128), ns, T).endswith("f136")          # ...s<K>f136: packed + stream-major
             y, st = prog.run_block_stream_major(xs, variant=v)
             assert ndiff(y.permute(1, 0, 2).contiguous().cpu().numpy(), want) == 0, (ns, T, U)
             assert torch.equal(st, st_ref), (ns, T, U)
         if T >= 36:                                                        # two windows, state carried, mixed bodies
             out = torch.zeros_like(y)
-            _, st2 = prog.run_block_stream_major(xs, out=out, n_samples=20, variant=F.make_variant(1, 8, 0, STAGE_PACK))
+            _, st2 = prog.run_block_stream_major(xs, out=out, n_samples=20, variant=F.make_variant(1, 8 if skew < 8 else 16, 0, STAGE_PACK))
             prog.run_block_stream_major(xs, out=out, state=st2, row0=20, variant=F.make_variant(1, 16, 0, NO_STAGE_PACK))
             assert torch.equal(out, y), (ns, T)
             out.zero_()

@@ -36,10 +36,6 @@ def FZ_VF_WAVES(n):
     return (n - 1) << 10 if 2 <= n <= 4 else 0
 
 
-def FZ_VF_TOUCH(n):
-    return (int(n) & 7) << 24
-
-
 def FZ_VF_MAX_WG(n):
     """at most n workgroups per CU (flags bits 20..22)"""
     return (int(n) & 7) << 20

@@ -214,8 +214,9 @@ struct fz_program {
 
 namespace fz {
 // the library's choice for a block shape; tile_streams 0 = plain time-major rows (stream-major frames: FZ_VF_STREAM_MAJOR in v->flags)
+// allow_lockstep: the most streams per lane the CU-wide lockstep workgroups of plain time-major frames may use (0: not chosen at all)
 Variant resolve_variant(const Graph& g, const fz_variant* v, uint64_t n_streams, uint32_t n_samples = 1u << 20, uint32_t tile_streams = 0,
-                        bool allow_lockstep = true);
+                        uint32_t allow_lockstep = 4);
 // the kernel a launch of that shape runs: resolved, fitted to the tile / the 4 GiB chunk limit, unroll lowered until nothing spills
 Variant finalize_variant(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, bool settle = true);
 // builds (or fetches from the caches) the kernel of variant v; fn_out != null: also load it on the

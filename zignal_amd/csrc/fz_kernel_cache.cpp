@@ -69,6 +69,15 @@ static std::vector<const char*> build_options(const Variant& v)
    std::vector<const char*> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                  "-fhip-fp32-correctly-rounded-divide-sqrt"};
    if (!(v.flags & FZ_VF_SLP)) o.push_back("-fno-slp-vectorize");
+   // The parts of a wave split carry ONE or two packed pairs of segments: so little instruction-level parallelism that the default
+   // scheduler (which orders for occupancy) leaves dependent v_pk_mul / v_pk_add back to back -- two s_nop per step in the ISA on
+   // top of the wait.  The max-ILP strategy interleaves the atoms: 411 instead of 477 instructions per round of 32 steps, no
+   // s_nop; measured +9 % at 16 384 streams and +1-4 % at 32 768 with rounds of 32 steps (profiles/r03/sweep_sched_strategy.txt).
+   // Rounds of 16 steps next to an I/O wave LOSE 15-20 % with it, and the single-wave kernels (three pairs: enough ILP) 0-4 %.
+   if (ws_parts(v.flags) >= 2 && v.U == 32) {
+      o.push_back("-mllvm");
+      o.push_back("-amdgpu-sched-strategy=max-ilp");
+   }
    // developer hook (kernel experiments: -DFZ_DBG_NOLOAD ... and compiler flags); part of the cache key like every option
    static const std::vector<std::string> extra = [] {
       std::vector<std::string> e;

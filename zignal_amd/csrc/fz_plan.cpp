@@ -18,7 +18,7 @@ constexpr uint64_t kMaxLdsBytes = 160 * 1024;
 
 // tile_streams: the frame layout the variant is for -- 0 (or >= n_streams) plain time-major rows, else stream tiles (stream-major
 // frames are named by FZ_VF_STREAM_MAJOR in the variant's flags).  allow_lockstep: see the time-major rule below.
-Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, bool allow_lockstep)
+Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, uint32_t allow_lockstep)
 {
    if (tile_streams >= n_streams) tile_streams = 0;
    Variant v;
@@ -202,14 +202,18 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    // and a graph whose registers fit the 128 a lane of a 1024-lane workgroup gets (fz_finalize_variant falls back otherwise).
    if (allow_lockstep && plain_auto && !tile_streams && n_streams >= (1u << 18) && g.n_in <= 2 && g.n_out <= 2 && g.far_lines.empty() &&
        g.n_lds_slots == 0 && !(v.flags & FZ_VF_STAGE_PACK)) {
-      const uint32_t P = (n_streams >= (1u << 19) && n_streams % 2 == 0 && (reg_state + g.n_param) * 2 <= 40) ? 2 : 1;
-      if ((reg_state + g.n_param) * P <= 48) {
-         v.P = P;
-         v.U = P == 2 ? 2 : 8;
-         v.block = 1024;
-         v.flags |= FZ_VF_LOCKSTEP;
-         return v;
-      }
+      // streams per lane: as many as still give 256 workgroups (a CU's piece of a row: 16 / 8 / 4 KiB), fewer rows in flight
+      // the wider the lane -- four streams per lane: one row per buffer and three buffers (the loads run two rows ahead):
+      // 0.72 / 0.69 of peak against 0.71 / 0.64 for two streams per lane on the two boards that ran both.  allow_lockstep
+      // caps the packing: fz_finalize_variant steps down when the kernel does not fit the 128 registers of a lane.
+      uint32_t P = (n_streams >= (1u << 20) && n_streams % 4 == 0) ? 4 : (n_streams >= (1u << 19) && n_streams % 2 == 0) ? 2 : 1;
+      P = std::min(P, allow_lockstep >= 3 ? 4u : allow_lockstep);
+      if (P == 3) P = 2;
+      v.P = P;
+      v.U = P == 4 ? 1 : P == 2 ? 2 : 8;
+      v.block = 1024;
+      v.flags |= FZ_VF_LOCKSTEP | (P == 4 ? (uint32_t)FZ_VF_PREFETCH3 : 0u);
+      return v;
    }
    // stream-tiled frames, packed lanes, chip oversubscribed: two workgroups per CU (262 144 streams in flight keep fewer tiles
    // open in DRAM: +2 % on the boards of round 3, level on those of round 2; profiles/r01/sweep_occupancy_cap.txt)
@@ -260,9 +264,17 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
    Variant v = fit(want);
    if (settle && (v.flags & FZ_VF_LOCKSTEP) && !(uv && (uv->flags & FZ_VF_LOCKSTEP))) {
       // the library's own lockstep choice needs its kernel in the 128 registers of a 1024-lane workgroup with the rows in flight
-      // it was chosen for; a graph that does not fit runs the ordinary four-wave workgroups
-      const auto k = get_kernel(p, v, nullptr);
-      if (k->res.scratch_bytes != 0 || v.U < want.U) v = fit(resolve_variant(g, uv, n_streams, n_samples, tile_streams, false));
+      // it was chosen for: step down the streams per lane until it fits; a graph that never does runs the ordinary four-wave
+      // workgroups (level 0)
+      Variant w = want;
+      for (uint32_t level = want.P; level > 0;) {
+         const auto k = get_kernel(p, v, nullptr);
+         if (k->res.scratch_bytes == 0 && v.U >= w.U) break;
+         level = level == 4 ? 2 : level - 1;
+         w = resolve_variant(g, uv, n_streams, n_samples, tile_streams, level);
+         v = fit(w);
+         if (!(v.flags & FZ_VF_LOCKSTEP)) break;
+      }
    }
    return v;
 }
@@ -395,12 +407,13 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
       cands.push_back(fz_variant{1, 24, 0, FZ_VF_STAGE_PACK});
       cands.push_back(fz_variant{1, 32, 0, FZ_VF_STAGE_PACK});
    } else if (d.flags & FZ_VF_LOCKSTEP) {   // plain time-major frames, many streams: the CU-wide workgroups in lockstep against four-wave workgroups running free
-      cands.push_back(fz_variant{d.P, 16, 256, 0});
-      cands.push_back(fz_variant{d.P, d.P == 2 ? 4u : 4u, 1024, FZ_VF_LOCKSTEP});
-      if (d.P == 2) cands.push_back(fz_variant{1, 8, 1024, FZ_VF_LOCKSTEP});
-      if (d.P == 2) cands.push_back(fz_variant{4, 8, 512, FZ_VF_LOCKSTEP});
-      if (d.P == 2) cands.push_back(fz_variant{4, 8, 256, 0});
+      cands.push_back(fz_variant{std::min(d.P, 2u), 16, 256, 0});
+      if (d.P == 4) cands.push_back(fz_variant{2, 2, 1024, FZ_VF_LOCKSTEP});
+      if (d.P >= 2) cands.push_back(fz_variant{2, 8, 1024, FZ_VF_LOCKSTEP});
+      if (d.P >= 2) cands.push_back(fz_variant{4, 8, 512, FZ_VF_LOCKSTEP});
+      if (d.P >= 2) cands.push_back(fz_variant{1, 8, 1024, FZ_VF_LOCKSTEP});
       if (d.P == 1) cands.push_back(fz_variant{1, 16, 1024, FZ_VF_LOCKSTEP});
+      if (d.P == 1) cands.push_back(fz_variant{1, 4, 1024, FZ_VF_LOCKSTEP});
    } else if (d.P == 2) {            // many streams, narrow frames: lane packing x prefetch depth x workgroups per CU
       cands.push_back(fz_variant{2, 16, 256, (d.flags & FZ_VF_MAX_WG(7)) ? 0u : FZ_VF_MAX_WG(2)});
       cands.push_back(fz_variant{2, 32, 256, 0});

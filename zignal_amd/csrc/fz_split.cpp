@@ -314,6 +314,8 @@ StageSplit find_stage_split(const Graph& g, bool plain, uint32_t divisor, uint32
          }
       }
       std::set<uint32_t> covered;
+      std::map<Tuple, uint32_t> last_frame;                // per source tuple: its copy in the latest atom's frame
+      for (auto& kv : line_depth) last_frame[kv.first.first] = std::max(last_frame[kv.first.first], kv.first.second);
       for (auto& kv : line_depth) {
          PackedLine pl;
          pl.srcs = kv.first.first;
@@ -322,6 +324,9 @@ StageSplit find_stage_split(const Graph& g, bool plain, uint32_t divisor, uint32
          for (uint32_t j = 0; j < K && s.ok; ++j) {
             const int l = g.line_of_node[pl.srcs[j]];
             if (l < 0) { s.ok = false; break; }
+            // one copy per wire keeps the line's FULL depth (a scalar prefix / suffix may read further back than the chain does,
+            // and the state buffer wants every row): the copy of the latest atom, which is where those parts look
+            if (pl.frame == last_frame[pl.srcs]) pl.depth = std::max(pl.depth, g.lines[(size_t)l].depth);
             covered.insert(pl.srcs[j]);
          }
          if (pl.depth > kRegMaxDepth) s.ok = false;
