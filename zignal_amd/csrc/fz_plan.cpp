@@ -463,6 +463,9 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
       const size_t c = warmup ? 0 : cc - 1;
       try {
          if (implicit && c != 0 && !kernel_at_hand(p, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams, false))) continue;
+         // (a candidate that would run from scratch memory even with its unroll lowered -- a 1024-lane lockstep workgroup of a
+         //  register-heavy graph -- is not measured: no kernel of this library runs from scratch, see DESIGN "Register budget")
+         if (c != 0 && get_kernel(p, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams), nullptr)->res.scratch_bytes != 0) continue;
          launch(p, in, out, state, params, n_streams, n_samples, &cands[c], stream, tile_streams);   // build, load, first touch
          // one launch to size the measurement (>= ~25 ms of kernel time: sub-millisecond kernels need
          // dozens of launches before their timing settles), then the measurement proper
