@@ -509,7 +509,8 @@ def main():
             q = v or (0, 0, 0, 0)
             k = prog.kernel_name(F.make_variant(q[0], q[1], q[2], q[3] | SMF), ns, T)
             return {"kernel": k, "avg_launch_ms": round(ms, 4), "Msamples_per_s": round(ns * T / ms / 1e3, 1),
-                    "achieved_GBs": round(b / ms / 1e6, 1), "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                    "achieved_GBs": round(b / ms / 1e6, 1), "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4),
+                    "traffic": traffic_of(k, f"cascade6_{ns}x{T}_streammajor")}
 
         res = {"library_default": one(None)}
         best_v = None

@@ -1515,7 +1515,9 @@ def test_tuned_plan_is_persisted_per_graph_shape_and_board(torch_cuda, F, tmp_pa
     assert (v0.streams_per_lane, v0.unroll, v0.block_threads, v0.flags) == (0, 0, 0, 0)
     chosen, _ = p1.tune(x)
     lines = (tmp_path / "plans.txt").read_text().splitlines()
-    assert len(lines) == 1 and lines[0].split()[1:3] == [str(ns), "0"]
+    f = lines[0].split()                                   # "<format tag> <graph hash> <n_streams> <tile> <board> <P> <U> <block> <flags> <ms> <n_samples>"
+    assert len(lines) == 1 and f[0] == "fzplan3" and f[2:4] == [str(ns), "0"] and f[-1] == str(T)
+    (tmp_path / "plans.txt").write_text("0123456789abcdef 131072 0 deadbeef 2 8 256 0 0.1\n" + lines[0] + "\n")   # a line of an older format is not ours to read
     p2 = F.compile(F.from_sexpr(G.df1_cascade(2, [G.PAR4_SETS[0], G.PAR4_SETS[1]])))        # same structure, other coefficients
     got = p2.plan(ns)
     assert (got.streams_per_lane, got.unroll, got.block_threads, got.flags) == (chosen.streams_per_lane, chosen.unroll, chosen.block_threads, chosen.flags)
