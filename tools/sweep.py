@@ -63,7 +63,7 @@ def main():
     for s, v in vs:                              # warm (JIT + first touch); a variant the graph / shape refuses is reported and skipped
         try:
             prog.run_block(x, state=state, params=params, out=y, variant=v)
-            ok.append((s + " " + prog.kernel_name(v, ns, T).replace("fz_block_kernel_", ""), v))
+            ok.append((s + " " + prog.kernel_name(v if v is not None else prog.plan(ns, a.tile), ns, T, a.tile).replace("fz_block_kernel_", ""), v))
         except F.FlowzError as e:
             print(f"# {s}: refused: {str(e)[:120]}")
     vs = ok

@@ -159,12 +159,14 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
          v.flags |= FZ_VF_SM_LONG;
       }
       if (v.flags & FZ_VF_SM_LONG) {
-         v.U = reqU ? reqU : 128;
+         // 512-byte runs per stream from 2048 samples on; shorter blocks do better with 256-byte runs (64-sample phases: patches of
+         // 19 KB per wave, two workgroups per CU, half the pipeline fill) -- 1 M streams x 1024: 1.78 ms against 1.92 ms; x 4096: 6.97
+         // against 6.65 ms (gpurun_out/r03j -> profiles/r03/stream_major_kernel.txt)
+         v.U = reqU ? reqU : (n_samples >= 2048 ? 128 : 64);
          // stage packing rides along when the block is long enough for the masked ends not to matter
          if ((v.flags & FZ_VF_STAGE_PACK) && !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
-         // (patch rows: the lag of the in-run (the skew rounded up to whole float4) + the run + one group of slack, stride 4 mod 8 floats)
-         const uint32_t lag = (v.flags & FZ_VF_STAGE_PACK) ? (g.split.atoms() - 1 + 3) / 4 * 4 : 0;
-         auto lds_long = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (w.U + (lag <= 8 ? 12 : 20)) * 4; };
+         // (patch rows: the lag of the in-run -- the skew rounded up to whole float4, at most 12 -- + the run, stride 4 mod 8 floats)
+         auto lds_long = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (w.U + 12) * 4; };
          while (lds_long(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
          if (lds_long(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: the LDS patches do not fit this block size");
          return v;
