@@ -646,7 +646,7 @@ def test_stage_pack_is_automatic_for_few_streams_and_rejected_when_impossible(to
     torch = torch_cuda
     prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
     src = prog.source(F.make_variant(1, 16, 256, STAGE_PACK))
-    assert "#define FZ_SKEW 11" in src and "#define FZ_NSEG 12" in src and "step2" in src     # 6 stages = 6 segments of 2 atoms
+    assert "#define FZ_SKEW 5" in src and "#define FZ_NSEG 6" in src and "step2" in src     # 6 stages = 6 segments (one atom each: only graphs of one or two packed pairs are cut further)
     x = torch.zeros((4, 64, 1), device="cuda")
     with pytest.raises(F.FlowzError):
         F.compile(F.from_sexpr(G.par4_sum_fanout())).run_block(x, variant=F.make_variant(1, 8, 256, STAGE_PACK))
@@ -1336,8 +1336,8 @@ def test_stream_major_stage_packing_is_automatic_for_long_blocks(torch_cuda, F):
     torch = torch_cuda
     prog = F.compile(F.from_sexpr(G.osc_chain(6)))
     ns, T = 4096 + 78, 512
-    assert "s6a2f" in prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, T)
-    assert "s6a2f" not in prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, 100)
+    assert "s6f" in prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, T)
+    assert "s6f" not in prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, 100)
     P = W.osc_chain_params(SEED + 3, np.arange(ns))
     x = np.zeros((T, ns, 1), np.float32)
     x[0] = 1.0
@@ -1402,7 +1402,7 @@ def test_stream_major_long_run_osc_chain_per_stream_coefficients_64k(torch_cuda,
     x[500] = -0.25
     yf, stf = prog.run_block(x, params=pd)
     ys, sts = prog.run_block_stream_major(x.permute(1, 0, 2).contiguous(), params=pd)
-    assert prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, T).endswith("s6a2f392")
+    assert prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, T).endswith("s6f392")
     assert torch.equal(ys.permute(1, 0, 2).contiguous(), yf) and torch.equal(sts, stf)
     ids = _sample_ids(ns, 256, 5)
     xh = np.zeros((T, len(ids), 1), np.float32)

@@ -259,7 +259,7 @@ def test_stage_split_detection_and_packed_kernel_builds(tmp_path, monkeypatch):
         F.compile(F.from_sexpr(G.df1())).build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))
     ps = F.compile(F.from_sexpr(want["osc_cascade_mix"][0]))
     src = ps.source(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))
-    assert "#define FZ_NSEG 12" in src and "6 isomorphic segments" in src   # still six packed segments (of two atoms each), prefix and suffix scalar
+    assert "#define FZ_NSEG 6" in src and "6 isomorphic segments" in src   # still six packed segments (one atom each: three pairs are ILP enough), prefix and suffix scalar
     ps.build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))
 
 
@@ -429,9 +429,9 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
     p = F.compile(F.from_sexpr(G.df1_cascade(6)))
     assert p.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u32b128w2iof33792"          # two compute waves + an I/O wave per 64 streams
     assert p.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w3iof34816"           # 256 workgroups: three compute waves of two biquads each + an I/O wave
-    assert p.kernel_name(None, 65536, 4096).startswith("fz_block_kernel_p1u16b256s6a2f")       # one wave per SIMD already
+    assert p.kernel_name(None, 65536, 4096).startswith("fz_block_kernel_p1u16b256s6f")       # one wave per SIMD already
     assert p.kernel_name(F.make_variant(0, 0, 0, F.C.FZ_VF_IO_WAVE), 65536, 4096) == "fz_block_kernel_p1u16b256w1iof32768"   # ... or an I/O wave next to it
-    assert p.kernel_name(None, 32768, 200).startswith("fz_block_kernel_p1u16b256s6a2f")        # short blocks: the ends would dominate
+    assert p.kernel_name(None, 32768, 200).startswith("fz_block_kernel_p1u16b256s6f")        # short blocks: the ends would dominate
     assert p.kernel_name(F.make_variant(0, 0, 0, 16), 32768, 4096) == "fz_block_kernel_p1u16b256f0"   # FZ_VF_NO_STAGE_PACK: the plain kernel
     src = p.source(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT))
     assert "namespace fz_r0 {" in src and "namespace fz_r1 {" in src and "#define FZ_WS_K0 4" in src and "#define FZ_WS_K1 4" in src   # (two segments of two atoms per part)

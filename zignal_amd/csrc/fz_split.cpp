@@ -255,6 +255,9 @@ StageSplit find_stage_split(const Graph& g, bool plain, uint32_t divisor, uint32
             return true;
          };
          uint32_t m = unit >= 8 ? (unit >= 18 ? 3u : 2u) : 1u;
+         // three or more packed pairs already give a wave enough independent work; there the atoms would only lengthen the masked
+         // ends of every block (one slow step per skewed unit at either end: ~0.3 us each, 2 % of a 4096-sample block of config 2)
+         if (K >= 6) m = 1;
          while (m > 1 && K * m > max_atoms) --m;
          std::vector<std::pair<uint32_t, uint32_t>> cand;    // (operations of the segment up to and including v, v)
          if (m > 1)
