@@ -1331,13 +1331,13 @@ def test_stream_major_stage_packed_kernel_vs_oracle(torch_cuda, F, name, T):
 
 
 def test_stream_major_stage_packing_is_automatic_for_long_blocks(torch_cuda, F):
-    """From 32 x (K-1) samples on the stream-major kernel picks the stage-packed body by itself (any stream count);
+    """From 16 x (skewed units - 1) samples on the stream-major kernel picks the stage-packed body by itself (any stream count);
     osc -> 6 DF1 with per-stream coefficients (scalar prefix) at a size where every wave of a block is busy."""
     torch = torch_cuda
     prog = F.compile(F.from_sexpr(G.osc_chain(6)))
     ns, T = 4096 + 78, 512
     assert "s6f" in prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, T)
-    assert "s6f" not in prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, 100)
+    assert "s6f" not in prog.kernel_name(F.make_variant(0, 0, 0, 128), ns, 72)
     P = W.osc_chain_params(SEED + 3, np.arange(ns))
     x = np.zeros((T, ns, 1), np.float32)
     x[0] = 1.0
@@ -1472,6 +1472,65 @@ def test_sample_rate_modulators_through_the_chunked_host_paths(torch_cuda, F):
     prog.set_modulation(md[:, :T - 8].contiguous())       # an array shorter than the block: refused by the chunk that would overrun it
     with pytest.raises(F.FlowzError):
         prog.bank(ns).process_host(xd.cpu().numpy())
+
+
+@pytest.mark.parametrize("name", ["cascade2", "cross_wire", "osc_chain"])
+def test_time_major_lockstep_workgroups_vs_oracle(torch_cuda, F, name):
+    """FZ_VF_LOCKSTEP (round 3): CU-wide workgroups of 1024 lanes that meet at a barrier after every chunk -- the library's
+    choice for plain time-major frames of many streams.  Ragged stream counts (a last workgroup with lanes AND whole waves
+    missing: waves that have left do not count at the barrier), block lengths around the chunk sizes, three buffers, every
+    lane packing; 0 ULP against the oracle, state included; blocks chain with the ordinary kernels."""
+    torch = torch_cuda
+    from zignal_amd import _capi
+    L = _capi.FZ_VF_LOCKSTEP
+    g = {"cascade2": lambda: G.df1_cascade(2), "cross_wire": G.cross_wire, "osc_chain": lambda: G.osc_chain(6)}[name]()
+    prog = F.compile(F.from_sexpr(g))
+    for ns, T in ((1024 * 4 + 260, 37), (3000, 64), (5000, 1), (2048, 130)):
+        x = O.synth_input(SEED + 31, np.arange(ns), T, n_wires=max(prog.n_in, 1))
+        params = W.osc_chain_params(SEED + 32, np.arange(ns)) if prog.n_param else None
+        want = C.osc_chain(params, x) if params is not None else O.compile(g, ns).run(x)
+        got0, st0 = run_gpu(torch, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK), params=params)
+        assert ndiff(got0, want) == 0
+        for v in ((1, 8, 1024, L), (2, 2, 1024, L), (4, 1, 1024, L | _capi.FZ_VF_PREFETCH3), (2, 4, 512, L), (1, 16, 256, L | NO_STAGE_PACK)):
+            if ns % v[0] or prog.kernel_resources(F.make_variant(*v), ns, T)["scratch_bytes"]:
+                continue                                         # (a register-heavy graph does not fit 128 registers per lane: the library never picks that)
+            got, st = run_gpu(torch, F, prog, x, variant=F.make_variant(*v), params=params)
+            assert ndiff(got, want) == 0 and torch.equal(st, st0), (name, ns, T, v)
+        # two blocks, the second one by an ordinary kernel from the lockstep kernel's state
+        if T >= 37 and ns % 2 == 0:
+            xd = torch.from_numpy(x).cuda()
+            pd = torch.from_numpy(params).cuda() if params is not None else None
+            out = torch.zeros((T, ns, prog.n_out), device="cuda")
+            st = torch.zeros((max(prog.n_state, 1), ns), device="cuda")
+            prog.run_window(xd, out, st, 0, 20, params=pd, variant=F.make_variant(2, 2, 1024, L))
+            prog.run_window(xd, out, st, 20, T - 20, params=pd, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+            assert ndiff(out.cpu().numpy(), want) == 0 and torch.equal(st, st0)
+
+
+def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, F, monkeypatch):
+    """Plain time-major frames from 262 144 streams on: the library picks the lockstep workgroups by itself (one, two, four
+    streams per lane as the stream count allows; a register-heavy graph steps down) -- same bits as the four-wave workgroups;
+    tiled frames and 4-wire frames keep theirs."""
+    torch = torch_cuda
+    from zignal_amd import _capi
+    monkeypatch.setenv("FLOWZ_HIP_NO_PLAN_CACHE", "1")
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    assert prog.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p4u1b1024f%d" % (_capi.FZ_VF_LOCKSTEP | _capi.FZ_VF_PREFETCH3)
+    assert prog.kernel_name(None, 1 << 19, 4096, 0) == "fz_block_kernel_p2u2b1024f%d" % _capi.FZ_VF_LOCKSTEP
+    assert prog.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p1u8b1024f%d" % _capi.FZ_VF_LOCKSTEP
+    assert prog.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % _capi.FZ_VF_MAX_WG(2)
+    assert "b1024" not in prog.kernel_name(None, 1 << 17, 4096, 0)
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u8b1024f%d" % _capi.FZ_VF_LOCKSTEP
+    assert F.compile(F.from_sexpr(G.par4_sum())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u32b256f0"
+    ns, T = (1 << 18) + 8, 24                                   # ragged on purpose
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED + 33)
+    y, st = prog.run_block(x)                                   # (too small a block for the first-launch measurement)
+    y0, st0 = prog.run_block(x, variant=F.make_variant(2, 16, 256))
+    assert torch.equal(y, y0) and torch.equal(st, st0)
+    ids = np.array([0, 1, 63, 64, 1023, 1024, ns - 1])
+    want = C.df1_cascade([G.STABLE] * 6, O.synth_input(SEED + 33, ids, T))
+    assert ndiff(y[:, torch.as_tensor(ids, device="cuda")].cpu().numpy(), want) == 0
 
 
 def test_autotune_env_measures_the_plan_on_first_use(torch_cuda):
