@@ -247,6 +247,9 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
        FZ_VF_LOCKSTEP = 524288u, /* time-major / tiled frames: the waves of a workgroup meet at a barrier after every chunk and so walk the
                                    same rows at the same time -- with plain time-major frames of many streams (rows megabytes apart)
                                    that keeps the pages a CU has in flight few; chosen automatically there                        */
+       FZ_VF_GRID_SYNC = 8388608u, /* with FZ_VF_LOCKSTEP: the workgroups of one XCD (one contiguous 1/8 of every row) also walk the rows together:
+                                   arrival counters in device memory (zeroed in stream order before the launch), bounded waits -- never a
+                                   hang, never a different bit; chosen automatically when the chip holds all workgroups at once      */
        FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
                                    float*): the results of graphs with double literals leave un-narrowed, float
                                    wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */

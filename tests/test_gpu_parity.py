@@ -1491,7 +1491,9 @@ def test_time_major_lockstep_workgroups_vs_oracle(torch_cuda, F, name):
         want = C.osc_chain(params, x) if params is not None else O.compile(g, ns).run(x)
         got0, st0 = run_gpu(torch, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK), params=params)
         assert ndiff(got0, want) == 0
-        for v in ((1, 8, 1024, L), (2, 2, 1024, L), (4, 1, 1024, L | _capi.FZ_VF_PREFETCH3), (2, 4, 512, L), (1, 16, 256, L | NO_STAGE_PACK)):
+        GS = _capi.FZ_VF_GRID_SYNC                                   # + the workgroups of an XCD synchronised through counters in memory
+        for v in ((1, 8, 1024, L), (2, 2, 1024, L), (4, 1, 1024, L | _capi.FZ_VF_PREFETCH3), (2, 4, 512, L), (1, 16, 256, L | NO_STAGE_PACK),
+                  (1, 4, 1024, L | GS), (2, 2, 1024, L | GS), (4, 1, 1024, L | GS | _capi.FZ_VF_PREFETCH3), (1, 8, 64, L | GS)):
             if ns % v[0] or prog.kernel_resources(F.make_variant(*v), ns, T)["scratch_bytes"]:
                 continue                                         # (a register-heavy graph does not fit 128 registers per lane: the library never picks that)
             got, st = run_gpu(torch, F, prog, x, variant=F.make_variant(*v), params=params)
@@ -1515,13 +1517,22 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     from zignal_amd import _capi
     monkeypatch.setenv("FLOWZ_HIP_NO_PLAN_CACHE", "1")
     prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
-    assert prog.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p4u1b1024f%d" % (_capi.FZ_VF_LOCKSTEP | _capi.FZ_VF_PREFETCH3)
-    assert prog.kernel_name(None, 1 << 19, 4096, 0) == "fz_block_kernel_p2u2b1024f%d" % _capi.FZ_VF_LOCKSTEP
-    assert prog.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p1u8b1024f%d" % _capi.FZ_VF_LOCKSTEP
+    LG = _capi.FZ_VF_LOCKSTEP | _capi.FZ_VF_GRID_SYNC
+    assert prog.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p4u1b1024f%d" % (LG | _capi.FZ_VF_PREFETCH3)
+    assert prog.kernel_name(None, 1 << 19, 4096, 0) == "fz_block_kernel_p2u2b1024f%d" % LG
+    assert prog.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p1u4b1024f%d" % LG
+    assert prog.kernel_name(None, 1 << 21, 4096, 0) == "fz_block_kernel_p4u1b1024f%d" % (_capi.FZ_VF_LOCKSTEP | _capi.FZ_VF_PREFETCH3)   # two generations of workgroups: no XCD-wide sync
     assert prog.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % _capi.FZ_VF_MAX_WG(2)
     assert "b1024" not in prog.kernel_name(None, 1 << 17, 4096, 0)
-    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u8b1024f%d" % _capi.FZ_VF_LOCKSTEP
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024f%d" % _capi.FZ_VF_LOCKSTEP   # (1024 workgroups: four generations)
     assert F.compile(F.from_sexpr(G.par4_sum())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u32b256f0"
+    # more workgroups than the chip holds at once (300 of 1024 lanes): two generations with counters of their own
+    ns, T = 300 * 1024 + 64, 40
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED + 34)
+    yg, stg = prog.run_block(x, variant=F.make_variant(1, 4, 1024, LG))
+    y0, st0 = prog.run_block(x, variant=F.make_variant(2, 16, 256))
+    assert torch.equal(yg, y0) and torch.equal(stg, st0)
     ns, T = (1 << 18) + 8, 24                                   # ragged on purpose
     x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
     F.synth_fill(x, SEED + 33)

@@ -3,8 +3,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "fz_runtime.hpp"
+
+fz_program::~fz_program()
+{
+   for (auto& kv : sync_dev)
+      if (kv.second.first) (void)hipFree(kv.second.first);
+}
 
 namespace fz {
 
@@ -15,6 +23,7 @@ struct ArgsHeader {
    float* state;
    const float* params;
    const float* mod;
+   unsigned int* sync;
    unsigned long long n_streams;
    unsigned int n_samples;
    unsigned int n_groups;
@@ -23,9 +32,9 @@ struct ArgsHeader {
    unsigned int rows_total;
    unsigned int row0;
    unsigned int mod_stride;
-   unsigned int pad_;
+   unsigned int gs_resident;
 };
-static_assert(sizeof(ArgsHeader) % 8 == 0 && sizeof(ArgsHeader) == 5 * 8 + 8 + 8 * 4, "ArgsHeader must match the head of the kernel's fz_args without padding");
+static_assert(sizeof(ArgsHeader) % 8 == 0 && sizeof(ArgsHeader) == 6 * 8 + 8 + 8 * 4, "ArgsHeader must match the head of the kernel's fz_args without padding");
 
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
            uint32_t n_samples, const fz_variant* uv, void* stream, uint32_t tile_streams, uint32_t rows_total, uint32_t row0,
@@ -173,8 +182,48 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       if ((uint64_t)mod_row0 + row0 + n_samples > mod_stride) fail(FZ_E_INVALID, "fz_program_set_modulation: stride is shorter than the rows of this launch");
       mod_dev += mod_row0;
    }
-   ArgsHeader h{in, out, state, params, mod_dev, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
-                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0, mod_stride, 0u};
+   const unsigned grid = (unsigned)(((unsigned int)(n_streams / v.P) + v.block - 1) / v.block);
+   // (wave split: v.block counts the 64 streams of a workgroup; two waves evaluate them)
+   const unsigned threads = ws_parts(v.flags) ? v.block * ws_waves(v.flags) : v.block;
+   unsigned int* sync_dev = nullptr;
+   unsigned int gs_resident = 0;
+   if (v.flags & FZ_VF_GRID_SYNC) {
+      // per-(generation, XCD) arrival counters, zeroed in stream order before the launch; `resident` = the workgroups of THIS
+      // kernel the chip holds at a time (occupancy x CUs, rounded down to whole laps over the 8 XCDs)
+      int dev = 0;
+      FZ_HIP(hipGetDevice(&dev));
+      {  // (asked once per kernel and device: the launch path stays free of driver queries)
+         static std::mutex mu;
+         static std::map<std::pair<void*, int>, unsigned> known;
+         std::lock_guard<std::mutex> lock(mu);
+         unsigned& r = known[{fn, dev}];
+         if (!r) {
+            int per_cu = 0, cus = 0;
+            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (hipFunction_t)fn, (int)threads, 0) != hipSuccess || per_cu < 1) {
+               (void)hipGetLastError();
+               per_cu = 1;
+            }
+            FZ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            r = std::max(8u, (unsigned)(cus * per_cu) / 8u * 8u);
+         }
+         gs_resident = r;
+      }
+      const size_t bytes = (size_t)((grid + gs_resident - 1) / gs_resident) * 8 * 128;
+      {
+         std::lock_guard<std::mutex> lock(p->mu);
+         auto& slot = p->sync_dev[dev];
+         if (slot.second < bytes) {
+            if (slot.first) FZ_HIP(hipFree(slot.first));   // (synchronises: nothing in flight uses the old counters)
+            slot = {nullptr, 0};
+            FZ_HIP(hipMalloc(&slot.first, std::max<size_t>(bytes, 8192)));
+            slot.second = std::max<size_t>(bytes, 8192);
+         }
+         sync_dev = static_cast<unsigned int*>(slot.first);
+      }
+      FZ_HIP(hipMemsetAsync(sync_dev, 0, bytes, (hipStream_t)stream));
+   }
+   ArgsHeader h{in, out, state, params, mod_dev, sync_dev, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
+                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0, mod_stride, gs_resident};
    std::memcpy(kbuf, &h, sizeof h);
    {
       std::lock_guard<std::mutex> lock(p->mu);
@@ -183,9 +232,6 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    }
    size_t size = kbytes;
    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, kbuf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-   const unsigned grid = (unsigned)((h.n_groups + v.block - 1) / v.block);
-   // (wave split: v.block counts the 64 streams of a workgroup; two waves evaluate them)
-   const unsigned threads = ws_parts(v.flags) ? v.block * ws_waves(v.flags) : v.block;
    FZ_HIP(hipModuleLaunchKernel((hipFunction_t)fn, grid, 1, 1, threads, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
    static const bool debug = std::getenv("FLOWZ_HIP_DEBUG") != nullptr;
    if (debug) {

@@ -31,6 +31,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    if (reqB != 0 && (reqB % 64 != 0 || reqB > 1024)) fail(FZ_E_INVALID, "block_threads must be a multiple of 64, <= 1024");
    if ((v.flags & FZ_VF_LOCKSTEP) && (ws_parts(v.flags) || (v.flags & (FZ_VF_STREAM_MAJOR | FZ_VF_STAGE_PACK))))
       fail(FZ_E_INVALID, "FZ_VF_LOCKSTEP applies to the plain frame kernel (time-major / tiled frames, no stage packing, no wave split)");
+   if ((v.flags & FZ_VF_GRID_SYNC) && !(v.flags & FZ_VF_LOCKSTEP)) fail(FZ_E_INVALID, "FZ_VF_GRID_SYNC goes with FZ_VF_LOCKSTEP");
    if (const uint32_t W = ws_parts(v.flags)) {
       // W compute waves per 64 streams, each evaluating one part of the serial graph (fz_split.cpp: find_wave_roles), and with
       // FZ_VF_IO_WAVE one more wave for the frame I/O
@@ -212,9 +213,15 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       P = std::min(P, allow_lockstep >= 3 ? 4u : allow_lockstep);
       if (P == 3) P = 2;
       v.P = P;
-      v.U = P == 4 ? 1 : P == 2 ? 2 : 8;
+      v.U = P == 4 ? 1 : P == 2 ? 2 : 4;
       v.block = 1024;
       v.flags |= FZ_VF_LOCKSTEP | (P == 4 ? (uint32_t)FZ_VF_PREFETCH3 : 0u);
+      // ... and the workgroups of an XCD walk the rows together too (FZ_VF_GRID_SYNC: see the kernel source) when the chip
+      // holds them all at once (256 CUs, one such workgroup each): 1 M streams 5.43-5.60 ms against 6.09-6.25 ms without
+      // (0.77-0.79 of peak: faster than stream tiles on the same boards), 524 288 streams 2.74 against 3.16 ms, 262 144 streams
+      // 1.58 against 1.84 ms; with two generations of workgroups (2 M streams) it loses 3 %: gpurun_out/r03n ->
+      // profiles/r03/sweep_time_major_grid_sync.txt
+      if ((n_streams / P + 1023) / 1024 <= 256 && n_samples >= 64) v.flags |= FZ_VF_GRID_SYNC;
       return v;
    }
    // stream-tiled frames, packed lanes, chip oversubscribed: two workgroups per CU (262 144 streams in flight keep fewer tiles
@@ -409,8 +416,10 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
       cands.push_back(fz_variant{1, 24, 0, FZ_VF_STAGE_PACK});
       cands.push_back(fz_variant{1, 32, 0, FZ_VF_STAGE_PACK});
    } else if (d.flags & FZ_VF_LOCKSTEP) {   // plain time-major frames, many streams: the CU-wide workgroups in lockstep against four-wave workgroups running free
+      const uint32_t G = d.flags & FZ_VF_GRID_SYNC;
       cands.push_back(fz_variant{std::min(d.P, 2u), 16, 256, 0});
-      if (d.P == 4) cands.push_back(fz_variant{2, 2, 1024, FZ_VF_LOCKSTEP});
+      if (G) cands.push_back(fz_variant{d.P, d.U, 1024, (d.flags & ~(uint32_t)FZ_VF_GRID_SYNC)});   // the same without the XCD-wide synchronisation
+      if (d.P == 4) cands.push_back(fz_variant{2, 2, 1024, FZ_VF_LOCKSTEP | G});
       if (d.P >= 2) cands.push_back(fz_variant{2, 8, 1024, FZ_VF_LOCKSTEP});
       if (d.P >= 2) cands.push_back(fz_variant{4, 8, 512, FZ_VF_LOCKSTEP});
       if (d.P >= 2) cands.push_back(fz_variant{1, 8, 1024, FZ_VF_LOCKSTEP});
@@ -418,6 +427,8 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
       if (d.P == 1) cands.push_back(fz_variant{1, 4, 1024, FZ_VF_LOCKSTEP});
    } else if (d.P == 2) {            // many streams, narrow frames: lane packing x prefetch depth x workgroups per CU
       cands.push_back(fz_variant{2, 16, 256, (d.flags & FZ_VF_MAX_WG(7)) ? 0u : FZ_VF_MAX_WG(2)});
+      // CU-wide workgroups in lockstep, XCD-wide synchronised (the time-major default): +2 % on tiled frames on one board
+      if (tile_streams && tile_streams % 2048 == 0 && (n_streams / 2 + 1023) / 1024 <= 512) cands.push_back(fz_variant{2, 2, 1024, FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC});
       cands.push_back(fz_variant{2, 32, 256, 0});
       cands.push_back(fz_variant{4, 8, 0, 0});
       cands.push_back(fz_variant{2, 32, 256, FZ_VF_MAX_WG(2)});
