@@ -320,9 +320,12 @@ def main():
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0)
-    ap.add_argument("--tile", type=int, default=8192,
-                    help="streams per frame tile (stream-tiled layout [tile][t][stream], the HBM-friendly "
-                         "default); 0 = plain time-major [t][stream]")
+    ap.add_argument("--tile", type=int, default=0,
+                    help="frame layout of the headline workload: 0 = plain time-major [t][stream] (SURVEY 8d's device layout; since round "
+                         "3 also the fastest: CU-wide workgroups in lockstep, XCD-wide synchronised), else streams per frame tile "
+                         "(stream-tiled layout [tile][t][stream])")
+    ap.add_argument("--secondary-tile", type=int, default=8192,
+                    help="streams per frame tile of the secondary configs and of the tiled-layout leg (1-wire frames; 0 = time-major)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config2", action="store_true", help="skip the 65 536-stream measurement (BASELINE configs[1])")
     ap.add_argument("--no-config34", action="store_true", help="skip BASELINE configs[2] and [3] (4-parallel sum, oscillator chain)")
@@ -390,7 +393,7 @@ def main():
 
     # ---- secondary configs (rank 0, N == 1): each frees its buffers before the next ---------------------------------
     def config2(ns2=65536):
-        t2 = pick_tile(ns2, args.tile)
+        t2 = pick_tile(ns2, args.secondary_tile)
         x2, y2 = frames(torch, dev, ns2, T, 1, t2), frames(torch, dev, ns2, T, 1, t2)
         st2 = torch.zeros((prog.n_state, ns2), dtype=torch.float32, device=dev)
         F.synth_fill(x2, SEED)
@@ -418,7 +421,9 @@ def main():
     def config3(fanout):
         g = W.par4_sum_fanout() if fanout else W.par4_sum()
         p3 = F.compile(F.from_sexpr(g))
-        t3 = pick_tile(ns3, p3.recommended_tile_streams())
+        # the 4-wire sum on stream tiles (its rows are wide: tiles stream best), the 1-wire fan-out variant on plain time-major
+        # frames like the headline (CU-wide lockstep workgroups, XCD-wide synchronised: 0.80 against 0.77-0.78 on tiles)
+        t3 = 0 if fanout else pick_tile(ns3, p3.recommended_tile_streams())
         x3, y3 = frames(torch, dev, ns3, T, p3.n_in, t3), frames(torch, dev, ns3, T, 1, t3)
         st3 = torch.zeros((p3.n_state, ns3), dtype=torch.float32, device=dev)
         F.synth_fill(x3, SEED)
@@ -444,7 +449,7 @@ def main():
 
     def config4():
         p4 = F.compile(F.from_sexpr(W.osc_chain(6)))
-        t4 = pick_tile(ns3, args.tile)
+        t4 = pick_tile(ns3, args.secondary_tile)
         x4, y4 = frames(torch, dev, ns3, T, 1, t4), frames(torch, dev, ns3, T, 1, t4)
         st4 = torch.zeros((p4.n_state, ns3), dtype=torch.float32, device=dev)
         P = W.osc_chain_params(SEED + 1, np.arange(ns3))
@@ -470,20 +475,23 @@ def main():
                            f"(BASELINE configs[3]), " + (f"tiled:{t4}" if t4 else "time-major"))
         return res
 
-    def time_major_leg():
-        """The headline workload on plain time-major frames [t][stream] (SURVEY 8d's device layout): library default and tuned."""
-        x2, y2 = frames(torch, dev, ns, T, 1, 0), frames(torch, dev, ns, T, 1, 0)
+    def frame_layout_leg(tl):
+        """The headline workload on the OTHER frame layout -- stream tiles when the headline runs on plain time-major frames
+        [t][stream] (SURVEY 8d's device layout, the default), time-major frames when it was asked to run on tiles: library default and tuned."""
+        tl = pick_tile(ns, tl)
+        x2, y2 = frames(torch, dev, ns, T, 1, tl), frames(torch, dev, ns, T, 1, tl)
         st2 = torch.zeros((prog.n_state, ns), dtype=torch.float32, device=dev)
         F.synth_fill(x2, SEED)
-        res, tv = measure_config(torch, F, prog, x2, y2, st2, None, ns, T, 0, max(5, args.steps // 2), f"cascade6_{ns}x{T}_timemajor",
-                                 do_tune=not args.no_autotune)
+        key = f"cascade6_{ns}x{T}_" + (f"tile{tl}" if tl else "timemajor")
+        res, tv = measure_config(torch, F, prog, x2, y2, st2, None, ns, T, tl, max(5, args.steps // 2), key, do_tune=not args.no_autotune)
         st2.zero_()
         prog.run_block(x2, state=st2, out=y2, variant=tv)
         ids = sample_ids(ns, PARITY_STREAMS, 15)
         from oracle import coracle, flowz_oracle as O
         want = coracle.df1_cascade([W.STABLE] * 6, O.synth_input(SEED, ids, T))
-        res["parity"] = parity_string(ndiff_bits(gather_streams(torch, y2, ids, 0), want), len(ids), T)
-        res["workload"] = f"6-stage DF1 cascade, {ns} streams x {T}-sample block, plain time-major frames [t][stream] (SURVEY 8d)"
+        res["parity"] = parity_string(ndiff_bits(gather_streams(torch, y2, ids, tl), want), len(ids), T)
+        res["workload"] = (f"6-stage DF1 cascade, {ns} streams x {T}-sample block, " +
+                           (f"stream-tiled frames [tile][t][{tl} streams]" if tl else "plain time-major frames [t][stream] (SURVEY 8d)"))
         return res
 
     def stream_major_leg():
@@ -545,7 +553,8 @@ def main():
     ns3 = args.streams
     if args.only:
         fn = {"config2": config2, "config2h": lambda: config2(32768), "config2q": lambda: config2(16384), "config3": lambda: config3(False), "config3f": lambda: config3(True),
-              "config4": config4, "timemajor": time_major_leg, "streammajor": stream_major_leg}[args.only]
+              "config4": config4, "timemajor": lambda: frame_layout_leg(0), "tiled": lambda: frame_layout_leg(args.secondary_tile),
+              "streammajor": stream_major_leg}[args.only]
         print(json.dumps({args.only: fn()}), flush=True)
         return
 
@@ -614,7 +623,10 @@ def main():
         del x, y, state
         torch.cuda.empty_cache()
         if not args.no_layout_legs:
-            secondary["time_major_layout"] = time_major_leg()
+            if tile:
+                secondary["time_major_layout"] = frame_layout_leg(0)
+            else:
+                secondary["tiled_layout"] = frame_layout_leg(args.secondary_tile)
             torch.cuda.empty_cache()
             secondary["stream_major_layout"] = stream_major_leg()
             torch.cuda.empty_cache()

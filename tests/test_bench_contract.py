@@ -34,7 +34,8 @@ def test_bench_json_contract_small_workload():
     for k in ("config2_65536_streams", "cascade6_32768_streams", "cascade6_16384_streams", "config3_par4_sum", "config3_par4_sum_fanout", "config4_osc_chain"):
         assert d[k]["parity"].startswith("bitwise-equal"), (k, d[k]["parity"])
         assert d[k]["library_default"]["frac"] > 0 and d[k]["tuned"]["kernel"].startswith("fz_block_kernel_p")
-    for k in ("time_major_layout", "stream_major_layout"):            # the two contract layouts on the driver line (round 3)
+    assert d["config"]["layout"] == "time-major"                       # SURVEY 8d's device layout is the headline's (round 3)
+    for k in ("tiled_layout", "stream_major_layout"):                  # the other frame layout and the reference's calling convention, same workload
         assert d[k]["parity"].startswith("bitwise-equal"), (k, d[k]["parity"])
         assert d[k]["library_default"]["frac"] > 0 and d[k]["tuned"]["kernel"].startswith("fz_block_kernel_p") and 0 < d[k]["frac"] < 1
     assert c["Msamples_per_s_per_core"] > 0 and c["physical_cores"] >= 1 and c["logical_cpus"] >= c["physical_cores"]

@@ -10,10 +10,10 @@ import os
 import sys
 
 base, outdir = sys.argv[1:3]
-WORKLOAD = {"head": "cascade6_1048576x4096_tile8192", "c2": "cascade6_65536x4096_tile8192", "c2h": "cascade6_32768x4096_tile8192", "c2q": "cascade6_16384x4096_tile8192",
-            "c3": "par4_1048576x4096_tile4096", "c3f": "par4f_1048576x4096_tile8192", "c4": "osc6_1048576x4096_tile8192",
+WORKLOAD = {"head": "cascade6_1048576x4096_timemajor", "tl": "cascade6_1048576x4096_tile8192", "c2": "cascade6_65536x4096_tile8192", "c2h": "cascade6_32768x4096_tile8192", "c2q": "cascade6_16384x4096_tile8192",
+            "c3": "par4_1048576x4096_tile4096", "c3f": "par4f_1048576x4096_timemajor", "c4": "osc6_1048576x4096_tile8192",
             "tm": "cascade6_1048576x4096_timemajor", "sm": "cascade6_1048576x4096_streammajor"}
-B_ALG = {"head": 1048576 * (4 * 4096 * 2 + 8 * 14), "c2": 65536 * (4 * 4096 * 2 + 8 * 14), "c2h": 32768 * (4 * 4096 * 2 + 8 * 14), "c2q": 16384 * (4 * 4096 * 2 + 8 * 14),
+B_ALG = {"head": 1048576 * (4 * 4096 * 2 + 8 * 14), "tl": 1048576 * (4 * 4096 * 2 + 8 * 14), "c2": 65536 * (4 * 4096 * 2 + 8 * 14), "c2h": 32768 * (4 * 4096 * 2 + 8 * 14), "c2q": 16384 * (4 * 4096 * 2 + 8 * 14),
          "c3": 1048576 * (4 * 4096 * 5 + 8 * 16), "c3f": 1048576 * (4 * 4096 * 2 + 8 * 18), "c4": 1048576 * (4 * 4096 * 2 + 8 * 16 + 4 * 31),
          "tm": 1048576 * (4 * 4096 * 2 + 8 * 14), "sm": 1048576 * (4 * 4096 * 2 + 8 * 14)}
 

@@ -15,7 +15,7 @@ pass() {   # pass <tag> <bench args...>: one FETCH_SIZE and one WRITE_SIZE run
   done
 }
 pass head_default $HEAD
-pass tm_default   --only timemajor
+pass tl_default   --only tiled
 pass sm_default   --only streammajor
 pass c2_default   --only config2
 pass c2h_default  --only config2h
@@ -25,7 +25,7 @@ pass c3f_default  --only config3f
 pass c4_default   --only config4
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 rocprofv3 --pmc $SQ --output-format csv -d $O/pmc_sq_head -o b -- python $R/bench.py $HEAD > $O/pmc_sq_head.log 2>&1
-for o in timemajor streammajor config2 config2h config2q; do
+for o in tiled streammajor config2 config2h config2q; do
   rocprofv3 --pmc $SQ --output-format csv -d $O/pmc_sq_$o -o b -- python $R/bench.py --only $o --no-autotune > $O/pmc_sq_$o.log 2>&1
 done
 for d in $O/trace $O/pmc_*; do [ -d "$d" ] && find $d -mindepth 2 -name '*.csv' -exec mv {} $d/ \; ; done
