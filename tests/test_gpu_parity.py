@@ -1521,12 +1521,13 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     assert prog.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p4u1b1024f%d" % (LG | _capi.FZ_VF_PREFETCH3)
     assert prog.kernel_name(None, 1 << 19, 4096, 0) == "fz_block_kernel_p2u2b1024f%d" % LG
     assert prog.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p1u4b1024f%d" % LG
-    assert prog.kernel_name(None, 1 << 21, 4096, 0) == "fz_block_kernel_p4u1b1024f%d" % (_capi.FZ_VF_LOCKSTEP | _capi.FZ_VF_PREFETCH3)   # two generations of workgroups: no XCD-wide sync
+    PERSIST = 1 << 27                                            # (internal: more blocks than CUs -> a persistent launch, a kernel of its own)
+    assert prog.kernel_name(None, 1 << 21, 4096, 0) == "fz_block_kernel_p2u2b1024f%d" % (LG | PERSIST)   # (four streams per lane do not fit the persistent kernel's registers)
     assert prog.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % _capi.FZ_VF_MAX_WG(2)
     assert "b1024" not in prog.kernel_name(None, 1 << 17, 4096, 0)
-    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024f%d" % _capi.FZ_VF_LOCKSTEP   # (1024 workgroups: four generations)
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024f%d" % (LG | PERSIST)   # (1024 blocks on 256 CUs: four laps)
     assert F.compile(F.from_sexpr(G.par4_sum())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u32b256f0"
-    # more workgroups than the chip holds at once (300 of 1024 lanes): two generations with counters of their own
+    # more blocks than the chip holds workgroups (300 of 1024 lanes): a persistent launch, two laps with counters of their own
     ns, T = 300 * 1024 + 64, 40
     x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
     F.synth_fill(x, SEED + 34)

@@ -176,7 +176,7 @@ def test_no_fma_contraction_in_generated_kernel(tmp_path, monkeypatch):
     for obj in tmp_path.glob("*.hsaco"):
         dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", str(obj)], text=True)
         assert "v_pk_mul_f32" in dis or "v_mul_f32" in dis
-        assert not re.search(r"v_(pk_)?(fma|fmac|mad|mac)_", dis)
+        assert not re.search(r"v_(pk_)?(fma|fmac|mad|mac)(_mix|_mixlo|_mixhi|_legacy)?_(f16|f32|f64|bf16)", dis)
         notes = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(obj)], text=True)
         assert ".vgpr_spill_count: 0" in notes and ".private_segment_fixed_size: 0" in notes
 
@@ -195,7 +195,7 @@ def test_wave_split_kernels_in_the_isa(tmp_path, monkeypatch):
     for obj in objs:
         dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", str(obj)], text=True)
         notes = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(obj)], text=True)
-        assert not re.search(r"v_(pk_)?(fma|fmac|mad|mac)_", dis)
+        assert not re.search(r"v_(pk_)?(fma|fmac|mad|mac)(_mix|_mixlo|_mixhi|_legacy)?_(f16|f32|f64|bf16)", dis)
         assert ".vgpr_spill_count: 0" in notes and ".private_segment_fixed_size: 0" in notes
         assert "v_cmp_eq_u64" not in dis and dis.count("v_readfirstlane_b32") < 16            # no waterfall loops (readfirstlane x 4 + 64-bit compares per access)
         assert "ds_write_b128" in dis and "ds_read_b128" in dis and "s_barrier" in dis
@@ -253,7 +253,7 @@ def test_stage_split_detection_and_packed_kernel_builds(tmp_path, monkeypatch):
     p.build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))
     (obj,) = tmp_path.glob("*.hsaco")
     dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", str(obj)], text=True)
-    assert dis.count("v_pk_mul_f32") > 100 and not re.search(r"v_(pk_)?(fma|fmac|mad|mac)_", dis)
+    assert dis.count("v_pk_mul_f32") > 100 and not re.search(r"v_(pk_)?(fma|fmac|mad|mac)(_mix|_mixlo|_mixhi|_legacy)?_(f16|f32|f64|bf16)", dis)
     F.compile(F.from_sexpr(G.osc_chain(6))).build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))   # scalar prefix + 6 segments
     with pytest.raises(F.FlowzError):
         F.compile(F.from_sexpr(G.df1())).build(F.make_variant(1, 8, 256, _capi.FZ_VF_STAGE_PACK))

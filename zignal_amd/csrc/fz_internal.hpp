@@ -144,6 +144,10 @@ inline uint32_t ws_io(uint32_t flags) { return (flags & FZ_VF_IO_WAVE) ? 1u : 0u
 inline uint32_t ws_parts(uint32_t flags) { const uint32_t W = wave_split_of(flags); return W ? W : ws_io(flags); }
 inline uint32_t ws_waves(uint32_t flags) { return ws_parts(flags) + (ws_parts(flags) ? ws_io(flags) : 0u); }
 
+// internal variant flag (never set by callers): FZ_VF_GRID_SYNC with more blocks than the chip holds workgroups -> persistent launch
+constexpr uint32_t FZ_VF_PERSIST = 1u << 27;
+constexpr uint32_t kChipCUs = 256;       // MI355X (gfx950): 8 XCDs x 32 CUs
+
 // register-resident delay lines up to this depth; deeper ones become LDS rings
 constexpr uint32_t kRegMaxDepth = 8;
 constexpr uint32_t kLdsMaxDepth = 256;   // deeper lines live in HBM (ring in the state buffer)

@@ -32,7 +32,7 @@ struct ArgsHeader {
    unsigned int rows_total;
    unsigned int row0;
    unsigned int mod_stride;
-   unsigned int gs_resident;
+   unsigned int n_blocks;
 };
 static_assert(sizeof(ArgsHeader) % 8 == 0 && sizeof(ArgsHeader) == 6 * 8 + 8 + 8 * 4, "ArgsHeader must match the head of the kernel's fz_args without padding");
 
@@ -182,16 +182,17 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       if ((uint64_t)mod_row0 + row0 + n_samples > mod_stride) fail(FZ_E_INVALID, "fz_program_set_modulation: stride is shorter than the rows of this launch");
       mod_dev += mod_row0;
    }
-   const unsigned grid = (unsigned)(((unsigned int)(n_streams / v.P) + v.block - 1) / v.block);
+   const unsigned n_blocks = (unsigned)(((unsigned int)(n_streams / v.P) + v.block - 1) / v.block);
+   unsigned grid = n_blocks;
    // (wave split: v.block counts the 64 streams of a workgroup; two waves evaluate them)
    const unsigned threads = ws_parts(v.flags) ? v.block * ws_waves(v.flags) : v.block;
    unsigned int* sync_dev = nullptr;
-   unsigned int gs_resident = 0;
    if (v.flags & FZ_VF_GRID_SYNC) {
-      // per-(generation, XCD) arrival counters, zeroed in stream order before the launch; `resident` = the workgroups of THIS
-      // kernel the chip holds at a time (occupancy x CUs, rounded down to whole laps over the 8 XCDs)
+      // persistent launch: the grid is what the chip holds of THIS kernel at a time (occupancy x CUs, whole laps over the 8 XCDs);
+      // per-(lap, XCD) arrival counters, zeroed in stream order before the launch
       int dev = 0;
       FZ_HIP(hipGetDevice(&dev));
+      unsigned resident = 0;
       {  // (asked once per kernel and device: the launch path stays free of driver queries)
          static std::mutex mu;
          static std::map<std::pair<void*, int>, unsigned> known;
@@ -206,9 +207,10 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
             FZ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
             r = std::max(8u, (unsigned)(cus * per_cu) / 8u * 8u);
          }
-         gs_resident = r;
+         resident = r;
       }
-      const size_t bytes = (size_t)((grid + gs_resident - 1) / gs_resident) * 8 * 128;
+      if ((v.flags & FZ_VF_PERSIST) && n_blocks > resident) grid = resident;   // (one lap: the waits of workgroups that are not running yet are bounded)
+      const size_t bytes = (size_t)((n_blocks + grid - 1) / grid) * 8 * 128;
       {
          std::lock_guard<std::mutex> lock(p->mu);
          auto& slot = p->sync_dev[dev];
@@ -223,7 +225,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       FZ_HIP(hipMemsetAsync(sync_dev, 0, bytes, (hipStream_t)stream));
    }
    ArgsHeader h{in, out, state, params, mod_dev, sync_dev, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
-                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0, mod_stride, gs_resident};
+                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0, mod_stride, n_blocks};
    std::memcpy(kbuf, &h, sizeof h);
    {
       std::lock_guard<std::mutex> lock(p->mu);

@@ -29,8 +29,8 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       fail(FZ_E_INVALID, "FZ_VF_OUT_F64 does not apply to fz_compile_typed programs: their frames carry every wire in its own type");
    if (reqU > 32 && !((v.flags & FZ_VF_SM_LONG) && (reqU == 64 || reqU == 128))) fail(FZ_E_INVALID, "unroll must be <= 32");
    if (reqB != 0 && (reqB % 64 != 0 || reqB > 1024)) fail(FZ_E_INVALID, "block_threads must be a multiple of 64, <= 1024");
-   if ((v.flags & FZ_VF_LOCKSTEP) && (ws_parts(v.flags) || (v.flags & (FZ_VF_STREAM_MAJOR | FZ_VF_STAGE_PACK))))
-      fail(FZ_E_INVALID, "FZ_VF_LOCKSTEP applies to the plain frame kernel (time-major / tiled frames, no stage packing, no wave split)");
+   if ((v.flags & FZ_VF_LOCKSTEP) && (ws_parts(v.flags) || (v.flags & FZ_VF_STREAM_MAJOR)))
+      fail(FZ_E_INVALID, "FZ_VF_LOCKSTEP applies to the frame kernel (time-major / tiled frames, lane-packed or stage-packed; no wave split)");
    if ((v.flags & FZ_VF_GRID_SYNC) && !(v.flags & FZ_VF_LOCKSTEP)) fail(FZ_E_INVALID, "FZ_VF_GRID_SYNC goes with FZ_VF_LOCKSTEP");
    if (const uint32_t W = ws_parts(v.flags)) {
       // W compute waves per 64 streams, each evaluating one part of the serial graph (fz_split.cpp: find_wave_roles), and with
@@ -216,12 +216,12 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       v.U = P == 4 ? 1 : P == 2 ? 2 : 4;
       v.block = 1024;
       v.flags |= FZ_VF_LOCKSTEP | (P == 4 ? (uint32_t)FZ_VF_PREFETCH3 : 0u);
-      // ... and the workgroups of an XCD walk the rows together too (FZ_VF_GRID_SYNC: see the kernel source) when the chip
-      // holds them all at once (256 CUs, one such workgroup each): 1 M streams 5.43-5.60 ms against 6.09-6.25 ms without
-      // (0.77-0.79 of peak: faster than stream tiles on the same boards), 524 288 streams 2.74 against 3.16 ms, 262 144 streams
-      // 1.58 against 1.84 ms; with two generations of workgroups (2 M streams) it loses 3 %: gpurun_out/r03n ->
-      // profiles/r03/sweep_time_major_grid_sync.txt
-      if ((n_streams / P + 1023) / 1024 <= 256 && n_samples >= 64) v.flags |= FZ_VF_GRID_SYNC;
+      // ... and the workgroups of an XCD walk the rows together too (FZ_VF_GRID_SYNC: a persistent launch, see the kernel
+      // source): 1 M streams 5.43-5.60 ms against 6.09-6.25 ms without (0.77-0.79 of peak: faster than stream tiles on the same
+      // boards), 524 288 streams 2.74 against 3.16 ms, 262 144 streams 1.58 against 1.84 ms
+      // (gpurun_out/r03n -> profiles/r03/sweep_time_major_grid_sync.txt)
+      // (blocks of a few rows are not worth zeroing the counters for)
+      if (n_samples >= 64) v.flags |= FZ_VF_GRID_SYNC;
       return v;
    }
    // stream-tiled frames, packed lanes, chip oversubscribed: two workgroups per CU (262 144 streams in flight keep fewer tiles
@@ -267,6 +267,10 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
          }
          if (row_bytes * v.U >= (1ull << 32)) fail(FZ_E_UNSUPPORTED, "rows too wide for this kernel variant (unroll x row bytes must stay below 4 GiB): tile the streams");
       }
+      // XCD-wide synchronisation needs every workgroup running: with more blocks than CUs (1024-lane workgroups: one per CU;
+      // smaller ones: a few, the launch asks the occupancy) the launch is persistent -- a kernel of its own
+      v.flags &= ~FZ_VF_PERSIST;
+      if ((v.flags & FZ_VF_GRID_SYNC) && (n_streams / v.P + v.block - 1) / v.block > kChipCUs) v.flags |= FZ_VF_PERSIST;
       return settle ? settle_variant(p, v) : v;
    };
    const Variant want = resolve_variant(g, uv, n_streams, n_samples, tile_streams);
@@ -415,6 +419,8 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
       }
       cands.push_back(fz_variant{1, 24, 0, FZ_VF_STAGE_PACK});
       cands.push_back(fz_variant{1, 32, 0, FZ_VF_STAGE_PACK});
+      // (the single stage-packed wave per SIMD with XCD-wide synchronisation was measured and LOSES 8 % at 65 536 streams -- 0.62
+      //  against 0.67 of peak, gpurun_out/r03r: not a candidate)
    } else if (d.flags & FZ_VF_LOCKSTEP) {   // plain time-major frames, many streams: the CU-wide workgroups in lockstep against four-wave workgroups running free
       const uint32_t G = d.flags & FZ_VF_GRID_SYNC;
       cands.push_back(fz_variant{std::min(d.P, 2u), 16, 256, 0});
@@ -428,7 +434,9 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
    } else if (d.P == 2) {            // many streams, narrow frames: lane packing x prefetch depth x workgroups per CU
       cands.push_back(fz_variant{2, 16, 256, (d.flags & FZ_VF_MAX_WG(7)) ? 0u : FZ_VF_MAX_WG(2)});
       // CU-wide workgroups in lockstep, XCD-wide synchronised (the time-major default): +2 % on tiled frames on one board
-      if (tile_streams && tile_streams % 2048 == 0 && (n_streams / 2 + 1023) / 1024 <= 512) cands.push_back(fz_variant{2, 2, 1024, FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC});
+      if (tile_streams && tile_streams % 2048 == 0) cands.push_back(fz_variant{2, 2, 1024, FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC});
+      if (tile_streams && tile_streams % 4096 == 0 && n_streams % 4 == 0) cands.push_back(fz_variant{4, 1, 1024, FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC | FZ_VF_PREFETCH3});
+      if (tile_streams && tile_streams % 1024 == 0) cands.push_back(fz_variant{1, 4, 1024, FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC});   // (register-heavy graphs: +3.6 % for the oscillator chain)
       cands.push_back(fz_variant{2, 32, 256, 0});
       cands.push_back(fz_variant{4, 8, 0, 0});
       cands.push_back(fz_variant{2, 32, 256, FZ_VF_MAX_WG(2)});
@@ -439,6 +447,10 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
       cands.push_back(fz_variant{4, 4, 256, FZ_VF_MAX_WG(2)});
    } else {
       cands.push_back(fz_variant{1, d.U == 32 ? 16u : 32u, 0, 0});
+      if (n_streams >= (1u << 18) && (!tile_streams || tile_streams % 1024 == 0)) {   // wide frames: CU-wide workgroups, XCD-wide synchronised
+         cands.push_back(fz_variant{1, 4, 1024, FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC});
+         cands.push_back(fz_variant{1, 2, 1024, FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC});
+      }
    }
    if (!(d.flags & (FZ_VF_STAGE_PACK | FZ_VF_LOCKSTEP)) && d.P != 2 && n_streams >= (1u << 17)) {
       cands.push_back(fz_variant{1, 16, 256, FZ_VF_MAX_WG(1)});
