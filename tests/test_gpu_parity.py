@@ -1545,6 +1545,56 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     assert ndiff(y[:, torch.as_tensor(ids, device="cuda")].cpu().numpy(), want) == 0
 
 
+def test_grid_sync_survives_a_busy_gpu_and_overlapping_streams(torch_cuda, F, monkeypatch):
+    """FZ_VF_GRID_SYNC waits for workgroups that may not be running: (i) two synchronised launches of the same program on two
+    streams at once (each stream has counters of its own; the CUs are shared, so neither launch has all its workgroups
+    resident), (ii) a synchronised launch next to a long copy on another stream, (iii) inside a captured hipGraph.  The waits
+    are bounded: everything finishes, and every bit equals the unsynchronised kernel's."""
+    torch = torch_cuda
+    from zignal_amd import _capi
+    monkeypatch.setenv("FLOWZ_HIP_NO_PLAN_CACHE", "1")
+    LG = _capi.FZ_VF_LOCKSTEP | _capi.FZ_VF_GRID_SYNC
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    ns, T = 1 << 19, 256
+    xs = [torch.empty((T, ns, 1), dtype=torch.float32, device="cuda") for _ in range(2)]
+    for k, x in enumerate(xs):
+        F.synth_fill(x, SEED + 40 + k)
+    want = [prog.run_block(x, variant=F.make_variant(2, 16, 256))[0] for x in xs]
+    v = F.make_variant(2, 2, 1024, LG)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = [torch.empty_like(x) for x in xs]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                prog.run_block(xs[k], out=outs[k], variant=v)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], want[0]) and torch.equal(outs[1], want[1])
+    big = torch.empty((1 << 28,), dtype=torch.float32, device="cuda")        # 1 GiB copies on the side
+    side = torch.empty_like(big)
+    outs[0].zero_()
+    with torch.cuda.stream(streams[1]):
+        for _ in range(4):
+            side.copy_(big)
+    with torch.cuda.stream(streams[0]):
+        prog.run_block(xs[0], out=outs[0], variant=v)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], want[0])
+    # captured: the counters' reset is a memset node in front of the kernel node
+    outs[1].zero_()
+    st = torch.zeros((prog.n_state, ns), dtype=torch.float32, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    prog.run_block(xs[1], state=st.clone(), out=outs[1], variant=v)            # (module loaded, counters allocated before the capture)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        prog.run_block(xs[1], state=st, out=outs[1], variant=v)
+    outs[1].zero_()
+    st.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1], want[1])
+
+
 def test_autotune_env_measures_the_plan_on_first_use(torch_cuda):
     """FLOWZ_HIP_AUTOTUNE=1: the first big block of a shape selects its plan by itself; state and results are
     what a plain launch gives (own process: the knob is read once per process)."""

@@ -212,7 +212,10 @@ struct fz_program {
    std::set<std::tuple<uint64_t, uint32_t, int>> tuned_default;   // shapes measured already (FLOWZ_HIP_AUTOTUNE)
    std::set<std::tuple<uint64_t, uint32_t, int>> plan_looked_up;  // shapes whose persisted plan (plans.txt of the kernel cache) was consulted
    uint64_t graph_hash = 0;                                        // structure of the lowered graph (no coefficient values)
-   std::map<int, std::pair<void*, size_t>> sync_dev;              // FZ_VF_GRID_SYNC: arrival counters per device (buffer, bytes)
+   // FZ_VF_GRID_SYNC: arrival counters per device: 16 slices of `second` bytes, handed to the launches in turn (launches on
+   // different streams may overlap and must not share counters; a slice comes round again after 15 other launches)
+   std::map<int, std::pair<void*, size_t>> sync_dev;              // device -> (buffer, bytes per slice)
+   uint32_t sync_next = 0;
    const float* mod_dev = nullptr;                                 // fz_program_set_modulation
    uint32_t mod_stride = 0;
    ~fz_program();                                                  // frees the counters (fz_launch.cpp)

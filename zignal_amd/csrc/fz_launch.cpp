@@ -11,7 +11,7 @@
 fz_program::~fz_program()
 {
    for (auto& kv : sync_dev)
-      if (kv.second.first) (void)hipFree(kv.second.first);
+      if (kv.second.first) (void)hipFree(kv.second.first);   // (hipFree waits for whatever still runs on the device)
 }
 
 namespace fz {
@@ -215,12 +215,18 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
          std::lock_guard<std::mutex> lock(p->mu);
          auto& slot = p->sync_dev[dev];
          if (slot.second < bytes) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) (void)hipGetLastError();
+            if (cap != hipStreamCaptureStatusNone)
+               fail(FZ_E_INVALID, "FZ_VF_GRID_SYNC: the arrival counters cannot be allocated while the stream is being captured: launch this "
+                                  "shape once before the capture");
             if (slot.first) FZ_HIP(hipFree(slot.first));   // (synchronises: nothing in flight uses the old counters)
             slot = {nullptr, 0};
-            FZ_HIP(hipMalloc(&slot.first, std::max<size_t>(bytes, 8192)));
-            slot.second = std::max<size_t>(bytes, 8192);
+            const size_t per = std::max<size_t>((bytes + 4095) / 4096 * 4096, 16384);
+            FZ_HIP(hipMalloc(&slot.first, per * 16));
+            slot.second = per;
          }
-         sync_dev = static_cast<unsigned int*>(slot.first);
+         sync_dev = reinterpret_cast<unsigned int*>(static_cast<char*>(slot.first) + (size_t)(p->sync_next++ % 16u) * slot.second);
       }
       FZ_HIP(hipMemsetAsync(sync_dev, 0, bytes, (hipStream_t)stream));
    }
