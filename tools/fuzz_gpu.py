@@ -36,7 +36,7 @@ first, count = int(sys.argv[1]), int(sys.argv[2])
 limit = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
 t_start, last = time.time(), first - 1
 ns, T = 200, 61
-ok = bad = skipped = 0
+ok = bad = skipped = refused = 0
 for seed in range(first, first + count):
     if time.time() - t_start > limit:
         break
@@ -60,10 +60,18 @@ for seed in range(first, first + count):
         rng = np.random.default_rng(seed)
         for P in (1, 2, 4):
             U = int(rng.choice([1, 3, 8, 16]))
-            fl = int(rng.choice([0, F.C.FZ_VF_PREFETCH3, F.C.FZ_VF_MAX_WG(2), F.C.FZ_VF_NO_STAGE_PACK]))
-            trace("P", P, "U", U, "flags", fl)
-            y, _ = p.run_block(xd, variant=F.make_variant(P, U, 256, fl))
-            res.append((f"P={P} U={U} flags={fl}", same(y.cpu().numpy(), want, np.float32)))
+            LG = F.C.FZ_VF_LOCKSTEP | F.C.FZ_VF_GRID_SYNC            # round 3: lockstep workgroups, XCD-wide synchronised (ragged 200-stream grids)
+            fl = int(rng.choice([0, F.C.FZ_VF_PREFETCH3, F.C.FZ_VF_MAX_WG(2), F.C.FZ_VF_NO_STAGE_PACK, F.C.FZ_VF_LOCKSTEP, LG, LG | F.C.FZ_VF_PREFETCH3]))
+            blk = int(rng.choice([64, 128])) if (fl & F.C.FZ_VF_LOCKSTEP) else 256   # (small workgroups: several of them for 200 streams, so that barriers and counters do something)
+            trace("P", P, "U", U, "block", blk, "flags", fl)
+            try:
+                y, _ = p.run_block(xd, variant=F.make_variant(P, U, blk, fl))
+            except F.FlowzError as e:
+                if (fl & F.C.FZ_VF_LOCKSTEP) and e.code == F.C.FZ_E_UNSUPPORTED:     # an explicit lockstep variant whose kernel has scratch is refused
+                    refused += 1
+                    continue
+                raise
+            res.append((f"P={P} U={U} block={blk} flags={fl}", same(y.cpu().numpy(), want, np.float32)))
         trace("f64 frames")
         y64, _ = p.run_block(xd, out_f64=True)
         res.append(("f64 frames", same(y64.cpu().numpy(), want64, np.float64)))
@@ -128,6 +136,6 @@ for seed in range(first, first + count):
         else:
             bad += 1
             print("MISMATCH seed", seed, "typed" if typed else "plain", [n for n, r in res if not r], g, flush=True)
-print(f"fuzz seeds {first}..{last}: {ok} graphs identical, {bad} mismatching, {skipped} skipped "
-      f"(per graph: P = 1, 2, 4 with random unroll / flags, float64 frames, a split block, the stream-major kernel short and long, fz_compile_typed with random input types)")
+print(f"fuzz seeds {first}..{last}: {ok} graphs identical, {bad} mismatching, {skipped} skipped, {refused} lockstep variants refused "
+      f"(per graph: P = 1, 2, 4 with random unroll / flags incl. lockstep and XCD-synchronised workgroups, float64 frames, a split block, the stream-major kernel short and long, fz_compile_typed with random input types)")
 sys.exit(1 if bad else 0)
