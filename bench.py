@@ -232,6 +232,52 @@ def event_ms(torch, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+class PowerSampler:
+    """Board power and shader clock (rocm-smi) sampled in a thread while the sustained leg runs: the 6-biquad cascade at 1 M streams
+    sits at the package power cap and the firmware lowers the clock until it fits (profiles/r03/power_and_clocks.txt), so a run's
+    number is also a statement about the board.  Best effort: None when rocm-smi is missing or prints something else."""
+
+    def __init__(self, device_index=0, period=0.3):
+        import shutil
+        import threading
+        self.exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+        self.dev, self.period, self.rows, self._stop = device_index, period, [], False
+        self.thread = threading.Thread(target=self._run, daemon=True) if self.exe else None
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop:
+            try:
+                o = subprocess.run([self.exe, "-d", str(self.dev), "--showpower", "--showclocks", "--showmaxpower", "--json"],
+                                   capture_output=True, text=True, timeout=5).stdout
+                c = next(iter(json.loads(o).values()))
+                watts = [float(v) for k, v in c.items() if "Power (W)" in k and "Max" not in k]
+                cap = [float(v) for k, v in c.items() if "Max" in k and "Power (W)" in k]
+                sclk = [int(re.search(r"(\d+)", v).group(1)) for k, v in c.items() if k.startswith("sclk clock speed")]
+                if watts and sclk:
+                    self.rows.append((time.perf_counter(), watts[0], cap[0] if cap else None, sclk[0]))
+            except Exception:  # noqa: BLE001 -- a sampler must never take the bench down
+                pass
+            time.sleep(self.period)
+
+    def start(self):
+        if self.thread:
+            self.thread.start()
+        self.t0 = time.perf_counter()
+
+    def stop(self, settle=0.7):
+        self._stop = True
+        if self.thread:
+            self.thread.join(timeout=6)
+        rows = [r for r in self.rows if r[0] - self.t0 >= settle] or self.rows
+        if not rows:
+            return None
+        med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+        return {"package_W": med([r[1] for r in rows]), "cap_W": rows[0][2], "sclk_MHz": med([r[3] for r in rows]),
+                "samples": len(rows), "source": "rocm-smi --showpower --showclocks, median over the sustained leg"}
+
+
 def b_alg_of(prog, ns, T):
     return ns * (4 * T * (prog.n_in + prog.n_out) + 8 * prog.n_state + 4 * prog.n_param)
 
@@ -604,12 +650,15 @@ def main():
         # batches of launches (one HIP-event pair each) until >= 2 s of GPU time have gone by
         batch = max(args.steps, int(math.ceil(0.25 / max(kern_avg_s, 1e-6))))
         n_sus, ms_tot = 0, 0.0
+        sampler = PowerSampler(dev.index or 0)
+        sampler.start()
         while ms_tot < 2000.0 and n_sus < 4_000_000:
             ms_tot += event_ms(torch, lambda: prog.run_block(x, state=state, out=y, variant=variant), batch) * batch
             n_sus += batch
         ms_sus = ms_tot / n_sus
         sustained = {"launches": n_sus, "seconds": round(ms_tot / 1e3, 3), "avg_launch_ms": round(ms_sus, 4),
-                     "achieved_GBs": round(b_alg / ms_sus / 1e6, 1), "frac": round(b_alg / ms_sus / 1e6 / HBM_PEAK_GBS, 4)}
+                     "achieved_GBs": round(b_alg / ms_sus / 1e6, 1), "frac": round(b_alg / ms_sus / 1e6 / HBM_PEAK_GBS, 4),
+                     "board": sampler.stop()}
 
     # copy-kernel yardstick (same bytes in + out), rank 0 only
     copy_gbs = None

@@ -30,6 +30,8 @@ def test_bench_json_contract_small_workload():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["parity"].startswith("bitwise-equal")
     assert d["roofline"]["sustained"]["seconds"] >= 1.9 and d["roofline"]["sustained"]["frac"] > 0
+    board = d["roofline"]["sustained"]["board"]        # rocm-smi during the sustained leg (best effort: None without rocm-smi)
+    assert board is None or (board["package_W"] > 0 and board["sclk_MHz"] > 0 and board["samples"] >= 1)
     assert "traffic_kernel" in d["roofline"]
     for k in ("config2_65536_streams", "cascade6_32768_streams", "cascade6_16384_streams", "config3_par4_sum", "config3_par4_sum_fanout", "config4_osc_chain"):
         assert d[k]["parity"].startswith("bitwise-equal"), (k, d[k]["parity"])
