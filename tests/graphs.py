@@ -118,3 +118,32 @@ def one_pole_modulated():
 def modulated_mix():
     """two modulators in a non-recursive / recursive mix: (m0*_1 + m1*_1[_2]) |= ~(0.5*_1[_1] + m1*_2)"""
     return seq(add(mul(mod(0), IN(1)), mul(mod(1), DEL(1, 2))), fb(add(mul(lit(0.5), DEL(1, 1)), mul(mod(1), IN(2)))))
+
+
+def canonical_shape_bodies():
+    """The bodies X of the unary feedbacks ~X whose canonical (binary-feedback) TYPE the reference checks in test/tests.cpp:26-60.
+    This library has no such type-level transform -- fz_feedback orders the loop by a delay-breaking topological sort -- so what is
+    checked for these expressions is behaviour: ~X lowers (or is refused) exactly as the oracle has it, and computes the same bits."""
+    _1, _2 = IN(1), IN(2)
+    d11, d21 = DEL(1, 1), DEL(2, 1)
+    return {
+        "t26_delay": d11,
+        "t27_wire_then_delay": seq(_1, d11),
+        "t29_left_nested_wires": seq(seq_left(_1, _1), d11),
+        "t30_right_nested_wires": seq(_1, seq(_1, d11)),
+        "t32_two_delayed_pairs": seq_left(seq(_1, d11), seq(_1, d11)),
+        "t33_delay_between_wires": seq_left(seq(_1, d11, _1), d11),
+        "t34_wire_then_chain": seq_left(_1, seq(d11, _1, d11)),
+        "t36_delay_plus_input": seq(_1, add(d11, _2)),
+        "t37_offset_then_delay_plus_input": seq(add(_1, lit(2.0)), add(d11, _2)),
+        "t38_offset_delay_minus_const": seq(add(_1, lit(2.0)), add(sub(d11, lit(13.0)), _2)),
+        "t40_sum_delay_fanout": seq(add(_1, _2), d11, chan(_1, _1)),
+        "t42_second_wire": seq(_2, _1),
+        "t43_second_wire_two_delays": seq(_2, add(d11, d21)),
+        "t44_second_wire_wire_two_delays": seq(_2, _1, add(d11, d21)),
+        "t46_sum_then_delay": seq(add(_1, _2), d11),
+        "t51_fanout_two_delays": seq(chan(_1, _1), add(d11, d21)),
+        "t52_fanout_sum_delay": seq(chan(_1, _1), add(_1, _2), d11),
+        "t57_nested_two_delays": fb(add(d11, d21)),
+        "t59_delay_into_nested": seq(d11, fb(add(d11, _2))),
+    }

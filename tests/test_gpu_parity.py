@@ -128,6 +128,25 @@ def test_graphs_vs_oracle_ragged(torch_cuda, F, name, P):
     assert ndiff(got, want) == 0
 
 
+@pytest.mark.parametrize("name", sorted(G.canonical_shape_bodies()))
+def test_feedback_expressions_of_the_canonical_shape_tests(torch_cuda, F, name):
+    """~X for every X of test/tests.cpp:26-60 (there: the TYPE un2bin gives the expression; here: what it computes -- no transform
+    of that kind exists in this library, see tests/graphs.py:canonical_shape_bodies): time-major with two streams per lane and
+    stream-major frames against the oracle."""
+    g = G.fb(G.canonical_shape_bodies()[name])
+    prog = F.compile(F.from_sexpr(g))
+    ns, T = 70, 52
+    assert (prog.n_in, prog.n_out) == (O.input_arity(g), O.output_arity(g))
+    x = O.synth_input(SEED + 7, np.arange(ns), T, n_wires=prog.n_in)
+    want = O.compile(g, ns).run(x)
+    got, _ = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(2, 4))
+    assert ndiff(got, want) == 0
+    if prog.n_in:                                     # (the autonomous ones have no [stream][t] buffer to come in through)
+        xs = torch_cuda.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))).cuda()
+        ys, _ = prog.run_block_stream_major(xs)
+        assert ndiff(ys.permute(1, 0, 2).contiguous().cpu().numpy(), want) == 0
+
+
 @pytest.mark.parametrize("U", [1, 3, 4, 16, 32])
 def test_unroll_variants_agree_with_oracle(torch_cuda, F, U):
     g = G.df1_cascade(3)

@@ -97,6 +97,19 @@ def test_lowering_vs_oracle(name):
     assert same(got, want)
 
 
+@pytest.mark.parametrize("name", sorted(G.canonical_shape_bodies()))
+def test_feedback_expressions_of_the_canonical_shape_tests_lower_like_the_oracle(name):
+    """test/tests.cpp:26-60 checks the canonical TYPE of ~X (un2bin: the split into a direct and a delayed part); this library orders
+    a feedback loop by a delay-breaking topological sort instead, so the check is behavioural: same arities, same bits."""
+    g = G.fb(G.canonical_shape_bodies()[name])
+    p = F.compile(F.from_sexpr(g))
+    assert (p.n_in, p.n_out) == (O.input_arity(g), O.output_arity(g))
+    ns, T = 3, 40
+    x = O.synth_input(13, np.arange(ns), T, n_wires=max(p.n_in, 1))
+    got, _ = run_ir(p, x)
+    assert same(got, O.compile(g, ns).run(x))
+
+
 def test_lowering_osc_chain_with_stream_params():
     g = G.osc_chain(6)
     p = F.compile(F.from_sexpr(g))
@@ -419,6 +432,34 @@ def test_no_headline_kernel_uses_scratch_memory_and_unroll_is_lowered_until_noth
     assert given["scratch_bytes"] > 0 and given["unroll"] == 16
     assert run["scratch_bytes"] == 0 and run["unroll"] == 8 and run["vgprs"] < 512
     assert p.kernel_name(v, 200, 61).startswith("fz_block_kernel_p4u8b256")
+
+
+def test_kernels_are_built_by_the_rocm_installations_compiler_whatever_the_host_process_loaded(tmp_path):
+    """A process that imported PyTorch first is bound to the hiprtc / comgr bundled with the wheel (an older ROCm): the library then
+    builds with the installation's own compiler in a link-map namespace of its own -- same code objects as a process without
+    torch (found by comparing the four-streams-per-lane headline kernel, which the wheel's compiler cannot fit in 128 registers)."""
+    import subprocess
+    import sys
+    prog = (
+        "import os, sys, hashlib\n"
+        "sys.path.insert(0, %r)\n"
+        "if sys.argv[1] == 'torch': import torch\n"
+        "from zignal_amd import flowz as F, workloads as G, _capi as C\n"
+        "p = F.compile(F.from_sexpr(G.df1_cascade(6)))\n"
+        "v = F.make_variant(4, 1, 1024, C.FZ_VF_LOCKSTEP | C.FZ_VF_GRID_SYNC | C.FZ_VF_PREFETCH3)\n"
+        "r = p.kernel_resources(v, 1 << 20, 4096, as_launched=False)\n"
+        "f = [n for n in os.listdir(os.environ['FLOWZ_HIP_CACHE']) if n.endswith('.hsaco')]\n"
+        "print(r['scratch_bytes'], r['vgprs'], p.kernel_name(None, 1 << 20, 4096, 0), f[0], hashlib.sha1(open(os.path.join(os.environ['FLOWZ_HIP_CACHE'], f[0]), 'rb').read()).hexdigest())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for who in ("plain", "torch"):
+        env = dict(os.environ, FLOWZ_HIP_CACHE=str(tmp_path / who), FLOWZ_HIP_NO_PLAN_CACHE="1")
+        env.pop("FLOWZ_HIP_HOST_HIPRTC", None)
+        r = subprocess.run([sys.executable, "-c", prog, who], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[who] = r.stdout.split()
+    assert out["plain"][:3] == ["0", "128", "fz_block_kernel_p4u1b1024f%d" % (F.C.FZ_VF_LOCKSTEP | F.C.FZ_VF_GRID_SYNC | F.C.FZ_VF_PREFETCH3)]
+    assert out["torch"] == out["plain"]                    # same resources, same cache key, byte-identical code object
 
 
 def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorphic_halves():

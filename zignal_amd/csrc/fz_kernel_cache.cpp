@@ -3,6 +3,8 @@
 #include <hip/hiprtc.h>
 
 #include <dlfcn.h>
+#include <limits.h>
+#include <link.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -129,7 +131,7 @@ struct CacheHeader {
    uint64_t size;
    uint64_t hash;
 };
-static const char kCacheMagic[8] = {'F', 'Z', 'K', 'C', '0', '0', '0', '2'};
+static const char kCacheMagic[8] = {'F', 'Z', 'K', 'C', '0', '0', '0', '3'};   // (0002: before the compiler was pinned -- objects of either hiprtc under one name)
 
 static uint64_t fnv1a_bytes(const char* d, size_t n)
 {
@@ -184,29 +186,107 @@ static void cache_store(const std::string& dir, const std::string& path, const s
    if (!ok || ::rename(tmp.c_str(), path.c_str()) != 0) ::unlink(tmp.c_str());
 }
 
+// ---- which hiprtc compiles the kernels ----------------------------------------------------------------------------------
+// The library links libhiprtc.so.7 of the ROCm installation it was built against.  A host process that has ANOTHER copy with that
+// soname loaded already -- a PyTorch wheel bundles the ROCm release it was built with, hiprtc and comgr (the compiler) included --
+// binds us to that copy instead, and the code then depends on who imported what first: the wheel's older compiler needs 22 more
+// registers for the four-streams-per-lane headline kernel, which therefore "has scratch" and the library steps down to two
+// (0.73 instead of 0.77 of peak), and what it builds lands in the cache under the same name as what `build()` pre-built.
+// So: when the hiprtc we are bound to is not the installation's, the installation's own is loaded into a link-map namespace of
+// its own (dlmopen: its dlopen("libamd_comgr.so.3") then resolves inside that namespace, to the comgr next to it) and used for
+// every build.  FLOWZ_HIP_HOST_HIPRTC=1 keeps the host's; if the private copy cannot be loaded the host's is used and the cache
+// keys say so ("foreign"), so that such code objects never stand in for the installation's.
+#ifndef FZ_ROCM_LIB_DIR
+#define FZ_ROCM_LIB_DIR "/opt/rocm/lib"
+#endif
+struct Rtc {
+   decltype(&hiprtcCreateProgram) create = &hiprtcCreateProgram;
+   decltype(&hiprtcCompileProgram) compile = &hiprtcCompileProgram;
+   decltype(&hiprtcGetProgramLogSize) log_size = &hiprtcGetProgramLogSize;
+   decltype(&hiprtcGetProgramLog) log = &hiprtcGetProgramLog;
+   decltype(&hiprtcGetCodeSize) code_size = &hiprtcGetCodeSize;
+   decltype(&hiprtcGetCode) code = &hiprtcGetCode;
+   decltype(&hiprtcDestroyProgram) destroy = &hiprtcDestroyProgram;
+   decltype(&hiprtcGetErrorString) error_string = &hiprtcGetErrorString;
+   decltype(&hiprtcVersion) version = &hiprtcVersion;
+   std::string identity;                               // part of every cache key
+   std::string path;                                   // the library the entry points come from
+   bool isolated = false;
+};
+
+static std::string real_path(const std::string& p)
+{
+   char buf[PATH_MAX];
+   return ::realpath(p.c_str(), buf) ? std::string(buf) : p;
+}
+
+static const Rtc& rtc()
+{
+   static const Rtc r = [] {
+      Rtc t;
+      Dl_info info;
+      const std::string bound = dladdr((const void*)&hiprtcCompileProgram, &info) && info.dli_fname ? real_path(info.dli_fname) : std::string("?");
+      const std::string ours = real_path(std::string(FZ_ROCM_LIB_DIR) + "/libhiprtc.so.7");
+      t.path = bound;
+      bool foreign = bound != ours && ::access(ours.c_str(), R_OK) == 0;
+      if (foreign && !std::getenv("FLOWZ_HIP_HOST_HIPRTC")) {
+         if (void* h = dlmopen(LM_ID_NEWLM, ours.c_str(), RTLD_NOW | RTLD_LOCAL)) {
+            Rtc iso;
+#define FZ_RTC_SYM(field, name) iso.field = reinterpret_cast<decltype(iso.field)>(dlsym(h, name))
+            FZ_RTC_SYM(create, "hiprtcCreateProgram");
+            FZ_RTC_SYM(compile, "hiprtcCompileProgram");
+            FZ_RTC_SYM(log_size, "hiprtcGetProgramLogSize");
+            FZ_RTC_SYM(log, "hiprtcGetProgramLog");
+            FZ_RTC_SYM(code_size, "hiprtcGetCodeSize");
+            FZ_RTC_SYM(code, "hiprtcGetCode");
+            FZ_RTC_SYM(destroy, "hiprtcDestroyProgram");
+            FZ_RTC_SYM(error_string, "hiprtcGetErrorString");
+            FZ_RTC_SYM(version, "hiprtcVersion");
+#undef FZ_RTC_SYM
+            if (iso.create && iso.compile && iso.log_size && iso.log && iso.code_size && iso.code && iso.destroy && iso.error_string && iso.version) {
+               iso.path = ours;
+               iso.isolated = true;
+               t = iso;
+               foreign = false;
+            }
+         } else if (std::getenv("FLOWZ_HIP_DEBUG")) {
+            std::fprintf(stderr, "[flowz_hip] dlmopen(%s): %s -- building with the host process's hiprtc (%s)\n", ours.c_str(), dlerror(), bound.c_str());
+         }
+      }
+      int major = 0, minor = 0;
+      t.version(&major, &minor);
+      t.identity = "hiprtc" + std::to_string(major) + "." + std::to_string(minor) + (foreign ? "|foreign:" + bound : std::string());
+      if (std::getenv("FLOWZ_HIP_DEBUG"))
+         std::fprintf(stderr, "[flowz_hip] kernels are built by %s%s\n", t.path.c_str(), t.isolated ? " (in a link-map namespace of its own: the host process is bound to another hiprtc)" : "");
+      return t;
+   }();
+   return r;
+}
+
 static std::vector<char> jit_compile(const Graph& g, const Variant& v)
 {
    const std::string cfg = gen_config(g, v), body = gen_body(g, v);
    const char* headers[2] = {cfg.c_str(), body.c_str()};
    const char* names[2] = {"fz_graph_config.h", "fz_graph_body.h"};
+   const Rtc& R = rtc();
    hiprtcProgram prog;
-   if (hiprtcCreateProgram(&prog, skeleton_source(), "fz_block_kernel.hip", 2, headers, names) != HIPRTC_SUCCESS)
+   if (R.create(&prog, skeleton_source(), "fz_block_kernel.hip", 2, headers, names) != HIPRTC_SUCCESS)
       fail(FZ_E_COMPILE, "hiprtcCreateProgram failed");
    std::vector<const char*> opts = build_options(v);
-   hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+   hiprtcResult r = R.compile(prog, (int)opts.size(), opts.data());
    if (r != HIPRTC_SUCCESS) {
       size_t n = 0;
-      hiprtcGetProgramLogSize(prog, &n);
+      R.log_size(prog, &n);
       std::string log(n, ' ');
-      if (n) hiprtcGetProgramLog(prog, &log[0]);
-      hiprtcDestroyProgram(&prog);
-      fail(FZ_E_COMPILE, std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log);
+      if (n) R.log(prog, &log[0]);
+      R.destroy(&prog);
+      fail(FZ_E_COMPILE, std::string("hiprtc: ") + R.error_string(r) + "\n" + log);
    }
    size_t n = 0;
-   hiprtcGetCodeSize(prog, &n);
+   R.code_size(prog, &n);
    std::vector<char> code(n);
-   hiprtcGetCode(prog, code.data());
-   hiprtcDestroyProgram(&prog);
+   R.code(prog, code.data());
+   R.destroy(&prog);
    return code;
 }
 
@@ -270,9 +350,7 @@ static std::string cache_file_of(const fz_program* p, const Variant& v)
 {
    std::string key_src = full_source(p->g, v);
    for (const char* o : build_options(v)) key_src += o;
-   int rtc_major = 0, rtc_minor = 0;
-   hiprtcVersion(&rtc_major, &rtc_minor);
-   key_src += "hiprtc" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor);
+   key_src += rtc().identity;                           // hiprtc version (+ "foreign" when the host process's compiler had to do)
    char name[64];
    std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)fnv1a(key_src));
    return name;

@@ -481,47 +481,67 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
    float best_ms = 0.f, default_ms = 0.f;
    int best = -1;
    std::string first_error;
-   // the default is measured twice: the first pass only brings the clocks and the memory system up to
-   // speed (whoever runs first would otherwise look slower than it is)
-   for (size_t cc = 0; cc <= cands.size(); ++cc) {
-      const bool warmup = cc == 0;
-      const size_t c = warmup ? 0 : cc - 1;
-      try {
-         if (implicit && c != 0 && !kernel_at_hand(p, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams, false))) continue;
-         // (a candidate that would run from scratch memory even with its unroll lowered -- a 1024-lane lockstep workgroup of a
-         //  register-heavy graph -- is not measured: no kernel of this library runs from scratch, see DESIGN "Register budget")
-         if (c != 0 && get_kernel(p, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams), nullptr)->res.scratch_bytes != 0) continue;
-         launch(p, in, out, state, params, n_streams, n_samples, &cands[c], stream, tile_streams);   // build, load, first touch
-         // one launch to size the measurement (>= ~25 ms of kernel time: sub-millisecond kernels need
-         // dozens of launches before their timing settles), then the measurement proper
-         float ms = 0.f;
-         int reps = 1;
-         for (int pass = 0; pass < 2; ++pass) {
-            FZ_HIP(hipEventRecord(e0, (hipStream_t)stream));
-            for (int r = 0; r < reps; ++r) launch(p, in, out, state, params, n_streams, n_samples, &cands[c], stream, tile_streams);
-            FZ_HIP(hipEventRecord(e1, (hipStream_t)stream));
-            FZ_HIP(hipEventSynchronize(e1));
-            FZ_HIP(hipEventElapsedTime(&ms, e0, e1));
-            ms /= (float)reps;
-            if (pass == 0) reps = std::max(3, std::min(100, (int)(25.f / std::max(ms, 1e-3f))));
+   // The boards are power-managed: a kernel that sits at the package power cap (the 6-biquad cascade at 1 M streams does,
+   // profiles/r03/power_and_clocks.txt) runs its first hundred milliseconds at a higher clock than it sustains, so whoever is
+   // measured first looks faster than it is.  Hence: a warm-up of the default (>= 100 ms), then TWO passes over the candidates,
+   // forwards and backwards -- every candidate is measured at the same mean position -- and the two times of a candidate averaged.
+   std::vector<int> reps_of(cands.size(), 0);                       // 0: not measured (not at hand / not allowed / scratch)
+   std::vector<float> ms_sum(cands.size(), 0.f);
+   auto timed = [&](size_t c, int reps) {
+      float ms = 0.f;
+      FZ_HIP(hipEventRecord(e0, (hipStream_t)stream));
+      for (int r = 0; r < reps; ++r) launch(p, in, out, state, params, n_streams, n_samples, &cands[c], stream, tile_streams);
+      FZ_HIP(hipEventRecord(e1, (hipStream_t)stream));
+      FZ_HIP(hipEventSynchronize(e1));
+      FZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+      return ms / (float)reps;
+   };
+   const bool log = std::getenv("FLOWZ_HIP_DEBUG") || std::getenv("FLOWZ_HIP_TUNE_LOG");
+   for (int pass = 0; pass < 2; ++pass) {
+      for (size_t k = 0; k < cands.size(); ++k) {
+         const size_t c = pass == 0 ? k : cands.size() - 1 - k;
+         if (pass == 1 && reps_of[c] == 0) continue;
+         try {
+            if (pass == 0) {
+               if (implicit && c != 0 && !kernel_at_hand(p, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams, false))) continue;
+               // (a candidate that would run from scratch memory even with its unroll lowered -- a 1024-lane lockstep workgroup of a
+               //  register-heavy graph -- is not measured: no kernel of this library runs from scratch, see DESIGN "Register budget")
+               if (c != 0 && get_kernel(p, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams), nullptr)->res.scratch_bytes != 0) continue;
+               launch(p, in, out, state, params, n_streams, n_samples, &cands[c], stream, tile_streams);   // build, load, first touch
+               // one launch to size the measurement (>= ~25 ms of kernel time: sub-millisecond kernels need dozens of launches
+               // before their timing settles)
+               const float ms1 = timed(c, 1);
+               reps_of[c] = std::max(3, std::min(100, (int)(25.f / std::max(ms1, 1e-3f))));
+               if (c == 0) {                                          // the warm-up: clocks and memory system up to speed, power settled
+                  const int wreps = std::max(reps_of[c], std::min(400, (int)(100.f / std::max(ms1, 1e-3f))));
+                  const float wms = timed(c, wreps);
+                  if (log) std::fprintf(stderr, "[flowz_hip] tune warm-up: %d launches of the default, %.4f ms each\n", wreps, wms);
+               }
+            }
+            const float ms = timed(c, reps_of[c]);
+            ms_sum[c] += ms;
+            if (log)
+               std::fprintf(stderr, "[flowz_hip] tune %s n_streams=%llu tile=%u: P=%u U=%u block=%u flags=%u: %.4f ms (pass %d)\n",
+                            kernel_name(g, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams)).c_str(), (unsigned long long)n_streams,
+                            tile_streams, cands[c].streams_per_lane, cands[c].unroll, cands[c].block_threads, cands[c].flags, ms, pass + 1);
+         } catch (const Error& er) {                          // a candidate this graph / shape does not allow
+            if (er.code == FZ_E_HIP || er.code == FZ_E_NO_DEVICE) {
+               (void)hipEventDestroy(e0);
+               (void)hipEventDestroy(e1);
+               throw;
+            }
+            reps_of[c] = 0;
+            if (first_error.empty()) first_error = er.msg;
          }
-         if (std::getenv("FLOWZ_HIP_DEBUG") || std::getenv("FLOWZ_HIP_TUNE_LOG"))
-            std::fprintf(stderr, "[flowz_hip] tune %s n_streams=%llu tile=%u: P=%u U=%u block=%u flags=%u: %.4f ms%s\n",
-                         kernel_name(g, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams)).c_str(), (unsigned long long)n_streams,
-                         tile_streams, cands[c].streams_per_lane, cands[c].unroll, cands[c].block_threads, cands[c].flags, ms,
-                         warmup ? " (warm-up pass)" : "");
-         if (!warmup && c == 0) default_ms = ms;
-         if (!warmup && (best < 0 || ms < best_ms)) {
-            best = (int)c;
-            best_ms = ms;
-         }
-      } catch (const Error& er) {                          // a candidate this graph / shape does not allow
-         if (er.code == FZ_E_HIP || er.code == FZ_E_NO_DEVICE) {
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
-            throw;
-         }
-         if (first_error.empty()) first_error = er.msg;
+      }
+   }
+   for (size_t c = 0; c < cands.size(); ++c) {
+      if (reps_of[c] == 0) continue;
+      const float ms = 0.5f * ms_sum[c];
+      if (c == 0) default_ms = ms;
+      if (best < 0 || ms < best_ms) {
+         best = (int)c;
+         best_ms = ms;
       }
    }
    (void)hipEventDestroy(e0);
