@@ -434,32 +434,48 @@ def test_no_headline_kernel_uses_scratch_memory_and_unroll_is_lowered_until_noth
     assert p.kernel_name(v, 200, 61).startswith("fz_block_kernel_p4u8b256")
 
 
-def test_kernels_are_built_by_the_rocm_installations_compiler_whatever_the_host_process_loaded(tmp_path):
-    """A process that imported PyTorch first is bound to the hiprtc / comgr bundled with the wheel (an older ROCm): the library then
-    builds with the installation's own compiler in a link-map namespace of its own -- same code objects as a process without
-    torch (found by comparing the four-streams-per-lane headline kernel, which the wheel's compiler cannot fit in 128 registers)."""
+def test_code_objects_carry_their_compiler_and_the_installations_are_preferred(tmp_path):
+    """A process that imported PyTorch first is bound to the hiprtc / comgr bundled with the wheel (an older ROCm whose code
+    for the four-streams-per-lane headline kernel needs scratch memory).  (1) What such a process builds is cached under a
+    name of its own, and an object the installation's compiler built (build() pre-builds them in a process without torch) is
+    found first.  (2) FLOWZ_HIP_ISOLATED_HIPRTC=1: the installation's compiler in a link-map namespace of its own --
+    byte-identical code objects with and without torch."""
+    import hashlib
     import subprocess
     import sys
     prog = (
-        "import os, sys, hashlib\n"
+        "import os, sys\n"
         "sys.path.insert(0, %r)\n"
-        "if sys.argv[1] == 'torch': import torch\n"
+        "if sys.argv[1] != 'plain': import torch\n"
         "from zignal_amd import flowz as F, workloads as G, _capi as C\n"
         "p = F.compile(F.from_sexpr(G.df1_cascade(6)))\n"
         "v = F.make_variant(4, 1, 1024, C.FZ_VF_LOCKSTEP | C.FZ_VF_GRID_SYNC | C.FZ_VF_PREFETCH3)\n"
         "r = p.kernel_resources(v, 1 << 20, 4096, as_launched=False)\n"
-        "f = [n for n in os.listdir(os.environ['FLOWZ_HIP_CACHE']) if n.endswith('.hsaco')]\n"
-        "print(r['scratch_bytes'], r['vgprs'], p.kernel_name(None, 1 << 20, 4096, 0), f[0], hashlib.sha1(open(os.path.join(os.environ['FLOWZ_HIP_CACHE'], f[0]), 'rb').read()).hexdigest())\n"
+        "print(r['scratch_bytes'], r['vgprs'], p.kernel_name(None, 1 << 20, 4096, 0))\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = {}
-    for who in ("plain", "torch"):
-        env = dict(os.environ, FLOWZ_HIP_CACHE=str(tmp_path / who), FLOWZ_HIP_NO_PLAN_CACHE="1")
-        env.pop("FLOWZ_HIP_HOST_HIPRTC", None)
+    want = ["0", "128", "fz_block_kernel_p4u1b1024f%d" % (F.C.FZ_VF_LOCKSTEP | F.C.FZ_VF_GRID_SYNC | F.C.FZ_VF_PREFETCH3)]
+
+    def run(who, cache, **extra):
+        env = dict(os.environ, FLOWZ_HIP_CACHE=str(tmp_path / cache), FLOWZ_HIP_NO_PLAN_CACHE="1", **extra)
+        if "FLOWZ_HIP_ISOLATED_HIPRTC" not in extra:
+            env.pop("FLOWZ_HIP_ISOLATED_HIPRTC", None)
         r = subprocess.run([sys.executable, "-c", prog, who], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        out[who] = r.stdout.split()
-    assert out["plain"][:3] == ["0", "128", "fz_block_kernel_p4u1b1024f%d" % (F.C.FZ_VF_LOCKSTEP | F.C.FZ_VF_GRID_SYNC | F.C.FZ_VF_PREFETCH3)]
-    assert out["torch"] == out["plain"]                    # same resources, same cache key, byte-identical code object
+        files = {n: hashlib.sha1(open(tmp_path / cache / n, "rb").read()).hexdigest() for n in os.listdir(tmp_path / cache) if n.endswith(".hsaco")}
+        return r.stdout.split(), files
+
+    # the wheel's compiler on its own: the headline kernel does not fit, the default steps down -- under names of its own
+    torch_out, torch_files = run("torch", "a")
+    plain_out, plain_files = run("plain", "b")
+    assert plain_out == want
+    if torch_out != want:                                       # (a wheel built with the installation's ROCm would not differ)
+        assert int(torch_out[0]) > 0 and torch_out[2] != want[2] and not set(torch_files) & set(plain_files)
+        # ... and next to pre-built objects it uses those
+        both_out, both_files = run("torch", "b")
+        assert both_out == want and set(plain_files) <= set(both_files) and all(both_files[n] == h for n, h in plain_files.items())
+    # the isolated compiler: the same names, the same bytes as without torch
+    iso_out, iso_files = run("torch", "c", FLOWZ_HIP_ISOLATED_HIPRTC="1")
+    assert iso_out == want and iso_files == plain_files
 
 
 def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorphic_halves():

@@ -191,11 +191,14 @@ static void cache_store(const std::string& dir, const std::string& path, const s
 // soname loaded already -- a PyTorch wheel bundles the ROCm release it was built with, hiprtc and comgr (the compiler) included --
 // binds us to that copy instead, and the code then depends on who imported what first: the wheel's older compiler needs 22 more
 // registers for the four-streams-per-lane headline kernel, which therefore "has scratch" and the library steps down to two
-// (0.73 instead of 0.77 of peak), and what it builds lands in the cache under the same name as what `build()` pre-built.
-// So: when the hiprtc we are bound to is not the installation's, the installation's own is loaded into a link-map namespace of
-// its own (dlmopen: its dlopen("libamd_comgr.so.3") then resolves inside that namespace, to the comgr next to it) and used for
-// every build.  FLOWZ_HIP_HOST_HIPRTC=1 keeps the host's; if the private copy cannot be loaded the host's is used and the cache
-// keys say so ("foreign"), so that such code objects never stand in for the installation's.
+// (0.73 instead of 0.77 of peak).  Two rules keep that from leaking:
+//  * every cache name carries the identity of the compiler that built the object, and a lookup tries the INSTALLATION's name
+//    first (what `build()` pre-builds in a process of its own), then this process's compiler's name; what a foreign compiler
+//    builds is stored under its own name and never stands in for the installation's;
+//  * FLOWZ_HIP_ISOLATED_HIPRTC=1: the installation's hiprtc is loaded into a link-map namespace of its own (dlmopen: its
+//    dlopen("libamd_comgr.so.3") resolves inside that namespace, to the comgr next to it) and builds everything -- byte-identical
+//    code objects with and without `import torch`.  Opt-in: one of three full GPU test runs with it ended in a segmentation
+//    fault that two more runs and 4000 builds under a backtrace handler did not reproduce.
 #ifndef FZ_ROCM_LIB_DIR
 #define FZ_ROCM_LIB_DIR "/opt/rocm/lib"
 #endif
@@ -220,6 +223,14 @@ static std::string real_path(const std::string& p)
    return ::realpath(p.c_str(), buf) ? std::string(buf) : p;
 }
 
+// the identity of the installation's compiler: "libhiprtc.so.7.2.70200"
+static std::string preferred_identity()
+{
+   const std::string ours = real_path(std::string(FZ_ROCM_LIB_DIR) + "/libhiprtc.so.7");
+   const size_t s = ours.rfind('/');
+   return s == std::string::npos ? ours : ours.substr(s + 1);
+}
+
 static const Rtc& rtc()
 {
    static const Rtc r = [] {
@@ -229,7 +240,8 @@ static const Rtc& rtc()
       const std::string ours = real_path(std::string(FZ_ROCM_LIB_DIR) + "/libhiprtc.so.7");
       t.path = bound;
       bool foreign = bound != ours && ::access(ours.c_str(), R_OK) == 0;
-      if (foreign && !std::getenv("FLOWZ_HIP_HOST_HIPRTC")) {
+      const char* iso_env = std::getenv("FLOWZ_HIP_ISOLATED_HIPRTC");
+      if (foreign && iso_env && *iso_env && std::strcmp(iso_env, "0") != 0) {
          if (void* h = dlmopen(LM_ID_NEWLM, ours.c_str(), RTLD_NOW | RTLD_LOCAL)) {
             Rtc iso;
 #define FZ_RTC_SYM(field, name) iso.field = reinterpret_cast<decltype(iso.field)>(dlsym(h, name))
@@ -253,9 +265,10 @@ static const Rtc& rtc()
             std::fprintf(stderr, "[flowz_hip] dlmopen(%s): %s -- building with the host process's hiprtc (%s)\n", ours.c_str(), dlerror(), bound.c_str());
          }
       }
-      int major = 0, minor = 0;
-      t.version(&major, &minor);
-      t.identity = "hiprtc" + std::to_string(major) + "." + std::to_string(minor) + (foreign ? "|foreign:" + bound : std::string());
+      // identity: the installation's hiprtc by its versioned file name (computable without loading it: see preferred_identity),
+      // any other by path and size
+      struct stat st;
+      t.identity = foreign ? "foreign:" + bound + ":" + std::to_string(::stat(bound.c_str(), &st) == 0 ? (long long)st.st_size : -1LL) : preferred_identity();
       if (std::getenv("FLOWZ_HIP_DEBUG"))
          std::fprintf(stderr, "[flowz_hip] kernels are built by %s%s\n", t.path.c_str(), t.isolated ? " (in a link-map namespace of its own: the host process is bound to another hiprtc)" : "");
       return t;
@@ -346,17 +359,25 @@ Variant settle_variant(fz_program* p, Variant v)
 }
 
 // file name of a variant's code object: a hash of (generated source, build options, hiprtc version)
-static std::string cache_file_of(const fz_program* p, const Variant& v)
+static std::string cache_file_of(const fz_program* p, const Variant& v, const std::string& compiler)
 {
    std::string key_src = full_source(p->g, v);
    for (const char* o : build_options(v)) key_src += o;
-   key_src += rtc().identity;                           // hiprtc version (+ "foreign" when the host process's compiler had to do)
+   key_src += compiler;                                 // who built it (Rtc::identity / preferred_identity)
    char name[64];
    std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)fnv1a(key_src));
    return name;
 }
 
 static bool cache_in_use(const std::string& dir) { return !std::getenv("FLOWZ_HIP_NO_CACHE") && !dir.empty(); }
+
+// lookups: the installation's compiler first (pre-built objects), then whoever compiles in this process
+static std::vector<std::string> compilers_to_look_for()
+{
+   std::vector<std::string> w{preferred_identity()};
+   if (rtc().identity != w[0]) w.push_back(rtc().identity);
+   return w;
+}
 
 bool kernel_at_hand(fz_program* p, const Variant& v)
 {
@@ -367,8 +388,12 @@ bool kernel_at_hand(fz_program* p, const Variant& v)
    }
    const std::string dir = cache_dir(), pkg = package_cache_dir();
    if (!cache_in_use(dir)) return false;
-   const std::string name = cache_file_of(p, v);
-   return ::access((dir + name).c_str(), R_OK) == 0 || (!pkg.empty() && pkg != dir && !std::getenv("FLOWZ_HIP_CACHE") && ::access((pkg + name).c_str(), R_OK) == 0);
+   const bool ro_pkg = !pkg.empty() && pkg != dir && !std::getenv("FLOWZ_HIP_CACHE");
+   for (const std::string& who : compilers_to_look_for()) {
+      const std::string name = cache_file_of(p, v, who);
+      if (::access((dir + name).c_str(), R_OK) == 0 || (ro_pkg && ::access((pkg + name).c_str(), R_OK) == 0)) return true;
+   }
+   return false;
 }
 
 std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out)
@@ -377,14 +402,28 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
    auto& slot = p->kernels[v];
    if (!slot) {
       auto k = std::make_shared<Kernel>();
-      const std::string name = cache_file_of(p, v), dir = cache_dir(), path = dir + name, pkg = package_cache_dir();
+      const std::string dir = cache_dir(), pkg = package_cache_dir(), path = dir + cache_file_of(p, v, rtc().identity);   // (path: where a build of THIS process goes)
       const bool use_cache = cache_in_use(dir);
-      k->cache_path = use_cache ? path : std::string();
       // (a package cache this user cannot write to -- installed by root, pre-filled by build() -- is still read)
       const bool ro_pkg = use_cache && !pkg.empty() && pkg != dir && !std::getenv("FLOWZ_HIP_CACHE");
-      if (!(use_cache && (cache_load(path, k->code) || (ro_pkg && cache_load(pkg + name, k->code, false))))) {
+      bool found = false;
+      if (use_cache)
+         for (const std::string& who : compilers_to_look_for()) {
+            const std::string name = cache_file_of(p, v, who);
+            if (cache_load(dir + name, k->code)) {
+               k->cache_path = dir + name;
+               found = true;
+            } else if (ro_pkg && cache_load(pkg + name, k->code, false)) {
+               found = true;                             // (no cache_path: not ours to delete)
+            }
+            if (found) break;
+         }
+      if (!found) {
          k->code = jit_compile(p->g, v);
-         if (use_cache) cache_store(dir, path, k->code);
+         if (use_cache) {
+            cache_store(dir, path, k->code);
+            k->cache_path = path;
+         }
       }
       k->res = read_resources(k->code);
       slot = k;
@@ -401,11 +440,11 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
                             (er.msg.find("invalid") != std::string::npos || er.msg.find("binary") != std::string::npos ||
                              er.msg.find("image") != std::string::npos || er.msg.find("shared object") != std::string::npos);
          if (slot->cache_path.empty() || !image) throw;
-         const std::string path = slot->cache_path;
-         ::unlink(path.c_str());
+         ::unlink(slot->cache_path.c_str());
          slot->code = jit_compile(p->g, v);
          slot->res = read_resources(slot->code);
-         cache_store(cache_dir(), path, slot->code);
+         slot->cache_path = cache_dir() + cache_file_of(p, v, rtc().identity);   // (under the name of the compiler that built it)
+         cache_store(cache_dir(), slot->cache_path, slot->code);
          *fn_out = slot->function_on_current_device(kernel_name(p->g, v));
       }
    }
