@@ -1537,10 +1537,15 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     monkeypatch.setenv("FLOWZ_HIP_NO_PLAN_CACHE", "1")
     prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
     LG = _capi.FZ_VF_LOCKSTEP | _capi.FZ_VF_GRID_SYNC
-    assert prog.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p4u1b1024f%d" % (LG | _capi.FZ_VF_PREFETCH3)
+    PERSIST = 1 << 27                                            # (internal: more blocks than CUs -> a persistent launch, a kernel of its own)
+    # four streams per lane where their kernel fits the 128 registers of a 1024-lane workgroup: it does with the ROCm installation's
+    # compiler (what build() pre-builds), not with the older one bundled with the PyTorch wheel (this process is bound to that one
+    # for whatever is not in the cache: INTEGRATION.md "Which compiler builds the kernels") -- then the library steps down to two
+    fits4 = prog.kernel_resources(F.make_variant(4, 1, 1024, LG | _capi.FZ_VF_PREFETCH3), 1 << 20, 4096, as_launched=False)["scratch_bytes"] == 0
+    assert prog.kernel_name(None, 1 << 20, 4096, 0) == ("fz_block_kernel_p4u1b1024f%d" % (LG | _capi.FZ_VF_PREFETCH3) if fits4 else
+                                                        "fz_block_kernel_p2u2b1024f%d" % (LG | PERSIST))
     assert prog.kernel_name(None, 1 << 19, 4096, 0) == "fz_block_kernel_p2u2b1024f%d" % LG
     assert prog.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p1u4b1024f%d" % LG
-    PERSIST = 1 << 27                                            # (internal: more blocks than CUs -> a persistent launch, a kernel of its own)
     assert prog.kernel_name(None, 1 << 21, 4096, 0) == "fz_block_kernel_p2u2b1024f%d" % (LG | PERSIST)   # (four streams per lane do not fit the persistent kernel's registers)
     assert prog.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % _capi.FZ_VF_MAX_WG(2)
     assert "b1024" not in prog.kernel_name(None, 1 << 17, 4096, 0)
