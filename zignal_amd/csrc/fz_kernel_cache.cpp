@@ -348,7 +348,15 @@ Variant settle_variant(fz_program* p, Variant v)
    for (;;) {
       const auto k = get_kernel(p, v, nullptr);
       if (k->res.scratch_bytes == 0) return v;
-      if (v.flags & FZ_VF_STREAM_MAJOR) return v;
+      if (v.flags & FZ_VF_STREAM_MAJOR) {
+         // the long-run body with 64-sample phases shares a SIMD between two waves (256 registers each): where that spills (the
+         // ROCm 7.0 compiler: 60 bytes for the 6-biquad cascade) the 128-sample phases of a lone wave (512 registers) run instead
+         if ((v.flags & FZ_VF_SM_LONG) && v.U == 64) {
+            v.U = 128;
+            continue;
+         }
+         return v;
+      }
       if (ws_parts(v.flags) && v.block * ws_waves(v.flags) > 256 && v.block > 64) {
          v.block /= 2;                                   // more than four waves per workgroup cap the registers of a lane at 256: fewer tuples per workgroup first
          continue;
