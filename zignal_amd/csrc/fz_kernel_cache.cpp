@@ -224,11 +224,14 @@ static std::string real_path(const std::string& p)
 }
 
 // the identity of the installation's compiler: "libhiprtc.so.7.2.70200"
-static std::string preferred_identity()
+static const std::string& preferred_identity()
 {
-   const std::string ours = real_path(std::string(FZ_ROCM_LIB_DIR) + "/libhiprtc.so.7");
-   const size_t s = ours.rfind('/');
-   return s == std::string::npos ? ours : ours.substr(s + 1);
+   static const std::string id = [] {
+      const std::string ours = real_path(std::string(FZ_ROCM_LIB_DIR) + "/libhiprtc.so.7");
+      const size_t s = ours.rfind('/');
+      return s == std::string::npos ? ours : ours.substr(s + 1);
+   }();
+   return id;
 }
 
 static const Rtc& rtc()
