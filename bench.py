@@ -274,7 +274,8 @@ class PowerSampler:
         if not rows:
             return None
         med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
-        return {"package_W": med([r[1] for r in rows]), "cap_W": rows[0][2], "sclk_MHz": med([r[3] for r in rows]),
+        watts, cap = med([r[1] for r in rows]), rows[0][2]
+        return {"package_W": watts, "cap_W": cap, "at_power_cap": bool(cap and watts >= 0.98 * cap), "sclk_MHz": med([r[3] for r in rows]),
                 "samples": len(rows), "source": "rocm-smi --showpower --showclocks, median over the sustained leg"}
 
 
