@@ -197,8 +197,8 @@ static void cache_store(const std::string& dir, const std::string& path, const s
 //    builds is stored under its own name and never stands in for the installation's;
 //  * FLOWZ_HIP_ISOLATED_HIPRTC=1: the installation's hiprtc is loaded into a link-map namespace of its own (dlmopen: its
 //    dlopen("libamd_comgr.so.3") resolves inside that namespace, to the comgr next to it) and builds everything -- byte-identical
-//    code objects with and without `import torch`.  Opt-in: one of three full GPU test runs with it ended in a segmentation
-//    fault that two more runs and 4000 builds under a backtrace handler did not reproduce.
+//    code objects with and without `import torch`.  Opt-in: one of five full GPU test runs with it ended in a segmentation
+//    fault that the other four (under a backtrace handler, tools/segv_backtrace.c) and 4000 builds in a fuzz run did not reproduce.
 #ifndef FZ_ROCM_LIB_DIR
 #define FZ_ROCM_LIB_DIR "/opt/rocm/lib"
 #endif
