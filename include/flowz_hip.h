@@ -347,7 +347,9 @@ uint32_t fz_recommended_tile_streams(const fz_program* p);
  * variant == NULL use it.  All variants compute bit-identical results.  The buffers are used as by
  * fz_run_block_tiled (tile_streams 0: time-major) for a few dozen blocks: `out` is overwritten and
  * `state` advances -- reset it afterwards.  chosen / chosen_ms (may be NULL): the winner and its time
- * per block.  Synchronises hip_stream.                                                            */
+ * per block.  Synchronises hip_stream.  (The boards are power-managed -- a kernel at the package power
+ * cap runs its first ~100 ms faster than it sustains --, so the default is run for >= 100 ms first and
+ * every candidate is then timed twice, in a forward and a backward pass over the list.)            */
 int fz_program_tune(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
                     uint32_t n_samples, uint32_t tile_streams, void* hip_stream, fz_variant* chosen, float* chosen_ms);
 
