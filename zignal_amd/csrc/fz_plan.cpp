@@ -547,13 +547,29 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
    (void)hipEventDestroy(e0);
    (void)hipEventDestroy(e1);
    if (best < 0) fail(FZ_E_INVALID, "fz_program_tune: no variant could run: " + first_error);
-   // repeated measurements of one variant scatter by 1-2 %: a candidate replaces the library default only when it wins by more
-   if (best > 0 && default_ms > 0.f && best_ms > 0.985f * default_ms) {
+   // repeated measurements of one variant scatter by 1-2 % (more on a board at its power cap): a candidate replaces the INCUMBENT --
+   // the plan this program already runs this shape with on this device, else the library default -- only when it wins by more
+   int dev = 0;
+   FZ_HIP(hipGetDevice(&dev));
+   int incumbent = 0;
+   {
+      std::lock_guard<std::mutex> lock(p->mu);
+      auto it = p->plans.find(std::make_tuple(n_streams, tile_streams, dev));
+      if (it != p->plans.end())
+         for (size_t c = 1; c < cands.size(); ++c)
+            if (reps_of[c] != 0 && cands[c].streams_per_lane == it->second.streams_per_lane && cands[c].unroll == it->second.unroll &&
+                cands[c].block_threads == it->second.block_threads && cands[c].flags == it->second.flags)
+               incumbent = (int)c;
+   }
+   const float incumbent_ms = reps_of[(size_t)incumbent] != 0 ? 0.5f * ms_sum[(size_t)incumbent] : 0.f;
+   if (best != incumbent && incumbent_ms > 0.f && best_ms > 0.985f * incumbent_ms) {
+      best = incumbent;
+      best_ms = incumbent_ms;
+   }
+   if (best > 0 && default_ms > 0.f && best_ms > 0.985f * default_ms) {   // (and the default is preferred to anything it is level with)
       best = 0;
       best_ms = default_ms;
    }
-   int dev = 0;
-   FZ_HIP(hipGetDevice(&dev));
    {
       std::lock_guard<std::mutex> lock(p->mu);
       if (best == 0) p->plans.erase(std::make_tuple(n_streams, tile_streams, dev));
