@@ -13,7 +13,9 @@ already resident in HBM.  Rank 0 prints ONE JSON line.
              peak = 8000 GB/s (HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md);
              traffic = PMC bytes of THIS kernel symbol on THIS workload (profiles/pmc_traffic.json,
              collected by tools/profile_round.sh), null when that symbol was not profiled;
-             sustained = the same launches back to back for >= 2 s (power-managed clocks settle)
+             sustained = the same launches back to back for >= 2 s (power-managed clocks settle), with
+             sustained.board = package power / power cap / shader clock sampled through rocm-smi meanwhile
+             (this workload runs at the board's power cap: profiles/r03/power_and_clocks.txt)
   cpu_baseline  the compiled scalar oracle (one closure per stream, one call per sample: what
              the reference's compile()-callable does) timed on this box's host cores on a
              bounded sample of the same workload, rank 0, N == 1 only (buffers pre-touched, threads
