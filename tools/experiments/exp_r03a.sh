@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, first exploration: (A) config 2 with three parts + I/O wave at 4 tuples per CU, (B) time-major frames in lockstep, (C) stream-major baseline
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03a; mkdir -p $O
 export FLOWZ_HIP_NO_PLAN_CACHE=1
 python tools/sweep.py --graph cascade6 --streams 65536 --tile 8192 --rounds 30 0,0 1,16,256,8 1,16,64,34816 1,8,64,34816 1,16,64,2048 1,32,64,2048 1,16,0,32768 1,16,128,33792 > $O/config2.txt 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: v_pk_mov_b32 pair assembly in the wave-split rounds -- parity of the wave-split tests, then the few-stream sweeps
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03ai; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "wave or stage_pack or few_streams" > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
 export FLOWZ_HIP_NO_PLAN_CACHE=1 FLOWZ_HIP_AUTOTUNE=0

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: one workgroup per CU for the few-stream kernels (FZ_VF_MAX_WG(1) = 1048576: LDS padding) -- does the dispatcher stack workgroups?
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03aj; mkdir -p $O
 export FLOWZ_HIP_NO_PLAN_CACHE=1 FLOWZ_HIP_AUTOTUNE=0
 M=1048576

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Experiment (GPU box): shader clock and power (rocm-smi) while the FEW-STREAM kernels run back to back for 3 s each."""
 import os, sys, subprocess, threading, time, json, re
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from zignal_amd import workloads as G, flowz as F

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: the step's operations list-scheduled by the generator and pinned (FLOWZ_HIP_PIN_ORDER=1) against the compiler's order
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03al; mkdir -p $O
 export FLOWZ_HIP_NO_PLAN_CACHE=1 FLOWZ_HIP_AUTOTUNE=0
 for pin in 0 1; do

@@ -2,7 +2,7 @@
 """Experiment (GPU box): 4096-sample blocks of few streams back to back -- eager launches against one captured hipGraph of 20 of them
 (HIP events around both)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from zignal_amd import workloads as G, flowz as F

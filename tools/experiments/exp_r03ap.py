@@ -2,7 +2,7 @@
 """Experiment (GPU box): power / clock / time of the cascade kernels with their frame traffic sent through zero-byte descriptors
 (FLOWZ_HIP_EXTRA_OPTS="-DFZ_DBG_NOLOAD -DFZ_DBG_NOSTORE"): what the arithmetic (+ LDS transposition) costs without HBM."""
 import os, sys, subprocess, threading, time, json, re
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from zignal_amd import workloads as G, flowz as F

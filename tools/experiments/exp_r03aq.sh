@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: more rows in flight for the synchronised time-major walk -- 512-lane workgroups (256 registers per lane), two laps
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03aq; mkdir -p $O
 export FLOWZ_HIP_NO_PLAN_CACHE=1 FLOWZ_HIP_AUTOTUNE=0
 L=524288; G=8388608; PF=32

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, second exploration: wave splits with the tuple-major / rotated role map; time-major frames in lockstep (block x P x U)
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03b; mkdir -p $O
 export FLOWZ_HIP_NO_PLAN_CACHE=1
 python tools/sweep.py --graph cascade6 --streams 65536 --tile 8192 --rounds 30 0,0 1,16,256,34816 1,8,256,34816 1,16,128,34816 1,16,64,34816 1,16,256,33792 1,16,128,33792 1,16,0,32768 1,16,256,2048 > $O/config2.txt 2>&1

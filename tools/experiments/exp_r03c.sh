@@ -2,7 +2,7 @@
 # round 3, third exploration: time-major lockstep refinement (rows in flight, prefetch distance, XCD map), other stream counts and a
 # 4-wire graph; the launch bubble of config 2 (block length scan)
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03c; mkdir -p $O
 export FLOWZ_HIP_NO_PLAN_CACHE=1
 L=524288

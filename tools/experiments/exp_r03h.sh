@@ -2,7 +2,7 @@
 # round 3: do the CUs of a launch drift apart on time-major frames?  the lockstep kernel on blocks of 128 ... 4096 samples
 # (a short block gives the workgroups no time to drift), and the old default next to it
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03h; mkdir -p $O
 export FLOWZ_HIP_NO_PLAN_CACHE=1 FLOWZ_HIP_AUTOTUNE=0
 for T in 128 256 512 1024 2048 4096; do

@@ -2,7 +2,7 @@
 # round 3: cache policies of the frame loads / stores for the time-major lockstep kernel (flags bits 12..14 loads, 16..18 stores:
 # 1 = none, 2 = sc0, 3 = sc1, 4 = sc0 sc1, 5 = sc0 nt, 6 = sc1 nt, 7 = nt)
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03l; mkdir -p $O
 export FLOWZ_HIP_NO_PLAN_CACHE=1 FLOWZ_HIP_AUTOTUNE=0
 B=$((524288+32))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: per-XCD synchronisation of the lockstep workgroups (FZ_VF_GRID_SYNC = 8388608): time-major and tiled frames, stream counts
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03n; mkdir -p $O
 export FLOWZ_HIP_NO_PLAN_CACHE=1 FLOWZ_HIP_AUTOTUNE=0
 python - > $O/parity.txt 2>&1 <<'PY'

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: XCD-synchronised lockstep workgroups on stream tiles of various sizes (is a tile of one XCD's worth of streams better than plain rows?)
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03p; mkdir -p $O
 export FLOWZ_HIP_NO_PLAN_CACHE=1 FLOWZ_HIP_AUTOTUNE=0
 G=8388608; L=524288; V4=$((L+32+G)); V2=$((L+G))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: persistent launch + XCD-wide synchronisation beyond one lap and on the other HBM-bound kernels
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03r; mkdir -p $O
 export FLOWZ_HIP_NO_PLAN_CACHE=1 FLOWZ_HIP_AUTOTUNE=0
 python - > $O/parity.txt 2>&1 <<'PY'

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: what do the barriers of the wave-split rounds cost?  (-DFZ_DBG_NOBARRIER: wrong results, time only)
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03w; mkdir -p $O
 export FLOWZ_HIP_NO_PLAN_CACHE=1 FLOWZ_HIP_AUTOTUNE=0
 for mode in base nobar; do

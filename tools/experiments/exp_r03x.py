@@ -3,7 +3,7 @@
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["FLOWZ_HIP_EXTRA_OPTS"] = (os.environ.get("FLOWZ_HIP_EXTRA_OPTS", "") + " -DFZ_DBG_PHASE_CLOCKS").strip()
 import torch  # noqa: E402
