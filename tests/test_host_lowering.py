@@ -241,6 +241,19 @@ def test_product_fails_loudly_without_gpu():
     assert "no CPU fallback" in _capi.last_error()
 
 
+def test_argument_checks_do_not_depend_on_assert_statements():
+    """The Python mirror hands raw pointers to the C ABI: its shape / dtype / device checks must survive `python -O`
+    (ADVICE round 2), so none of them may be an `assert`; a host tensor is refused before anything is launched."""
+    import torch
+    src = open(os.path.join(ROOT, "zignal_amd", "flowz.py")).read()
+    assert not [ln for ln in src.splitlines() if ln.lstrip().startswith("assert ")]
+    p = F.compile(F.from_sexpr(G.df1()))
+    with pytest.raises(F.NoDeviceError):
+        p.run_block(torch.zeros((8, 64, 1)))
+    with pytest.raises(F.FlowzError):
+        p.run_window(torch.zeros((8, 64, 1)), torch.zeros((8, 64, 1)), torch.zeros((p.n_state, 64)), 0, 4)
+
+
 def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "zignal_amd")):
         for f in files:

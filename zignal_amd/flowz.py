@@ -204,6 +204,12 @@ def make_variant(streams_per_lane=0, unroll=0, block_threads=0, flags=0) -> Vari
     return Variant(int(streams_per_lane), int(unroll), int(block_threads), int(flags))
 
 
+def _require(ok, what):
+    """Argument check that survives `python -O` (the C ABI takes raw pointers: a wrong shape is an out-of-bounds access)."""
+    if not ok:
+        raise FlowzError(C.FZ_E_INVALID, str(what))
+
+
 def _check_dev(t, shape, what, dtype=None):
     """A caller-supplied device buffer handed to the C ABI as a raw pointer: float32 (or `dtype`), CUDA, contiguous and of
     exactly the shape the kernel will address -- anything else would be a silent out-of-bounds device access."""
@@ -214,6 +220,18 @@ def _check_dev(t, shape, what, dtype=None):
         raise FlowzError(C.FZ_E_INVALID, f"{what}: expected a contiguous CUDA {dtype} tensor of shape {tuple(shape)}, got "
                                          f"{t.dtype} {tuple(t.shape)} on {t.device}" + ("" if t.is_contiguous() else " (not contiguous)"))
     return t
+
+
+def _check_frames(x, last, what="x"):
+    """Input frames handed over as a raw pointer: contiguous float32 CUDA tensor whose last axis is the wire count."""
+    import torch
+
+    if not x.is_cuda:
+        raise NoDeviceError(C.FZ_E_NO_DEVICE, f"{what}: needs CUDA (ROCm) tensors: zignal_amd has no CPU path")
+    if not (x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == last):
+        raise FlowzError(C.FZ_E_INVALID, f"{what}: expected contiguous float32 frames with {last} wire(s) on the last axis, got "
+                                         f"{x.dtype} {tuple(x.shape)}" + ("" if x.is_contiguous() else " (not contiguous)"))
+    return x
 
 
 class Program:
@@ -411,7 +429,7 @@ class Program:
         more samples than the block): fz_run_block_window.  state advances; params as for run_block."""
         import torch
 
-        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == max(self.n_in, 1)
+        _check_frames(x, max(self.n_in, 1))
         if x.dim() == 4:
             n_tiles, rows, tile, _ = x.shape
             ns = n_tiles * tile
@@ -439,7 +457,7 @@ class Program:
 
         if x.dim() == 2:
             x = x.unsqueeze(-1)
-        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == max(self.n_in, 1)
+        _check_frames(x, max(self.n_in, 1))
         ns, rows, _ = x.shape
         n = rows - row0 if n_samples is None else int(n_samples)
         if out is None:
@@ -467,7 +485,7 @@ class Program:
             raise NoDeviceError(C.FZ_E_NO_DEVICE, "run_block needs CUDA (ROCm) tensors: zignal_amd has no CPU path")
         if x.dim() == 2:
             x = x.unsqueeze(-1)
-        assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == self.n_in, (x.shape, self.n_in)
+        _check_frames(x, self.n_in)
         if x.dim() == 4:
             n_tiles, T, tile, _ = x.shape
             ns = n_tiles * tile
@@ -482,14 +500,15 @@ class Program:
             variant = Variant(v0.streams_per_lane, v0.unroll, v0.block_threads, v0.flags | C.FZ_VF_OUT_F64)
         if out is None:
             out = torch.empty(oshape, dtype=odt, device=x.device)
-        assert out.dtype == odt
+        _check_dev(out, oshape, "out", odt)
         if state is None:
             state = torch.zeros((max(self.n_state, 1), ns), dtype=torch.float32, device=x.device)
-        assert state.is_contiguous() and out.is_contiguous() and tuple(out.shape) == oshape
+        _check_dev(state, (max(self.n_state, 1), ns), "state")
         pp = None
         if self.n_param:
-            assert params is not None and params.is_contiguous() and tuple(params.shape) == (self.n_param, ns)
-            pp = params.data_ptr()
+            if params is None:
+                raise FlowzError(C.FZ_E_INVALID, f"params: the graph has {self.n_param} per-stream coefficient(s), none given")
+            pp = _check_dev(params, (self.n_param, ns), "params").data_ptr()
         self.run_block_ptr(x.data_ptr() if self.n_in else None, out.data_ptr(),
                            state.data_ptr() if self.n_state else None, pp, ns, T, variant,
                            torch.cuda.current_stream().cuda_stream, tile)
@@ -503,7 +522,7 @@ def _tune(self, x, state=None, params=None, out=None):
     Returns (Variant, milliseconds per block)."""
     import torch
 
-    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    _check_frames(x, x.shape[-1])
     if x.dim() == 4:
         n_tiles, T, tile, _ = x.shape
         ns = n_tiles * tile
@@ -551,7 +570,7 @@ class Bank:
         """params: numpy float32 [n_param, n_streams]"""
         import numpy as np
         p = np.ascontiguousarray(params, dtype=np.float32)
-        assert p.shape == (self.prog.n_param, self.n_streams)
+        _require(p.shape == (self.prog.n_param, self.n_streams), "p: wrong shape, dtype, layout or device for this call")
         C.check(C.lib.fz_bank_set_params_host(self._h, p.ctypes.data))
 
     def process_blocks(self, x, out, block_len: int, params_blocks=None, variant: Optional[Variant] = None):
@@ -560,7 +579,7 @@ class Bank:
         (CUDA float32 [n_blocks, n_param, n_streams]); fz_bank_process_blocks."""
         import torch
 
-        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == max(self.prog.n_in, 1)
+        _require(x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == max(self.prog.n_in, 1), "x: wrong shape, dtype, layout or device for this call")
         rows, tile = (x.shape[1], x.shape[2]) if x.dim() == 4 else (x.shape[0], 0)
         ns = x.shape[0] * x.shape[2] if x.dim() == 4 else x.shape[1]
         if ns != self.n_streams:
@@ -584,7 +603,7 @@ class Bank:
         T = int(x.shape[1])
         if is_torch:
             import torch
-            assert x.dtype == torch.float32 and x.is_contiguous() and not x.is_cuda
+            _require(x.dtype == torch.float32 and x.is_contiguous() and not x.is_cuda, "x: wrong shape, dtype, layout or device for this call")
             if out is None:
                 out = torch.empty((self.n_streams, T, self.prog.n_out), dtype=torch.float32, pin_memory=x.is_pinned())
             xp, op = x.data_ptr(), out.data_ptr()
@@ -593,9 +612,9 @@ class Bank:
             if out is None:
                 out = np.empty((self.n_streams, T, self.prog.n_out), np.float32)
             xp, op = x.ctypes.data, out.ctypes.data
-        assert tuple(x.shape) in ((self.n_streams, T, max(self.prog.n_in, 1)), (self.n_streams, T)), x.shape
-        assert tuple(out.shape) == (self.n_streams, T, self.prog.n_out) and (out.is_contiguous() if is_torch else out.flags.c_contiguous)
-        assert (out.dtype == torch.float32) if is_torch else (out.dtype == np.float32)
+        _require(tuple(x.shape) in ((self.n_streams, T, max(self.prog.n_in, 1)), (self.n_streams, T)), x.shape)
+        _require(tuple(out.shape) == (self.n_streams, T, self.prog.n_out) and (out.is_contiguous() if is_torch else out.flags.c_contiguous), "out: wrong shape, dtype, layout or device for this call")
+        _require((out.dtype == torch.float32) if is_torch else (out.dtype == np.float32), "out: wrong shape, dtype, layout or device for this call")
         C.check(C.lib.fz_bank_process_host_stream_major(self._h, xp if self.prog.n_in else None, op, T))
         return out
 
@@ -609,7 +628,7 @@ class Bank:
         T = int(x.shape[0])
         if is_torch:
             import torch
-            assert x.dtype == torch.float32 and x.is_contiguous() and not x.is_cuda
+            _require(x.dtype == torch.float32 and x.is_contiguous() and not x.is_cuda, "x: wrong shape, dtype, layout or device for this call")
             if out is None:
                 out = torch.empty((T, self.n_streams, self.prog.n_out), dtype=torch.float64 if out_f64 else torch.float32,
                                   pin_memory=x.is_pinned())
@@ -619,10 +638,10 @@ class Bank:
             if out is None:
                 out = np.empty((T, self.n_streams, self.prog.n_out), np.float64 if out_f64 else np.float32)
             xp, op = x.ctypes.data, out.ctypes.data
-        assert tuple(x.shape[1:]) in ((self.n_streams, self.prog.n_in), (self.n_streams,)) or self.prog.n_in == 0
-        assert tuple(out.shape) == (T, self.n_streams, self.prog.n_out) and (out.is_contiguous() if is_torch else out.flags.c_contiguous)
+        _require(tuple(x.shape[1:]) in ((self.n_streams, self.prog.n_in), (self.n_streams,)) or self.prog.n_in == 0, "x: wrong shape, dtype, layout or device for this call")
+        _require(tuple(out.shape) == (T, self.n_streams, self.prog.n_out) and (out.is_contiguous() if is_torch else out.flags.c_contiguous), "out: wrong shape, dtype, layout or device for this call")
         want_dt = (torch.float64 if out_f64 else torch.float32) if is_torch else (np.float64 if out_f64 else np.float32)
-        assert out.dtype == want_dt, (out.dtype, want_dt)
+        _require(out.dtype == want_dt, (out.dtype, want_dt))
         fn = C.lib.fz_bank_process_host_f64 if out_f64 else C.lib.fz_bank_process_host
         C.check(fn(self._h, xp if self.prog.n_in else None, op, T))
         return out
@@ -634,7 +653,7 @@ Program.bank = lambda self, n_streams: Bank(self, n_streams)
 def to_tiled(x, tile_streams: int):
     """time-major [T, n_streams, w] -> stream-tiled [n_tiles, T, tile_streams, w] (torch or numpy)."""
     T, ns, w = x.shape
-    assert ns % tile_streams == 0
+    _require(ns % tile_streams == 0, "the stream count must be a multiple of tile_streams")
     y = x.reshape(T, ns // tile_streams, tile_streams, w)
     y = y.permute(1, 0, 2, 3).contiguous() if hasattr(y, "permute") else y.transpose(1, 0, 2, 3).copy()
     return y
@@ -707,7 +726,7 @@ def synth_fill(dst, seed: int, stream0: int = 0, t0: int = 0):
     else:
         T, ns, nw = dst.shape
         tile = 0
-    assert dst.is_cuda and dst.dtype == torch.float32 and dst.is_contiguous()
+    _require(dst.is_cuda and dst.dtype == torch.float32 and dst.is_contiguous(), "dst: wrong shape, dtype, layout or device for this call")
     C.check(C.lib.fz_synth_fill(dst.data_ptr(), ns, T, nw, int(seed), int(stream0), int(t0), int(tile),
                                 torch.cuda.current_stream().cuda_stream))
     return dst
@@ -720,9 +739,9 @@ def rbj_lowpass(freq, q, sample_rate: float, raw6=None, df1=None):
     import torch
 
     n = freq.numel()
-    assert freq.is_cuda and q.is_cuda and q.numel() == n and freq.dtype == q.dtype == torch.float32
+    _require(freq.is_cuda and q.is_cuda and q.numel() == n and freq.dtype == q.dtype == torch.float32, "freq: wrong shape, dtype, layout or device for this call")
     for t, rows in ((raw6, 6), (df1, 5)):
-        assert t is None or (t.is_cuda and t.is_contiguous() and tuple(t.shape) == (rows, n))
+        _require(t is None or (t.is_cuda and t.is_contiguous() and tuple(t.shape) == (rows, n)), "t: wrong shape, dtype, layout or device for this call")
     C.check(C.lib.fz_rbj_lowpass(freq.data_ptr(), q.data_ptr(), float(sample_rate), n,
                                  raw6.data_ptr() if raw6 is not None else None,
                                  df1.data_ptr() if df1 is not None else None,
@@ -738,12 +757,12 @@ def frames_from_stream_major(x, tile_streams: int = 0, out=None):
     if x.dim() == 2:
         x = x.unsqueeze(-1)
     ns, T, w = x.shape
-    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    _check_frames(x, x.shape[-1])
     tile = tile_streams if tile_streams and tile_streams < ns else 0
     shape = (ns // tile, T, tile, w) if tile else (T, ns, w)
     if out is None:
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
-    assert tuple(out.shape) == shape and out.is_contiguous()
+    _require(tuple(out.shape) == shape and out.is_contiguous(), "out: wrong shape, dtype, layout or device for this call")
     C.check(C.lib.fz_transpose_frames(x.data_ptr(), out.data_ptr(), ns, T, w, tile, 0, torch.cuda.current_stream().cuda_stream))
     return out
 
@@ -752,7 +771,7 @@ def frames_to_stream_major(y, out=None):
     """frames ([n_samples, n_streams, w] or stream-tiled [n_tiles, n_samples, tile, w]) -> [n_streams, n_samples, w]."""
     import torch
 
-    assert y.is_cuda and y.dtype == torch.float32 and y.is_contiguous()
+    _require(y.is_cuda and y.dtype == torch.float32 and y.is_contiguous(), "y: wrong shape, dtype, layout or device for this call")
     if y.dim() == 4:
         n_tiles, T, tile, w = y.shape
         ns = n_tiles * tile
@@ -761,7 +780,7 @@ def frames_to_stream_major(y, out=None):
         tile = 0
     if out is None:
         out = torch.empty((ns, T, w), dtype=torch.float32, device=y.device)
-    assert tuple(out.shape) == (ns, T, w) and out.is_contiguous()
+    _require(tuple(out.shape) == (ns, T, w) and out.is_contiguous(), "out: wrong shape, dtype, layout or device for this call")
     C.check(C.lib.fz_transpose_frames(y.data_ptr(), out.data_ptr(), ns, T, w, tile, 1, torch.cuda.current_stream().cuda_stream))
     return out
 
@@ -769,6 +788,6 @@ def frames_to_stream_major(y, out=None):
 def copy_probe(src, dst):
     import torch
 
-    assert src.is_cuda and dst.is_cuda and src.numel() == dst.numel() and src.numel() % 4 == 0
+    _require(src.is_cuda and dst.is_cuda and src.numel() == dst.numel() and src.numel() % 4 == 0, "src: wrong shape, dtype, layout or device for this call")
     C.check(C.lib.fz_copy_probe(src.data_ptr(), dst.data_ptr(), src.numel(),
                                 torch.cuda.current_stream().cuda_stream))
