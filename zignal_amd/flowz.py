@@ -503,7 +503,8 @@ class Program:
         _check_dev(out, oshape, "out", odt)
         if state is None:
             state = torch.zeros((max(self.n_state, 1), ns), dtype=torch.float32, device=x.device)
-        _check_dev(state, (max(self.n_state, 1), ns), "state")
+        if self.n_state:
+            _check_dev(state, (self.n_state, ns), "state")
         pp = None
         if self.n_param:
             if params is None:
