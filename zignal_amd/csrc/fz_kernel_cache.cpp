@@ -80,6 +80,14 @@ static std::vector<const char*> build_options(const Variant& v)
       o.push_back("-mllvm");
       o.push_back("-amdgpu-sched-strategy=max-ilp");
    }
+   // The pair long-run stream-major body (two streams per lane, ONE wave per SIMD): the graph of a step is one serial chain of packed
+   // operations and nothing else shares the SIMD, so the default order (a step after the other: every v_pk_add behind the v_pk_mul
+   // it waits for, 857 s_nop in the cascade's code) would run at the latency of the chain.  The iterative ILP scheduler overlaps
+   // the stages of consecutive steps (286 s_nop, two to three chains in flight).
+   if ((v.flags & FZ_VF_STREAM_MAJOR) && (v.flags & FZ_VF_SM_LONG) && v.P == 2) {
+      o.push_back("-mllvm");
+      o.push_back("-amdgpu-sched-strategy=iterative-ilp");
+   }
    // developer hook (kernel experiments: -DFZ_DBG_NOLOAD ... and compiler flags); part of the cache key like every option
    static const std::vector<std::string> extra = [] {
       std::vector<std::string> e;
@@ -354,7 +362,7 @@ Variant settle_variant(fz_program* p, Variant v)
       if (v.flags & FZ_VF_STREAM_MAJOR) {
          // the long-run body with 64-sample phases shares a SIMD between two waves (256 registers each): where that spills (the
          // ROCm 7.0 compiler: 60 bytes for the 6-biquad cascade) the 128-sample phases of a lone wave (512 registers) run instead
-         if ((v.flags & FZ_VF_SM_LONG) && v.U == 64) {
+         if ((v.flags & FZ_VF_SM_LONG) && v.U == 64 && v.P == 1) {
             v.U = 128;
             continue;
          }
