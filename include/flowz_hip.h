@@ -232,7 +232,10 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
        FZ_VF_STREAM_MAJOR = 128u,   /* set by fz_run_block_stream_major (the frame layout is part of the kernel) */
        FZ_VF_SM_LONG = 256u,    /* stream-major frames, 1-in/1-out graphs: the long-run body -- 512-byte runs per stream (unroll 128;
                                    64 selectable), one in-place LDS patch per wave, one wave per SIMD; chosen automatically for
-                                   blocks of >= 256 samples; FZ_VF_SM_SHORT keeps the 32-sample chunks                          */
+                                   blocks of >= 256 samples; FZ_VF_SM_SHORT keeps the 32-sample chunks.  With streams_per_lane = 2
+                                   (unroll 64): the PAIR body -- two streams per lane, every node one packed instruction, halves of
+                                   64 samples, 256-byte in-runs and 512-byte out-runs; the default for deep graphs with uniform
+                                   coefficients from 2^19 (even) streams on                                                     */
        FZ_VF_SM_SHORT = 512u,
        FZ_VF_WAVE_SPLIT = 1024u, /* fewer streams than lanes: a serial graph of K isomorphic segments is cut into W parts of K / W
                                    segments, W waves of a workgroup evaluate the parts for the same 64 streams (the cut wires

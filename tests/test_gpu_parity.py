@@ -1408,6 +1408,75 @@ def test_stream_major_long_run_kernel_vs_oracle(torch_cuda, F, name):
         assert torch.equal(out, y), (ns, T)
 
 
+PAIR_GRAPHS = {"cascade6": lambda: G.df1_cascade(6), "cascade7_prefix_plus_6": PACKABLE["cascade7_prefix_plus_6"],
+               "cascade12_two_stages_per_segment": PACKABLE["cascade12_two_stages_per_segment"],
+               "df1": G.df1, "df2t": G.df2t, "integrator": G.integrator,
+               "depth8_fir": lambda: G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 8)))}
+
+
+@pytest.mark.parametrize("name", sorted(PAIR_GRAPHS))
+def test_stream_major_pair_long_run_kernel_vs_oracle(torch_cuda, F, name):
+    """The PAIR long-run body of the stream-major kernel (streams_per_lane = 2 with FZ_VF_SM_LONG: two streams per lane, every
+    node one packed instruction, halves of 64 samples in an interleaved in-place patch, 256-byte in-runs, 512-byte out-runs
+    held back in registers): ragged even stream counts (waves with idle lanes, a lone pair), blocks with and without full
+    128-sample phases, ragged tails, windows and chains with the one-stream bodies -- vs the oracle, 0 ULP, canonical state."""
+    torch = torch_cuda
+    g = PAIR_GRAPHS[name]()
+    prog = F.compile(F.from_sexpr(g))
+    pair = F.make_variant(2, 64, 0, SM_LONG)
+    assert prog.kernel_name(F.make_variant(2, 64, 0, SM_LONG | 128), 1024, 512).startswith("fz_block_kernel_p2u64b256f")
+    for ns, T in ((334, 256), (2, 388), (778, 300), (130, 128), (64, 124), (1026, 640)):
+        x = O.synth_input(SEED + 101, np.arange(ns), T)
+        want = O.compile(g, ns).run(x)
+        xs = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))).cuda()
+        y, st = prog.run_block_stream_major(xs, variant=pair)
+        assert ndiff(y.permute(1, 0, 2).contiguous().cpu().numpy(), want) == 0, (ns, T)
+        _, st_ref = prog.run_block(torch.from_numpy(x).cuda(), variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+        assert torch.equal(st, st_ref), (ns, T)
+        yv, stv = prog.run_block_stream_major(xs, variant=F.make_variant(2, 0, 128, SM_LONG))       # two waves per workgroup
+        assert torch.equal(yv, y) and torch.equal(stv, st), (ns, T)
+        # windows: the pair body, then the library's own choice continues (and the other way round); row0 multiples of 4
+        out = torch.zeros_like(y)
+        cut = 132 if T > 260 else 64
+        _, st2 = prog.run_block_stream_major(xs, out=out, n_samples=cut, variant=pair)
+        prog.run_block_stream_major(xs, out=out, state=st2, row0=cut)
+        assert torch.equal(out, y), (ns, T)
+        out.zero_()
+        _, st2 = prog.run_block_stream_major(xs, out=out, n_samples=20, variant=F.make_variant(0, 0, 0, SM_SHORT))
+        prog.run_block_stream_major(xs, out=out, state=st2, row0=20, variant=pair)
+        assert torch.equal(out, y), (ns, T)
+    with pytest.raises(F.FlowzError):                                            # an odd stream count has no pairs
+        prog.run_block_stream_major(torch.zeros((7, 256, 1), device="cuda"), variant=pair)
+    with pytest.raises(F.FlowzError):                                            # halves of 64 samples only
+        prog.run_block_stream_major(torch.zeros((8, 256, 1), device="cuda"), variant=F.make_variant(2, 128, 0, SM_LONG))
+
+
+def test_stream_major_pair_body_is_the_default_for_deep_graphs_on_many_streams(torch_cuda, F):
+    """From 2^19 (even) streams on, a deep 1-in/1-out graph with uniform coefficients runs the pair long-run body by itself
+    (the 6-biquad cascade: 27 packed instructions per stream and step against 30 with stage packing); shallow graphs, fewer
+    streams, odd counts and short blocks keep the one-stream bodies.  Full size: against the frame kernel on every stream,
+    sampled streams against the C oracle."""
+    torch = torch_cuda
+    sm = F.make_variant(0, 0, 0, 128)
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    assert prog.kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b256f384"
+    assert prog.kernel_name(sm, 1 << 19, 256) == "fz_block_kernel_p2u64b256f384"
+    assert prog.kernel_name(sm, 1 << 18, 4096).startswith("fz_block_kernel_p1u128b256s6f")
+    assert prog.kernel_name(sm, (1 << 20) + 1, 4096).startswith("fz_block_kernel_p1u128b256s6f")
+    assert prog.kernel_name(sm, 1 << 20, 128).startswith("fz_block_kernel_p1u")
+    assert F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u128b256f")
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u")   # per-stream coefficients
+    ns, T = (1 << 19) + 130, 644
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED + 7)
+    yf, stf = prog.run_block(x)
+    ys, sts = prog.run_block_stream_major(x.permute(1, 0, 2).contiguous())
+    assert torch.equal(ys.permute(1, 0, 2).contiguous(), yf) and torch.equal(sts, stf)
+    ids = _sample_ids(ns, 256, 9)
+    want = C.df1_cascade([W.STABLE] * 6, O.synth_input(SEED + 7, ids, T))
+    assert ndiff(yf[:, torch.from_numpy(ids).cuda()].cpu().numpy(), want) == 0
+
+
 def test_stream_major_long_run_osc_chain_per_stream_coefficients_64k(torch_cuda, F):
     """resonator -> 6 DF1 with 31 per-stream coefficients (scalar prefix + 6 packed segments) through the long-run body at
     a size where every SIMD has a wave; the full output against the frame kernel, sampled streams against the C oracle."""

@@ -366,6 +366,12 @@ Variant settle_variant(fz_program* p, Variant v)
             v.U = 128;
             continue;
          }
+         // (the pair long-run body keeps 256 staging registers next to the graph's: a graph that does not fit runs the one-stream body)
+         if ((v.flags & FZ_VF_SM_LONG) && v.P == 2) {
+            v.P = 1;
+            v.U = 128;
+            continue;
+         }
          return v;
       }
       if (ws_parts(v.flags) && v.block * ws_waves(v.flags) > 256 && v.block > 64) {

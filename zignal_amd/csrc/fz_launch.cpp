@@ -160,6 +160,12 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       uv = nullptr;
       v = finalize_variant(p, nullptr, n_streams, n_samples, tile_streams);
    }
+   if (stream_major && (v.flags & FZ_VF_SM_LONG) && v.P == 2 && (uint64_t)rows_total >= (1ull << 23)) {
+      // the library's own choice of the pair body (128 rows per descriptor) on buffers too long for it: one stream per lane
+      fz_variant one = *uv;
+      one.streams_per_lane = 1;
+      v = finalize_variant(p, &one, n_streams, n_samples, tile_streams);
+   }
    void* fn = nullptr;
    auto k = get_kernel(p, v, &fn);
 

@@ -18,6 +18,12 @@ constexpr uint64_t kMaxLdsBytes = 160 * 1024;
 
 // tile_streams: the frame layout the variant is for -- 0 (or >= n_streams) plain time-major rows, else stream tiles (stream-major
 // frames are named by FZ_VF_STREAM_MAJOR in the variant's flags).  allow_lockstep: see the time-major rule below.
+// (stream-major frames: nothing asked for besides the layout)
+static bool uv_has_shape(const fz_variant* uv)
+{
+   return uv && (uv->streams_per_lane || uv->unroll || uv->block_threads || (uv->flags & ~(uint32_t)FZ_VF_STREAM_MAJOR));
+}
+
 Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, uint32_t allow_lockstep)
 {
    if (tile_streams >= n_streams) tile_streams = 0;
@@ -141,6 +147,17 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // one stream per lane: two (packed FP32) are possible but measured slower everywhere -- twice the
       // patch traffic per wave and 360 VGPRs (profiles/r01/stream_major_kernel.txt)
       v.P = reqP ? reqP : 1u;
+      // ... except for DEEP 1-in/1-out graphs on many streams and blocks long enough for the long-run bodies: the PAIR long-run
+      // body (below) carries two streams per lane with every node ONE packed instruction -- 27 per stream and step for the 6-biquad
+      // cascade where stage packing needs 30 (its pairs hand a value from the low to the high half once per step) -- measured at
+      // 1 M streams: 6.12-6.13 ms against 6.38-6.42 ms per 4096 samples (0.70 of peak against 0.67), 1.66-1.68 against 1.81-1.88 ms
+      // per 1024; level at 262 144 streams, and SLOWER for shallow graphs (2 biquads 5.84 against 5.45 ms, one 7.29 against 5.77: a
+      // lone wave with one packed chain per step runs at the latency of the chain) -- profiles/r03/stream_major_pair_body.txt
+      if (!uv_has_shape(uv) && g.n_in == 1 && g.n_out == 1 && g.n_lds_slots == 0 && g.far_lines.empty() && g.n_param == 0 && g.n_mod == 0 &&
+          !g.typed && g.n_ops > 27 && g.n_state <= 20 && n_streams >= (1u << 19) && n_streams % 2 == 0 && n_samples >= 256) {
+         v.P = 2;
+         v.flags |= FZ_VF_SM_LONG;
+      }
       // stage packing (one stream per lane) carries over: the skew only shifts which output chunk a step completes.
       // It is what lifts deep serial graphs off the VALU floor here, whatever the stream count.
       if (v.P != 1 || !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;

@@ -227,6 +227,6 @@ BASELINE_GRAPHS = {
 
 
 # Stream-major frames ([stream][t][wire], the reference's calling convention): kernel variants (P, U, block, flags without
-# FZ_VF_STREAM_MAJOR) a caller may want to measure -- the library default, the long-run body with and without stage packing,
-# short chunks.  fz_program_tune measures frame layouts only; bench.py's stream-major leg times these (build() pre-builds them).
-SM_CANDIDATES = [(0, 0, 0, 0), (1, 128, 0, 256), (1, 128, 0, 256 | 16), (1, 32, 0, 512 | 16), (0, 0, 0, 512)]
+# FZ_VF_STREAM_MAJOR) a caller may want to measure -- the library default, the pair long-run body (two streams per lane), the one-stream long-run body with and
+# without stage packing, short chunks.  fz_program_tune measures frame layouts only; bench.py's stream-major leg times these (build() pre-builds them).
+SM_CANDIDATES = [(0, 0, 0, 0), (2, 64, 0, 256), (1, 128, 0, 256), (1, 128, 0, 256 | 16), (1, 32, 0, 512 | 16), (0, 0, 0, 512)]
