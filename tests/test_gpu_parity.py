@@ -1424,7 +1424,12 @@ def test_stream_major_pair_long_run_kernel_vs_oracle(torch_cuda, F, name):
     g = PAIR_GRAPHS[name]()
     prog = F.compile(F.from_sexpr(g))
     pair = F.make_variant(2, 64, 0, SM_LONG)
-    assert prog.kernel_name(F.make_variant(2, 64, 0, SM_LONG | 128), 1024, 512).startswith("fz_block_kernel_p2u64b256f")
+    # (a graph whose registers do not fit next to the 256 staging registers runs the one-stream long-run body instead: the 12-stage
+    #  cascade does with the compiler bundled with the PyTorch wheel, not with the ROCm installation's)
+    kn = prog.kernel_name(F.make_variant(2, 64, 0, SM_LONG | 128), 1024, 512)
+    assert kn.startswith(("fz_block_kernel_p2u64b256f", "fz_block_kernel_p1u128b256")), kn
+    if name in ("cascade6", "df1"):
+        assert kn.startswith("fz_block_kernel_p2u64b256f"), kn
     for ns, T in ((334, 256), (2, 388), (778, 300), (130, 128), (64, 124), (1026, 640)):
         x = O.synth_input(SEED + 101, np.arange(ns), T)
         want = O.compile(g, ns).run(x)
@@ -1473,7 +1478,7 @@ def test_stream_major_pair_body_is_the_default_for_deep_graphs_on_many_streams(t
     ys, sts = prog.run_block_stream_major(x.permute(1, 0, 2).contiguous())
     assert torch.equal(ys.permute(1, 0, 2).contiguous(), yf) and torch.equal(sts, stf)
     ids = _sample_ids(ns, 256, 9)
-    want = C.df1_cascade([W.STABLE] * 6, O.synth_input(SEED + 7, ids, T))
+    want = C.df1_cascade([G.STABLE] * 6, O.synth_input(SEED + 7, ids, T))
     assert ndiff(yf[:, torch.from_numpy(ids).cuda()].cpu().numpy(), want) == 0
 
 

@@ -63,7 +63,7 @@ void* Kernel::function_on_current_device(const std::string& symbol)
 }
 
 // ---- kernel cache -----------------------------------------------------------------------------------
-static std::vector<const char*> build_options(const Variant& v)
+static std::vector<const char*> build_options(const Graph& g, const Variant& v)
 {
    // -ffp-contract=off: one rounding per graph node (no v_fma/v_fmac); IEEE division.
    // The SLP vectoriser is off by default: with one stream per lane it pairs unrelated scalar
@@ -84,7 +84,8 @@ static std::vector<const char*> build_options(const Variant& v)
    // operations and nothing else shares the SIMD, so the default order (a step after the other: every v_pk_add behind the v_pk_mul
    // it waits for, 857 s_nop in the cascade's code) would run at the latency of the chain.  The iterative ILP scheduler overlaps
    // the stages of consecutive steps (286 s_nop, two to three chains in flight).
-   if ((v.flags & FZ_VF_STREAM_MAJOR) && (v.flags & FZ_VF_SM_LONG) && v.P == 2) {
+   // (deep graphs only: on shallow ones it hoists every LDS read of the unrolled steps and runs out of registers)
+   if ((v.flags & FZ_VF_STREAM_MAJOR) && (v.flags & FZ_VF_SM_LONG) && v.P == 2 && g.n_ops > 27) {
       o.push_back("-mllvm");
       o.push_back("-amdgpu-sched-strategy=iterative-ilp");
    }
@@ -296,7 +297,7 @@ static std::vector<char> jit_compile(const Graph& g, const Variant& v)
    hiprtcProgram prog;
    if (R.create(&prog, skeleton_source(), "fz_block_kernel.hip", 2, headers, names) != HIPRTC_SUCCESS)
       fail(FZ_E_COMPILE, "hiprtcCreateProgram failed");
-   std::vector<const char*> opts = build_options(v);
+   std::vector<const char*> opts = build_options(g, v);
    hiprtcResult r = R.compile(prog, (int)opts.size(), opts.data());
    if (r != HIPRTC_SUCCESS) {
       size_t n = 0;
@@ -370,6 +371,8 @@ Variant settle_variant(fz_program* p, Variant v)
          if ((v.flags & FZ_VF_SM_LONG) && v.P == 2) {
             v.P = 1;
             v.U = 128;
+            // (with the stage packing the one-stream body would have had by itself: resolve_variant's rule for deep graphs)
+            if (p->g.split.ok && p->g.split.atoms() <= 13 && p->g.n_ops > 27) v.flags |= FZ_VF_STAGE_PACK;
             continue;
          }
          return v;
@@ -387,7 +390,7 @@ Variant settle_variant(fz_program* p, Variant v)
 static std::string cache_file_of(const fz_program* p, const Variant& v, const std::string& compiler)
 {
    std::string key_src = full_source(p->g, v);
-   for (const char* o : build_options(v)) key_src += o;
+   for (const char* o : build_options(p->g, v)) key_src += o;
    key_src += compiler;                                 // who built it (Rtc::identity / preferred_identity)
    char name[64];
    std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)fnv1a(key_src));
