@@ -14,8 +14,9 @@ from zignal_amd import flowz as F  # noqa: E402
 
 PAIR = F.make_variant(2, 64, 0, 256)
 graphs = {"cascade6": lambda: G.df1_cascade(6), "cascade2": lambda: G.df1_cascade(2), "df1": G.df1}
+QUICK = bool(os.environ.get("PAIR_PROBE_QUICK"))          # the cascade only: parity, then the time at 1 M streams x 4096
 bad = 0
-for name in graphs:
+for name in (["cascade6"] if QUICK else graphs):
     prog = F.compile(F.from_sexpr(graphs[name]()))
     for ns, T in ((2, 128), (130, 256), (776, 300), (1024, 124), (4098, 1000), (70000, 516)):
         torch.manual_seed(ns + T)
@@ -47,7 +48,8 @@ def timed(fn, reps=8):
 
 
 os.environ["FLOWZ_HIP_AUTOTUNE"] = "0"
-for name, ns, T in (("cascade6", 1 << 20, 4096), ("cascade2", 1 << 20, 4096), ("df1", 1 << 20, 4096), ("cascade6", 1 << 18, 4096), ("cascade6", 1 << 20, 1024)):
+for name, ns, T in ((("cascade6", 1 << 20, 4096),) if QUICK else
+                    (("cascade6", 1 << 20, 4096), ("cascade2", 1 << 20, 4096), ("df1", 1 << 20, 4096), ("cascade6", 1 << 18, 4096), ("cascade6", 1 << 20, 1024))):
     prog = F.compile(F.from_sexpr(graphs[name]()))
     x = torch.randn((ns, T, 1), device="cuda") * 0.1
     out = torch.empty((ns, T, 1), device="cuda")
@@ -55,8 +57,9 @@ for name, ns, T in (("cascade6", 1 << 20, 4096), ("cascade2", 1 << 20, 4096), ("
     b = ns * T * 8
     print(f"# {name}, {ns} streams x {T} samples, B_alg {b / 1e9:.2f} GB")
     for rnd in range(2):
-        for label, v in (("default", None), ("pair P=2 U=64 SM_LONG", PAIR)):
+        for label, v in (("default", None), ("one stream per lane", F.make_variant(1, 128, 0, 256)), ("pair P=2 U=64 SM_LONG", PAIR)):
             ms = timed(lambda: prog.run_block_stream_major(x, state=st, out=out, variant=v))
-            print(f"  {label:24s} {prog.kernel_name(F.make_variant(0, 0, 0, 128) if v is None else F.make_variant(2, 64, 0, 384), ns, T, 0):40s} {ms:8.3f} ms  {b / ms / 1e6:7.1f} GB/s  frac {b / ms / 1e6 / 8000:.4f}", flush=True)
+            kv = F.make_variant(0, 0, 0, 128) if v is None else F.make_variant(v.streams_per_lane, v.unroll, 0, v.flags | 128)
+            print(f"  {label:24s} {prog.kernel_name(kv, ns, T, 0):40s} {ms:8.3f} ms  {b / ms / 1e6:7.1f} GB/s  frac {b / ms / 1e6 / 8000:.4f}", flush=True)
     del x, out, st
     torch.cuda.empty_cache()
