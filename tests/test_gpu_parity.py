@@ -1458,7 +1458,7 @@ def test_stream_major_pair_long_run_kernel_vs_oracle(torch_cuda, F, name):
 
 def test_stream_major_pair_body_is_the_default_for_deep_graphs_on_many_streams(torch_cuda, F):
     """From 2^19 (even) streams on, a deep 1-in/1-out graph with uniform coefficients runs the pair long-run body by itself
-    (the 6-biquad cascade: 27 packed instructions per stream and step against 30 with stage packing); shallow graphs, fewer
+    (the 6-biquad cascade: 28.0 instructions per stream and step against 30.4 with stage packing); shallow graphs, fewer
     streams, odd counts and short blocks keep the one-stream bodies.  Full size: against the frame kernel on every stream,
     sampled streams against the C oracle."""
     torch = torch_cuda

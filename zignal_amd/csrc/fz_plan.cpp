@@ -148,8 +148,9 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // patch traffic per wave and 360 VGPRs (profiles/r01/stream_major_kernel.txt)
       v.P = reqP ? reqP : 1u;
       // ... except for DEEP 1-in/1-out graphs on many streams and blocks long enough for the long-run bodies: the PAIR long-run
-      // body (below) carries two streams per lane with every node ONE packed instruction -- 27 per stream and step for the 6-biquad
-      // cascade where stage packing needs 30 (its pairs hand a value from the low to the high half once per step) -- measured at
+      // body (below) carries two streams per lane with every node ONE packed instruction -- 28.0 instructions per stream and step in the
+      // loop of the 6-biquad cascade where the stage-packed body issues 30.4 (two moves per step: the chain's crossing from the low to
+      // the high half, the output's way out of the high half) -- measured at
       // 1 M streams: 6.12-6.13 ms against 6.38-6.42 ms per 4096 samples (0.70 of peak against 0.67), 1.66-1.68 against 1.81-1.88 ms
       // per 1024; level at 262 144 streams, and SLOWER for shallow graphs (2 biquads 5.84 against 5.45 ms, one 7.29 against 5.77: a
       // lone wave with one packed chain per step runs at the latency of the chain) -- profiles/r03/stream_major_pair_body.txt
