@@ -98,10 +98,11 @@ for seed in range(first, first + count):
             xl = O.synth_input(seed + 1, np.arange(ns), TL, n_wires=1)
             wl = O.compile(g, ns).run(xl)
             xsl = torch.from_numpy(np.ascontiguousarray(np.transpose(xl, (1, 0, 2)))).cuda()
-            for v in (None, F.make_variant(1, 64, 0, F.C.FZ_VF_SM_LONG)):
-                trace("stream-major long", "auto" if v is None else "U=64", "T", TL)
+            for v in (None, F.make_variant(1, 64, 0, F.C.FZ_VF_SM_LONG), F.make_variant(2, 64, 0, F.C.FZ_VF_SM_LONG)):   # (the last: the pair body, two streams per lane)
+                label = "auto" if v is None else f"P={v.streams_per_lane} U=64"
+                trace("stream-major long", label, "T", TL)
                 ys, _ = p.run_block_stream_major(xsl, variant=v)
-                res.append((f"stream-major long {'auto' if v is None else 'U=64'} T={TL}", same(ys.permute(1, 0, 2).contiguous().cpu().numpy(), wl, np.float32)))
+                res.append((f"stream-major long {label} T={TL}", same(ys.permute(1, 0, 2).contiguous().cpu().numpy(), wl, np.float32)))
         # fz_compile_typed: ResultType through inputs (random float / double wires), state and outputs
         dts = [str(rng.choice(["f32", "f64"])) for _ in range(n_in)]
         try:
@@ -137,5 +138,5 @@ for seed in range(first, first + count):
             bad += 1
             print("MISMATCH seed", seed, "typed" if typed else "plain", [n for n, r in res if not r], g, flush=True)
 print(f"fuzz seeds {first}..{last}: {ok} graphs identical, {bad} mismatching, {skipped} skipped, {refused} lockstep variants refused "
-      f"(per graph: P = 1, 2, 4 with random unroll / flags incl. lockstep and XCD-synchronised workgroups, float64 frames, a split block, the stream-major kernel short and long, fz_compile_typed with random input types)")
+      f"(per graph: P = 1, 2, 4 with random unroll / flags incl. lockstep and XCD-synchronised workgroups, float64 frames, a split block, the stream-major kernel short, long and pair-long, fz_compile_typed with random input types)")
 sys.exit(1 if bad else 0)
