@@ -47,5 +47,26 @@ for d in sorted(glob.glob(os.path.join(base, "pmc_*_FETCH_SIZE"))):
                                     "launches": len(cf[k]["FETCH_SIZE"]), "FETCH_SIZE_KiB": f / 1024, "WRITE_SIZE_KiB": w / 1024, "traffic_bytes_per_launch": t,
                                     "algorithmic_bytes_per_launch": B_ALG[wl], "traffic_over_algorithmic": round(t / B_ALG[wl], 5)})
         print(f"{tag:16s} {k:40s} traffic/alg {t / B_ALG[wl]:.5f}")
+# SQ counter passes of the same batch (directories pmc_sq_<object>, as tools/profile_r03.sh makes them)
+for d in sorted(glob.glob(os.path.join(base, "pmc_sq_*"))):
+    f = os.path.join(d, "b_counter_collection.csv")
+    if not (os.path.isdir(d) and os.path.exists(f)):
+        continue
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        per[k]["_ms"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    for k, cs in per.items():
+        if not k.startswith("fz_block_kernel"):
+            continue
+        c = {n: sum(v) / len(v) for n, v in cs.items()}
+        if "GRBM_GUI_ACTIVE" in c:
+            c["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8 / (c["_ms"] * 1e6)          # summed over the 8 XCDs
+        if "SQ_WAVE_CYCLES" in c:
+            for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+                c[n + "_share_of_wave_cycles"] = c.get(n, 0) / c["SQ_WAVE_CYCLES"]
+        summ.setdefault("sq_counters", {})[os.path.basename(d)[7:] + ":" + k] = c
+        print(f"sq {os.path.basename(d)[7:]:12s} {k:40s} " + "  ".join(f"{n.replace('_share_of_wave_cycles', '')} {x:.3f}" for n, x in c.items() if "share" in n or "clock" in n))
 json.dump(traffic, open(tp, "w"), indent=1)
 json.dump(summ, open(sp, "w"), indent=1)
