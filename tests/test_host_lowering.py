@@ -230,6 +230,56 @@ def test_wave_split_kernels_in_the_isa(tmp_path, monkeypatch):
     assert arith == 16 * 18, arith                                        # 9 packed + 9 scalar per step, 16 steps per round
 
 
+def test_stream_major_pair_long_run_body_rules_and_code(tmp_path, monkeypatch):
+    """The pair long-run body of the stream-major kernel (host side): the default for deep 1-in/1-out graphs with uniform
+    coefficients from 2^19 even streams on, on request otherwise (streams_per_lane = 2 with FZ_VF_SM_LONG, unroll 64 only);
+    its code object: no contraction, no scratch, no waterfall loops, the patch of [64 lanes][2 x 64 + 4] floats per wave, and
+    a loop whose steps are nothing but the graph's packed operations (no moves: the patch rows are the register pairs)."""
+    import subprocess
+    monkeypatch.setenv("FLOWZ_HIP_CACHE", str(tmp_path))
+    SMF, LONG = F.C.FZ_VF_STREAM_MAJOR, F.C.FZ_VF_SM_LONG
+    sm = F.make_variant(0, 0, 0, SMF)
+    p = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    assert p.kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b256f384"
+    assert p.kernel_name(sm, 1 << 19, 256) == "fz_block_kernel_p2u64b256f384"
+    assert p.kernel_name(sm, 1 << 18, 4096).startswith("fz_block_kernel_p1u128b256s6f")           # fewer streams: level, the one-stream body stays
+    assert p.kernel_name(sm, (1 << 20) + 1, 4096).startswith("fz_block_kernel_p1u128b256s6f")      # an odd count has no pairs
+    assert p.kernel_name(sm, 1 << 20, 128).startswith("fz_block_kernel_p1u")                        # shorter than a long-run block
+    assert p.kernel_name(F.make_variant(0, 0, 0, SMF | F.C.FZ_VF_SM_SHORT), 1 << 20, 4096).startswith("fz_block_kernel_p1u32")   # anything asked for: as before
+    assert F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u128b256f")     # shallow graphs
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u")               # per-stream coefficients
+    for bad in (F.make_variant(2, 128, 0, SMF | LONG), F.make_variant(2, 32, 0, SMF | LONG)):
+        with pytest.raises(F.FlowzError):
+            p.kernel_name(bad, 1024, 512)
+    with pytest.raises(F.FlowzError):
+        p.kernel_name(F.make_variant(2, 64, 0, SMF | LONG), 1023, 512)                              # n_streams % streams_per_lane
+    with pytest.raises(F.FlowzError):
+        F.compile(F.from_sexpr(G.par4_sum())).kernel_name(F.make_variant(2, 64, 0, SMF | LONG), 1024, 512)   # 4-wire frames
+    r = p.kernel_resources(F.make_variant(2, 64, 0, SMF | LONG), 1 << 20, 4096)
+    assert r["scratch_bytes"] == 0 and r["lds_bytes"] == 4 * 64 * (2 * 64 + 4) * 4 and r["vgprs"] <= 512 and r["unroll"] == 64
+    obj = [o for o in tmp_path.glob("*.hsaco")
+           if "p2u64b256f384" in subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(o)], text=True)][0]
+    dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", str(obj)], text=True)
+    assert not re.search(r"v_(pk_)?(fma|fmac|mad|mac)(_mix|_mixlo|_mixhi|_legacy)?_(f16|f32|f64|bf16)", dis)
+    assert "scratch_" not in dis and "flat_load" not in dis and "v_cmp_eq_u64" not in dis and dis.count("v_readfirstlane_b32") < 8
+    # the blocks of straight-line code between branches that hold most of the arithmetic: the 16-step loop bodies of the two halves
+    ops = [ln.split()[0] for ln in dis.splitlines() if ln.startswith("\t")]
+    blocks, cur = [], []
+    for op in ops:
+        cur.append(op)
+        if op.startswith(("s_cbranch", "s_branch", "s_endpgm")):
+            blocks.append(cur)
+            cur = []
+    loops = [b for b in blocks if sum(o.startswith("v_pk_") for o in b) >= 10 * 54]
+    assert len(loops) == 2, [len(b) for b in blocks]
+    for b in loops:
+        packed = sum(o.startswith(("v_pk_mul_f32", "v_pk_add_f32")) for o in b)
+        assert packed % 54 == 0 and packed >= 13 * 54                    # whole steps of two streams: 54 packed operations each
+        other_valu = [o for o in b if o.startswith("v_") and not o.startswith("v_pk_")]
+        assert len(other_valu) <= 4, other_valu                          # address arithmetic of the loop, no pair assembly
+        assert sum(o == "s_nop" for o in b) <= 4                         # the stages of consecutive steps overlap (iterative ILP scheduling)
+
+
 def test_product_fails_loudly_without_gpu():
     if F.device_count() > 0:
         pytest.skip("GPU present")

@@ -171,11 +171,11 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       const bool long_ok = g.n_in == 1 && g.n_out == 1 && v.P == 1 && g.n_lds_slots == 0 && (!g.split.ok || g.split.atoms() <= 13);
       // the PAIR long-run body (two streams per lane, halves of 64 samples, 512-byte out-runs): on request
       // (streams_per_lane = 2 with FZ_VF_SM_LONG); every node one packed instruction, no stage packing
-      const bool pair_ok = g.n_in == 1 && g.n_out == 1 && v.P == 2 && g.n_lds_slots == 0;
+      const bool pair_ok = g.n_in == 1 && g.n_out == 1 && v.P == 2 && g.n_lds_slots == 0 && !g.typed;
       const bool want_short = uv && (uv->flags & FZ_VF_SM_SHORT);
       v.flags &= ~(uint32_t)FZ_VF_SM_SHORT;
       if ((v.flags & FZ_VF_SM_LONG) && v.P == 2) {
-         if (!pair_ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG with two streams per lane: needs a 1-in/1-out graph, no delay lines beyond 8 samples");
+         if (!pair_ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG with two streams per lane: needs a 1-in/1-out float graph (not fz_compile_typed), no delay lines beyond 8 samples");
          if (reqU && reqU != 64) fail(FZ_E_INVALID, "FZ_VF_SM_LONG with two streams per lane: unroll must be 64");
          v.U = 64;
          auto lds_pair = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (2 * w.U + 4) * 4; };
