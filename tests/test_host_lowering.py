@@ -276,7 +276,7 @@ def test_stream_major_pair_long_run_body_rules_and_code(tmp_path, monkeypatch):
         packed = sum(o.startswith(("v_pk_mul_f32", "v_pk_add_f32")) for o in b)
         assert packed % 54 == 0 and packed >= 13 * 54                    # whole steps of two streams: 54 packed operations each
         other_valu = [o for o in b if o.startswith("v_") and not o.startswith("v_pk_")]
-        assert len(other_valu) <= 4, other_valu                          # address arithmetic of the loop, no pair assembly
+        assert len(other_valu) <= 8, other_valu                          # address arithmetic of the loop (either compiler), no pair assembly: a move per step would be 14+
         assert sum(o == "s_nop" for o in b) <= 4                         # the stages of consecutive steps overlap (iterative ILP scheduling)
 
 
