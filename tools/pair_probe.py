@@ -57,9 +57,10 @@ for name, ns, T in ((("cascade6", 1 << 20, 4096),) if QUICK else
     b = ns * T * 8
     print(f"# {name}, {ns} streams x {T} samples, B_alg {b / 1e9:.2f} GB")
     for rnd in range(2):
-        for label, v in (("default", None), ("one stream per lane", F.make_variant(1, 128, 0, 256)), ("pair P=2 U=64 SM_LONG", PAIR)):
+        more = [("pair, 128-lane workgroups", F.make_variant(2, 64, 128, 256)), ("pair, 64-lane workgroups", F.make_variant(2, 64, 64, 256))] if os.environ.get("PAIR_PROBE_BLOCKS") else []
+        for label, v in [("default", None), ("one stream per lane", F.make_variant(1, 128, 0, 256)), ("pair P=2 U=64 SM_LONG", PAIR)] + more:
             ms = timed(lambda: prog.run_block_stream_major(x, state=st, out=out, variant=v))
-            kv = F.make_variant(0, 0, 0, 128) if v is None else F.make_variant(v.streams_per_lane, v.unroll, 0, v.flags | 128)
+            kv = F.make_variant(0, 0, 0, 128) if v is None else F.make_variant(v.streams_per_lane, v.unroll, v.block_threads, v.flags | 128)
             print(f"  {label:24s} {prog.kernel_name(kv, ns, T, 0):40s} {ms:8.3f} ms  {b / ms / 1e6:7.1f} GB/s  frac {b / ms / 1e6 / 8000:.4f}", flush=True)
     del x, out, st
     torch.cuda.empty_cache()
