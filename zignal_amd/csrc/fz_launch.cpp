@@ -46,7 +46,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    if (stream_major) {
       if (tile_streams) fail(FZ_E_INVALID, "stream-major frames are not tiled");
       if ((uint64_t)rows_total * std::max(p->g.n_in, p->g.n_out) >= ((uv->flags & FZ_VF_SM_LONG) && uv->streams_per_lane == 2 ? (1ull << 23) : (1ull << 24)))
-         fail(FZ_E_UNSUPPORTED, "stream-major frames: more than 2^24 floats per stream buffer (a wave's 64 rows are addressed through one 4 GiB descriptor): use a window");
+         fail(FZ_E_UNSUPPORTED, "stream-major frames: more than 2^24 floats per stream buffer (2^23 with two streams per lane; the rows of a wave are addressed through one 4 GiB descriptor): use a window");
       if (((uint64_t)rows_total * p->g.n_in) % 4 || ((uint64_t)row0 * p->g.n_in) % 4 || ((uint64_t)rows_total * p->g.n_out) % 4 ||
           ((uint64_t)row0 * p->g.n_out) % 4)
          fail(FZ_E_INVALID, "stream-major frames: rows_total and row0 times the wires per frame must be multiples of 4 floats");
