@@ -1457,7 +1457,7 @@ def test_stream_major_pair_long_run_kernel_vs_oracle(torch_cuda, F, name):
 
 
 def test_stream_major_pair_body_is_the_default_for_deep_graphs_on_many_streams(torch_cuda, F):
-    """From 2^19 (even) streams on, a deep 1-in/1-out graph with uniform coefficients runs the pair long-run body by itself
+    """From 2^19 (even) streams on -- and from 2^17 on where its 512-stream workgroups fill the chip's rounds -- a deep 1-in/1-out graph with uniform coefficients runs the pair long-run body by itself
     (the 6-biquad cascade: 28.0 instructions per stream and step against 30.4 with stage packing); shallow graphs, fewer
     streams, odd counts and short blocks keep the one-stream bodies.  Full size: against the frame kernel on every stream,
     sampled streams against the C oracle."""
@@ -1466,7 +1466,9 @@ def test_stream_major_pair_body_is_the_default_for_deep_graphs_on_many_streams(t
     prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
     assert prog.kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b256f384"
     assert prog.kernel_name(sm, 1 << 19, 256) == "fz_block_kernel_p2u64b256f384"
-    assert prog.kernel_name(sm, 1 << 18, 4096).startswith("fz_block_kernel_p1u128b256s6f")
+    assert prog.kernel_name(sm, 1 << 17, 4096) == "fz_block_kernel_p2u64b256f384"
+    assert prog.kernel_name(sm, 3 << 16, 4096).startswith("fz_block_kernel_p1u128b256s6f")
+    assert prog.kernel_name(sm, 1 << 16, 4096).startswith("fz_block_kernel_p1u128b256s6f")
     assert prog.kernel_name(sm, (1 << 20) + 1, 4096).startswith("fz_block_kernel_p1u128b256s6f")
     assert prog.kernel_name(sm, 1 << 20, 128).startswith("fz_block_kernel_p1u")
     assert F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u128b256f")

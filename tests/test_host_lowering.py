@@ -232,7 +232,7 @@ def test_wave_split_kernels_in_the_isa(tmp_path, monkeypatch):
 
 def test_stream_major_pair_long_run_body_rules_and_code(tmp_path, monkeypatch):
     """The pair long-run body of the stream-major kernel (host side): the default for deep 1-in/1-out graphs with uniform
-    coefficients from 2^19 even streams on, on request otherwise (streams_per_lane = 2 with FZ_VF_SM_LONG, unroll 64 only);
+    coefficients from 2^19 even streams on (from 2^17 on where its workgroups fill the chip's rounds), on request otherwise (streams_per_lane = 2 with FZ_VF_SM_LONG, unroll 64 only);
     its code object: no contraction, no scratch, no waterfall loops, the patch of [64 lanes][2 x 64 + 4] floats per wave, and
     a loop whose steps are nothing but the graph's packed operations (no moves: the patch rows are the register pairs)."""
     import subprocess
@@ -242,7 +242,9 @@ def test_stream_major_pair_long_run_body_rules_and_code(tmp_path, monkeypatch):
     p = F.compile(F.from_sexpr(G.df1_cascade(6)))
     assert p.kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b256f384"
     assert p.kernel_name(sm, 1 << 19, 256) == "fz_block_kernel_p2u64b256f384"
-    assert p.kernel_name(sm, 1 << 18, 4096).startswith("fz_block_kernel_p1u128b256s6f")           # fewer streams: level, the one-stream body stays
+    assert p.kernel_name(sm, 1 << 17, 4096) == "fz_block_kernel_p2u64b256f384"                       # 256 workgroups of 512 streams: one per CU
+    assert p.kernel_name(sm, 3 << 16, 4096).startswith("fz_block_kernel_p1u128b256s6f")           # 384 workgroups: the second round would be half empty
+    assert p.kernel_name(sm, 1 << 16, 4096).startswith("fz_block_kernel_p1u128b256s6f")           # 128 workgroups: half of the CUs idle
     assert p.kernel_name(sm, (1 << 20) + 1, 4096).startswith("fz_block_kernel_p1u128b256s6f")      # an odd count has no pairs
     assert p.kernel_name(sm, 1 << 20, 128).startswith("fz_block_kernel_p1u")                        # shorter than a long-run block
     assert p.kernel_name(F.make_variant(0, 0, 0, SMF | F.C.FZ_VF_SM_SHORT), 1 << 20, 4096).startswith("fz_block_kernel_p1u32")   # anything asked for: as before

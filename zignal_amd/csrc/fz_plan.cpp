@@ -154,8 +154,17 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // 1 M streams: 6.12-6.13 ms against 6.38-6.42 ms per 4096 samples (0.70 of peak against 0.67), 1.66-1.68 against 1.81-1.88 ms
       // per 1024; level at 262 144 streams, and SLOWER for shallow graphs (2 biquads 5.84 against 5.45 ms, one 7.29 against 5.77: a
       // lone wave with one packed chain per step runs at the latency of the chain) -- profiles/r03/stream_major_pair_body.txt
+      // Below 2^19 streams the pair body's workgroups (512 streams, one per CU at a time) are few: it is chosen when they fill the
+      // chip's rounds as well as the one-stream body's 256-stream workgroups do -- measured x 4096 samples (tools/experiments/
+      // exp_r03pair_threshold.py): 131 072 streams 0.775 against 0.804-0.815 ms, 262 144 1.69 against 1.67 (level), 393 216 2.28
+      // against 2.41, 524 288 3.00 against 3.20; at 65 536 its 128 workgroups would leave half of the CUs idle
+      auto fill = [](uint64_t ns, uint64_t per_wg) {
+         const uint64_t wg = (ns + per_wg - 1) / per_wg, rounds = (wg + kChipCUs - 1) / kChipCUs;
+         return (double)wg / (double)(rounds * kChipCUs);
+      };
+      const bool enough = n_streams >= (1u << 19) || (n_streams >= (1u << 17) && fill(n_streams, 512) >= fill(n_streams, 256) - 0.02);
       if (!uv_has_shape(uv) && g.n_in == 1 && g.n_out == 1 && g.n_lds_slots == 0 && g.far_lines.empty() && g.n_param == 0 && g.n_mod == 0 &&
-          !g.typed && g.n_ops > 27 && g.n_state <= 20 && n_streams >= (1u << 19) && n_streams % 2 == 0 && n_samples >= 256) {
+          !g.typed && g.n_ops > 27 && g.n_state <= 20 && enough && n_streams % 2 == 0 && n_samples >= 256) {
          v.P = 2;
          v.flags |= FZ_VF_SM_LONG;
       }
