@@ -213,7 +213,6 @@ def cpu_baseline(n_samples, seed, coefs):
         base["vectorised_across_streams"] = {"error": str(e)[:200]}
     return base
 
-
 # ---- GPU side helpers ----------------------------------------------------------------------------------------------
 def frames(torch, dev, ns, T, w, tile):
     return torch.empty((ns // tile, T, tile, w) if tile else (T, ns, w), dtype=torch.float32, device=dev)
@@ -234,24 +233,54 @@ def event_ms(torch, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-class PowerSampler:
-    """Board power and shader clock (rocm-smi) sampled in a thread while the sustained leg runs: the 6-biquad cascade at 1 M streams
-    sits at the package power cap and the firmware lowers the clock until it fits (profiles/r03/power_and_clocks.txt), so a run's
-    number is also a statement about the board.  Best effort: None when rocm-smi is missing or prints something else."""
+def rocm_smi_card_of(torch, dev_index):
+    """rocm-smi's card index of torch's LOGICAL device `dev_index`: under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (leased boxes)
+    the two differ, so the board is found by its PCI bus id (rocm-smi --showbus).  None when it cannot be told."""
+    import re
+    import shutil
+    import subprocess
 
-    def __init__(self, device_index=0, period=0.3):
-        import shutil
+    exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+    if not exe:
+        return None, None
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        want = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}".lower()
+        o = json.loads(subprocess.run([exe, "--showbus", "--json"], capture_output=True, text=True, timeout=10).stdout)
+        cards = []
+        for card, c in o.items():
+            m = re.match(r"card(\d+)", card)
+            bus = next((str(v).lower() for k, v in c.items() if "PCI Bus" in k), "")
+            if m:
+                cards.append(int(m.group(1)))
+                if bus.startswith(want):
+                    return exe, int(m.group(1))
+        if len(cards) == 1:                                   # one visible board: nothing to confuse
+            return exe, cards[0]
+    except Exception:  # noqa: BLE001
+        pass
+    return exe, None
+
+
+class PowerSampler:
+    """Board power and shader clock (rocm-smi) sampled in a thread while a sustained leg runs: the 6-biquad cascade at 1 M streams
+    sits at the package power cap and the firmware lowers the clock until it fits (profiles/r03/power_and_clocks.txt), so a run's
+    number is also a statement about the board.  The board is torch's device mapped to rocm-smi's card by PCI bus id; one sample
+    per second (a rocm-smi process each).  Best effort: None when rocm-smi is missing, the board cannot be told or it prints
+    something else."""
+
+    def __init__(self, torch, device_index=0, period=1.0):
         import threading
-        self.exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
-        self.dev, self.period, self.rows, self._stop = device_index, period, [], False
-        self.thread = threading.Thread(target=self._run, daemon=True) if self.exe else None
+        self.exe, self.card = rocm_smi_card_of(torch, device_index)
+        self.period, self.rows, self._stop = period, [], False
+        self.thread = threading.Thread(target=self._run, daemon=True) if (self.exe and self.card is not None) else None
 
     def _run(self):
         import re
         import subprocess
         while not self._stop:
             try:
-                o = subprocess.run([self.exe, "-d", str(self.dev), "--showpower", "--showclocks", "--showmaxpower", "--json"],
+                o = subprocess.run([self.exe, "-d", str(self.card), "--showpower", "--showclocks", "--showmaxpower", "--json"],
                                    capture_output=True, text=True, timeout=5).stdout
                 c = next(iter(json.loads(o).values()))
                 watts = [float(v) for k, v in c.items() if "Power (W)" in k and "Max" not in k]
@@ -261,14 +290,16 @@ class PowerSampler:
                     self.rows.append((time.perf_counter(), watts[0], cap[0] if cap else None, sclk[0]))
             except Exception:  # noqa: BLE001 -- a sampler must never take the bench down
                 pass
-            time.sleep(self.period)
+            t_end = time.perf_counter() + self.period
+            while not self._stop and time.perf_counter() < t_end:
+                time.sleep(0.05)
 
     def start(self):
         if self.thread:
             self.thread.start()
         self.t0 = time.perf_counter()
 
-    def stop(self, settle=0.7):
+    def stop(self, settle=0.5):
         self._stop = True
         if self.thread:
             self.thread.join(timeout=6)
@@ -278,26 +309,28 @@ class PowerSampler:
         med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
         watts, cap = med([r[1] for r in rows]), rows[0][2]
         return {"package_W": watts, "cap_W": cap, "at_power_cap": bool(cap and watts >= 0.98 * cap), "sclk_MHz": med([r[3] for r in rows]),
-                "samples": len(rows), "source": "rocm-smi --showpower --showclocks, median over the sustained leg"}
+                "samples": len(rows), "rocm_smi_card": self.card,
+                "source": "rocm-smi --showpower --showclocks of the board with torch's PCI bus id, median over the sustained leg"}
 
 
-def b_alg_of(prog, ns, T):
-    return ns * (4 * T * (prog.n_in + prog.n_out) + 8 * prog.n_state + 4 * prog.n_param)
-
-
-def gather_streams(torch, y, ids, tile):
-    """[T, len(ids), w] numpy of the streams `ids` (local indices) of a frame tensor."""
-    idt = torch.as_tensor(ids, device=y.device, dtype=torch.long)
-    if tile:
-        return y[idt // tile, :, idt % tile, :].permute(1, 0, 2).contiguous().cpu().numpy()
-    return y[:, idt].contiguous().cpu().numpy()
+def sustained_run(torch, fn, ms_est, dev_index, seconds=2.0, min_batch=1):
+    """fn back to back for >= `seconds` of GPU time in batches of ~0.25 s (one HIP-event pair each), board power sampled meanwhile"""
+    batch = max(min_batch, int(math.ceil(250.0 / max(ms_est, 1e-3))))
+    n, ms_tot = 0, 0.0
+    sampler = PowerSampler(torch, dev_index)
+    sampler.start()
+    while ms_tot < seconds * 1e3 and n < 4_000_000:
+        ms_tot += event_ms(torch, fn, batch) * batch
+        n += batch
+    return n, ms_tot, sampler.stop()
 
 
 def sample_ids(ns, k, seed):
     import numpy as np
 
     rng = np.random.default_rng(seed)
-    return np.unique(np.concatenate([[0, 1, 63, 64, ns - 1], rng.integers(0, ns, k)]))
+    edge = [i for i in (0, 1, 63, 64, ns - 1) if 0 <= i < ns]
+    return np.unique(np.concatenate([edge, rng.integers(0, ns, k)]))
 
 
 def ndiff_bits(a, b):
@@ -312,45 +345,328 @@ def parity_string(nd, n_streams, T):
     return f"bitwise-equal on {n_streams} random streams x {T} samples" if nd == 0 else f"MISMATCH {nd} samples"
 
 
+def _profile_table(name):
+    path = os.path.join(ROOT, "profiles", name)
+    return json.load(open(path)) if os.path.exists(path) else {}
+
+
 def traffic_of(kernel, workload_key):
-    """PMC HBM bytes per launch of exactly this kernel symbol on this workload, or None."""
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(tpath):
-        return None
-    return json.load(open(tpath)).get(f"{kernel}|{workload_key}")
+    """PMC HBM bytes per launch of exactly this kernel symbol on this workload (profiles/pmc_traffic.json), or None."""
+    return _profile_table("pmc_traffic.json").get(f"{kernel}|{workload_key}")
 
 
-def measure_config(torch, F, prog, x, y, state, params, ns, T, tile, steps, workload_key, do_tune=True):
-    """library default and (optionally) the tuned plan of one workload: ms per launch, GB/s, fraction of peak."""
-    b = b_alg_of(prog, ns, T)
-    out = {}
+def issue_share_of(kernel, workload_key):
+    """SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of this kernel on this workload from the committed counter passes
+    (profiles/sq_issue_share.json), or None."""
+    return _profile_table("sq_issue_share.json").get(f"{kernel}|{workload_key}")
+
+
+def limiter_of(issue_share, board, frac_of_row_walk):
+    """What holds a kernel back, as far as the run itself can tell: "issue" when the counter passes show its waves issuing
+    in >= 60 % of their cycles (the lone wave of a SIMD: nothing left to overlap), "power" when the board sat at its package cap during the sustained
+    run and the kernel is more than 3 % slower than the arithmetic-free row walk measured on the same box (the cap took the
+    clock the arithmetic needed), else "hbm"."""
+    if issue_share is not None and issue_share >= 0.60:
+        return "issue"
+    if board and board.get("at_power_cap") and frac_of_row_walk is not None and frac_of_row_walk < 0.97:
+        return "power"
+    return "hbm"
+
+
+# ---- workloads ---------------------------------------------------------------------------------------------------------
+class Spec:
+    """One synthetic workload: a graph, its size, its drive, its coefficients and the oracle that checks it."""
+
+    def __init__(self, key, desc, graph, ns, T, oracle, drive="noise", typed=False, params=None, mod=None, blocks=None, b_alg=None,
+                 n_parity=PARITY_STREAMS, seed_off=0):
+        self.key, self.desc, self.graph, self.ns, self.T, self.oracle = key, desc, graph, int(ns), int(T), oracle
+        self.drive, self.typed, self.params, self.mod, self.blocks, self._b_alg = drive, typed, params, mod, blocks, b_alg
+        self.n_parity, self.seed_off = n_parity, seed_off
+        self._prog = None
+
+    def resized(self, ns, T=None):
+        """the same workload at another size (shares the compiled program)"""
+        q = Spec(self.key, self.desc, self.graph, ns, T or self.T, self.oracle, self.drive, self.typed, self.params, self.mod, self.blocks, self._b_alg,
+                 self.n_parity, self.seed_off)
+        q._prog = self._prog
+        return q
+
+    def program(self, F):
+        if self._prog is None:
+            self._prog = F.compile(F.from_sexpr(self.graph), typed=self.typed)
+        return self._prog
+
+    def b_alg(self, prog):
+        if self._b_alg:
+            return int(self._b_alg(prog, self.ns, self.T))
+        return self.ns * (4 * self.T * (prog.n_in + prog.n_out) + 8 * prog.n_state + 4 * prog.n_param)
+
+
+class Ctx:
+    pass
+
+
+def gather(torch, y, ids, layout, tile):
+    """[T, len(ids), w] numpy of the streams `ids` (local indices) of a frame / stream-major tensor."""
+    idt = torch.as_tensor(ids, device=y.device, dtype=torch.long)
+    if layout == "stream_major":
+        return y[idt].permute(1, 0, 2).contiguous().cpu().numpy()
+    if tile:
+        return y[idt // tile, :, idt % tile, :].permute(1, 0, 2).contiguous().cpu().numpy()
+    return y[:, idt].contiguous().cpu().numpy()
+
+
+LAYOUT_TEXT = {"time_major": "plain time-major frames [t][stream][wire] (SURVEY 8d's device layout)",
+               "stream_major": "stream-major buffers [stream][t][wire] (the reference's calling convention, test/benchmark.cpp:137-147), no layout pass"}
+
+
+def leg(cx, sp, layout, tile=0, tune=True, forced=None, energy=False, reps_ms=60.0, keep=None):
+    """One workload on one layout: library default and tuned plan (ms per launch from HIP events, GB/s, fraction of peak,
+    PMC traffic when profiled), oracle parity of the best plan on random streams.  layout: time_major | tiled | stream_major."""
+    torch, F, np, dev = cx.torch, cx.F, cx.np, cx.dev
+    prog = sp.program(F)
+    ns, T = sp.ns, sp.T
+    sm = layout == "stream_major"
+    tile = pick_tile(ns, tile) if layout == "tiled" else 0
+    lay = "streammajor" if sm else (f"tile{tile}" if tile else "timemajor")
+    wkey = f"{sp.key}_{ns}x{T}_{lay}"
+    nin = max(prog.n_in, 1)
+    xf = frames(torch, dev, ns, T, nin, tile)
+    if sp.drive == "dirac":                                  # a dirac at t = 0 on every stream
+        xf.zero_()
+        (xf[:, 0] if tile else xf[0]).fill_(1.0)
+    else:
+        F.synth_fill(xf, cx.SEED + sp.seed_off)
+    if sm:
+        x = torch.empty((ns, T, nin), dtype=torch.float32, device=dev)
+        F.frames_to_stream_major(xf, out=x)
+        del xf
+        y = torch.empty((ns, T, prog.n_out), dtype=torch.float32, device=dev)
+    else:
+        x, y = xf, frames(torch, dev, ns, T, prog.n_out, tile)
+    state = torch.zeros((max(prog.n_state, 1), ns), dtype=torch.float32, device=dev)
+    pd = None
+    if sp.params is not None:
+        pd = torch.from_numpy(sp.params(np.arange(ns))).to(dev)
+    if sp.mod is not None:
+        prog.set_modulation(torch.from_numpy(sp.mod).to(dev))
+    bank = pb = None
+    if sp.blocks:                                            # control-rate coefficient sets: fz_bank_process_blocks
+        L, pfn = sp.blocks
+        nb = (T + L - 1) // L
+        pb = torch.empty((nb, prog.n_param, ns), dtype=torch.float32, device=dev)
+        for k in range(nb):
+            pb[k].copy_(torch.from_numpy(pfn(k, np.arange(ns))))
+        bank = prog.bank(ns)
+    SMF = F.C.FZ_VF_STREAM_MAJOR
+
+    def mk(v):
+        return None if v is None else (v if isinstance(v, F.Variant) else F.make_variant(*v))
 
     def run(v):
-        prog.run_block(x, state=state, params=params, out=y, variant=v)
+        if bank is not None:
+            bank.process_blocks(x, y, sp.blocks[0], pb, variant=mk(v))
+        elif sm:
+            prog.run_block_stream_major(x, state=state, params=pd, out=y, variant=mk(v))
+        else:
+            prog.run_block(x, state=state, params=pd, out=y, variant=mk(v))
 
-    def timed(label, v):
+    def name_of(v):
+        if bank is not None:
+            return prog.kernel_name(mk(v), ns, sp.blocks[0], tile)
+        if sm:
+            q = mk(v) or F.make_variant(0, 0, 0, 0)
+            return prog.kernel_name(F.make_variant(q.streams_per_lane, q.unroll, q.block_threads, q.flags | SMF), ns, T)
+        return prog.kernel_name(mk(v) if v is not None else prog.plan(ns, tile), ns, T, tile)
+
+    b = sp.b_alg(prog)
+
+    def timed(v):
         for _ in range(3):
-            run(v)
+            run(v)                                           # (no variant: the first big launch of a shape measures the candidates at hand)
         torch.cuda.synchronize()
-        ms = event_ms(torch, lambda: run(v), steps)
-        k = prog.kernel_name(v if v is not None else prog.plan(ns, tile), ns, T, tile)
-        out[label] = {"kernel": k, "avg_launch_ms": round(ms, 4), "Msamples_per_s": round(ns * T / ms / 1e3, 1),
-                      "achieved_GBs": round(b / ms / 1e6, 1), "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4),
-                      "traffic": traffic_of(k, workload_key)}
+        ms1 = event_ms(torch, lambda: run(v), 1)
+        reps = max(5, min(400, int(math.ceil(reps_ms / max(ms1, 1e-3)))))
+        ms = event_ms(torch, lambda: run(v), reps)
+        k = name_of(v)
+        return {"kernel": k, "avg_launch_ms": round(ms, 4), "Msamples_per_s": round(ns * T / ms / 1e3, 1), "achieved_GBs": round(b / ms / 1e6, 1),
+                "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic_of(k, wkey), "launches_timed": reps}
 
-    # what a caller who never tunes gets: no variant.  The first big launch of a shape measures the candidates at hand by itself
-    # (the warm-up launches above the timed ones; FLOWZ_HIP_AUTOTUNE=0 / --no-autotune: the static choice)
-    timed("library_default", None)
-    tv = None
-    if do_tune:
-        tv, _ = prog.tune(x, state=state, params=params, out=y)
-        timed("tuned", tv)
-    out["algorithmic_bytes_per_launch"] = b
-    out["steps"] = steps
-    best = max((k for k in ("library_default", "tuned") if k in out), key=lambda k: out[k]["frac"])
-    out["frac"] = out[best]["frac"]
-    out["best_plan"] = best
-    return out, tv
+    res = {}
+    best_v = forced
+    if forced is not None:
+        res["forced"] = timed(forced)
+    else:
+        res["library_default"] = timed(None)
+        if tune and bank is None:
+            if sm:
+                cands = {}
+                for v in cx.W.SM_CANDIDATES:
+                    try:
+                        cands[v] = timed(v)
+                    except F.FlowzError:
+                        pass                                  # (a body this graph does not allow)
+                best_v = min(cands, key=lambda v: cands[v]["avg_launch_ms"])
+                # (as in fz_program_tune: a candidate replaces the default only when it wins by more than the scatter of repeats)
+                if cands[best_v]["avg_launch_ms"] > 0.985 * res["library_default"]["avg_launch_ms"]:
+                    best_v = None
+                res["tuned"] = timed(best_v)
+                res["candidates_ms"] = {f"{v[0]},{v[1]},{v[2]},{v[3]}": c["avg_launch_ms"] for v, c in cands.items()}
+            else:
+                best_v, _ = prog.tune(x, state=state, params=pd, out=y)
+                res["tuned"] = timed(best_v)
+    plans = [k for k in ("library_default", "tuned", "forced") if k in res]
+    best = max(plans, key=lambda k: res[k]["frac"])
+    res["frac"], res["best_plan"], res["algorithmic_bytes_per_launch"] = res[best]["frac"], best, b
+    if energy:                                               # joules per launch at the board's sustained state (>= 1 s back to back)
+        n_sus, ms_tot, board = sustained_run(torch, lambda: run(best_v), res[best]["avg_launch_ms"], dev.index or 0, seconds=1.5)
+        res["sustained"] = {"launches": n_sus, "avg_launch_ms": round(ms_tot / n_sus, 4), "frac": round(b / (ms_tot / n_sus) / 1e6 / HBM_PEAK_GBS, 4), "board": board,
+                            "joules_per_launch": round(board["package_W"] * ms_tot / n_sus / 1e3, 3) if board else None}
+    sh = issue_share_of(res[best]["kernel"], wkey)
+    if sh is not None:
+        res["issue_share"] = round(sh, 3)
+        res["limiter"] = limiter_of(sh, (res.get("sustained") or {}).get("board") or cx.head_board, None)
+    # parity: one block from zero state with the best plan against the oracle, random streams
+    if bank is not None:
+        bank.reset()
+    state.zero_()
+    run(best_v if best != "library_default" else None)
+    torch.cuda.synchronize()
+    ids = sample_ids(ns, sp.n_parity, 11 + sp.seed_off)
+    nd = ndiff_bits(gather(torch, y, ids, layout, tile), sp.oracle(sp, ids))
+    if sp.drive != "dirac":
+        from oracle import flowz_oracle as O
+        nd += ndiff_bits(gather(torch, x, ids, layout, tile), O.synth_input(cx.SEED + sp.seed_off, ids, T, n_wires=nin))   # the device generator itself
+    res["parity"] = parity_string(nd, len(ids), T)
+    res["workload"] = f"{sp.desc}, {ns} streams x {T}-sample block, " + (LAYOUT_TEXT.get(layout) or f"stream-tiled frames [tile][t][{tile} streams][wire]")
+    if keep is not None:
+        keep.update(x=x, y=y, state=state, prog=prog)
+    return res
+
+
+def make_specs(cx, ns_big, T):
+    """The workloads of the bench line.  Oracle closures import oracle/ lazily: the checker."""
+    np, W = cx.np, cx.W
+
+    def noise(sp, ids, nw=1):
+        from oracle import flowz_oracle as O
+        return O.synth_input(cx.SEED + sp.seed_off, ids, sp.T, n_wires=nw)
+
+    def dirac(sp, ids):
+        x = np.zeros((sp.T, len(ids), 1), np.float32)
+        x[0] = 1.0
+        return x
+
+    def o_cascade(sp, ids):
+        from oracle import coracle
+        return coracle.df1_cascade([W.STABLE] * 6, noise(sp, ids))
+
+    def o_par4(fanout):
+        def f(sp, ids):
+            from oracle import coracle
+            return coracle.par4_sum(W.PAR4_SETS, noise(sp, ids, nw=1 if fanout else 4), fanout=fanout)
+        return f
+
+    def o_osc(sp, ids):
+        from oracle import coracle
+        return coracle.osc_chain(np.ascontiguousarray(W.osc_chain_params(cx.SEED + 1, ids)), dirac(sp, ids))
+
+    def o_generic(graph, typed=False, mod=None):
+        def f(sp, ids):
+            from oracle import flowz_oracle as O
+            x = noise(sp, ids)
+            if typed:
+                orc = O.compile(graph, len(ids), typed=True)
+                return cx.F.pack_typed(O.run_typed(orc, [x[:, :, 0]]), O.output_dtypes_typed(graph))
+            return O.compile(graph, len(ids)).run(x, mod=mod)
+        return f
+
+    S = {}
+    cas = W.df1_cascade(6)
+    for ns in (ns_big, 65536, 32768, 16384, 262144):
+        S[f"cascade6_{ns}"] = Spec("cascade6", "6-stage DF1 cascade (flowz fwd|=bwd x6), uniform stable coefficients", cas, ns, T, o_cascade)
+    S["par4"] = Spec("par4", "(bq|bq|bq|bq) |= (_1+_2+_3+_4), 4 input wires (BASELINE configs[2])", W.par4_sum(), ns_big, T, o_par4(False))
+    S["par4f"] = Spec("par4f", "(_1,_1,_1,_1) |= (bq|bq|bq|bq) |= (_1+_2+_3+_4), 1 input wire (BASELINE configs[2], fan-out variant)", W.par4_sum_fanout(), ns_big, T, o_par4(True))
+    S["osc6"] = Spec("osc6", "resonator oscillator -> 6 x DF1, 31 per-stream coefficients, dirac drive (BASELINE configs[3])", W.osc_chain(6), ns_big, T, o_osc,
+                     drive="dirac", params=lambda ids: W.osc_chain_params(cx.SEED + 1, ids))
+    # the reference's own benchmark cases, test/benchmark.cpp:157-262 (coefficients :18-23)
+    REFC = (W.B0, W.B1, W.B2, W.A1, W.A2)
+
+    def o_ref(fn):
+        def f(sp, ids):
+            from oracle import coracle
+            x = noise(sp, ids)
+            return coracle.df1_cascade([REFC], x) if fn == "df1" else getattr(coracle, fn)(REFC, x)
+        return f
+    for name, g, fn in (("df1", W.df1(), "df1"), ("df2", W.df2(), "df2"), ("df1t", W.df1t(), "df1t"), ("df2t", W.df2t(), "df2t_flowz")):
+        S[name] = Spec(name, f"single biquad {name.upper()} of test/benchmark.cpp:157-262 (coefficients :18-23)", g, ns_big, T, o_ref(fn), seed_off=3)
+    # SURVEY 8(f) rows
+    S["lds_ring"] = Spec("ldsring", "f1: (_1 + 0.5*_1[_40]) |= ~(0.7*_1[_23] + _2), delay lines of 40 and 23 samples in LDS rings", W.lds_ring_comb(), ns_big, T,
+                         o_generic(W.lds_ring_comb()), n_parity=192, seed_off=4)
+    S["far_ring"] = Spec("farring", "f1: ~(0.5*_1[_300] + _2), a 300-sample delay line as a ring in HBM (16 algorithmic bytes per stream-sample: frame in/out + one appended row + one far read)",
+                         W.far_comb(300), ns_big, T, o_generic(W.far_comb(300)), n_parity=192, seed_off=5,
+                         b_alg=lambda p, ns, TT: ns * (4 * TT * 4 + 8))
+    L = 64
+    nbk = (T + L - 1) // L
+
+    def block_params(k, ids):                                # coefficient set of block k: the oscillator chain's stage sets, re-drawn per block
+        return np.ascontiguousarray(W.osc_chain_params(cx.SEED + 7 + k, ids)[1:])
+
+    def o_blocks(sp, ids):
+        from oracle import flowz_oracle as O
+        g = W.df1_cascade_params(6)
+        f = O.compile(g, len(ids), params=block_params(0, ids))
+        x, outs = noise(sp, ids), []
+        for k in range(nbk):
+            f._params = np.ascontiguousarray(block_params(k, ids), np.float32)
+            outs.append(f.run(x[k * L:(k + 1) * L]))
+        return np.concatenate(outs)
+    S["blocks64"] = Spec("blocks64", f"f2: 6 x DF1 with 30 per-stream coefficients under fz_bank_process_blocks, {L}-sample windows, one coefficient set per window "
+                                     "(std::ref terminals at block rate, flowz/README.md:42-61)", W.df1_cascade_params(6), ns_big, T, o_blocks, blocks=(L, block_params),
+                         n_parity=128, seed_off=6, b_alg=lambda p, ns, TT: ns * (4 * TT * 2 + ((TT + L - 1) // L) * (8 * p.n_state + 4 * p.n_param)))
+    modv = (0.2 + 0.1 * W.hash32(cx.SEED + 9, 0, np.arange(T)).astype(np.float64) / 4294967296.0).astype(np.float32)[None, :]
+    S["modulated"] = Spec("mod6", "f2: 6 x DF1 whose a1 is a sample-rate fz_modulator (std::ref re-read every sample, flowz/README.md:42-61), one value per sample for all streams",
+                          W.df1_cascade_modulated(6), ns_big, T, o_generic(W.df1_cascade_modulated(6), mod=modv), mod=modv, n_parity=192, seed_off=8)
+    S["double_biquad"] = Spec("f64biquad", "f3: one DF1 biquad with double literals under fz_compile_typed: double wires, double delay line, double output frames "
+                                           "(ResultType, flowz.hpp:585-644) -- 12 frame bytes per sample, FP64 arithmetic", W.df1_double(), ns_big, T,
+                              o_generic(W.df1_double(), typed=True), typed=True, n_parity=128, seed_off=10)
+
+    def o_cplx(sp, ids):
+        from oracle import coracle
+        return coracle.complex_one_pole(noise(sp, ids), std=True)
+    S["complex_one_pole"] = Spec("c32onepole", "f3: ~( c*_1[_1] + _2 ) with a std::complex<float> coefficient under fz_compile_typed: complex wire and delay line, "
+                                               "(re, im) output frames (test/tests.cpp:206-207)", W.complex_one_pole(), ns_big, T, o_cplx, typed=True, seed_off=11)
+    return S
+
+
+def obj_layouts(cx, sp, first_layout, first_tile, steps_hint=None, tune=True):
+    """A config object: today's primary figure at top level (its layout named in `workload`), plus `time_major` and `stream_major`
+    sub-objects -- the two contract layouts (test/benchmark.cpp:137-147)."""
+    torch = cx.torch
+    res = leg(cx, sp, first_layout, first_tile, tune=tune)
+    torch.cuda.empty_cache()
+    res.update({k: res[res["best_plan"]][k] for k in ("avg_launch_ms", "Msamples_per_s", "achieved_GBs", "kernel")})
+    if first_layout != "time_major":
+        res["time_major"] = leg(cx, sp, "time_major", tune=tune)
+        torch.cuda.empty_cache()
+    res["stream_major"] = leg(cx, sp, "stream_major", tune=tune)
+    torch.cuda.empty_cache()
+    return res
+
+
+def dirac_check(cx, name, graph):
+    """the first 201 samples of the dirac response on every stream of a small block against the vectors the reference's own
+    hand-written filter produced (tests/golden/ref_biquad_vectors.json; oracle/build_ref.sh)"""
+    torch, F, np = cx.torch, cx.F, cx.np
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_biquad_vectors.json")))
+    want = np.array([int(h, 16) for h in ref["outputs"]["dirac"][name]], np.uint32)[:201]
+    prog = F.compile(F.from_sexpr(graph))
+    x = torch.zeros((201, 256, 1), dtype=torch.float32, device=cx.dev)
+    x[0].fill_(1.0)
+    y, _ = prog.run_block(x)
+    got = y[:, :, 0].cpu().numpy().view(np.uint32)
+    nd = int((got != want[:, None]).sum())
+    return "bitwise-equal to the reference-built vector on 256 streams x 201 samples" if nd == 0 else f"MISMATCH {nd}"
 
 
 def main():
@@ -374,18 +690,20 @@ def main():
                          "3 also the fastest: CU-wide workgroups in lockstep, XCD-wide synchronised), else streams per frame tile "
                          "(stream-tiled layout [tile][t][stream])")
     ap.add_argument("--secondary-tile", type=int, default=8192,
-                    help="streams per frame tile of the secondary configs and of the tiled-layout leg (1-wire frames; 0 = time-major)")
+                    help="streams per frame tile of the tiled-layout legs (1-wire frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-config2", action="store_true", help="skip the 65 536-stream measurement (BASELINE configs[1])")
+    ap.add_argument("--no-config2", action="store_true", help="skip the 65 536 / 32 768 / 16 384-stream objects (BASELINE configs[1] and below)")
     ap.add_argument("--no-config34", action="store_true", help="skip BASELINE configs[2] and [3] (4-parallel sum, oscillator chain)")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8(f) kernels (LDS / HBM rings, block-rate and sample-rate modulation, typed state)")
+    ap.add_argument("--no-extras", action="store_true", help="skip ragged stream counts, the reference's benchmark topologies and the smaller stream-major shapes")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s back-to-back run")
-    ap.add_argument("--only", default="", help="profiling aid: run ONLY this secondary config (config2|config2h|config2q|config3|config3f|config4) "
-                                               "with the forced / default variant and print its object")
+    ap.add_argument("--only", default="", help="profiling aid: run ONLY this object / leg (see OBJECTS in the source; <object>:<layout> picks one layout) "
+                                               "with the forced / default variant and print it")
     ap.add_argument("--no-autotune", action="store_true",
                     help="do not try the alternative kernel variants during warm-up (the pool's boxes differ by a few %%)")
     ap.add_argument("--no-layout-legs", action="store_true",
-                    help="skip the same workload on the two contract layouts: plain time-major frames [t][stream] (SURVEY 8d) and "
-                         "stream-major buffers [stream][t] (the reference's calling convention, test/benchmark.cpp:137-147)")
+                    help="skip the headline workload on the other layouts: stream tiles and stream-major buffers [stream][t] "
+                         "(the reference's calling convention, test/benchmark.cpp:137-147)")
     args = ap.parse_args()
     if args.no_autotune:
         os.environ["FLOWZ_HIP_AUTOTUNE"] = "0"               # library_default = the static choice, nothing measured on first use
@@ -435,176 +753,81 @@ def main():
     tile = pick_tile(ns, args.tile)
     lay = f"tile{tile}" if tile else "timemajor"
 
+    cx = Ctx()
+    cx.torch, cx.F, cx.W, cx.np, cx.dev, cx.args, cx.SEED, cx.head_board = torch, F, W, np, dev, args, SEED, None
+    do_tune = not args.no_autotune
+    S = make_specs(cx, args.streams, T)
+    big = args.streams
+
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- secondary configs (rank 0, N == 1): each frees its buffers before the next ---------------------------------
-    def config2(ns2=65536):
-        t2 = pick_tile(ns2, args.secondary_tile)
-        x2, y2 = frames(torch, dev, ns2, T, 1, t2), frames(torch, dev, ns2, T, 1, t2)
-        st2 = torch.zeros((prog.n_state, ns2), dtype=torch.float32, device=dev)
-        F.synth_fill(x2, SEED)
-        key = f"cascade6_{ns2}x{T}_" + (f"tile{t2}" if t2 else "timemajor")
-        if args.only:
-            for _ in range(20):
-                prog.run_block(x2, state=st2, out=y2, variant=variant)
-            ms = event_ms(torch, lambda: prog.run_block(x2, state=st2, out=y2, variant=variant), 200)
-            return {"kernel": prog.kernel_name(variant, ns2, T, t2), "avg_launch_ms": round(ms, 4)}
-        for _ in range(20):
-            prog.run_block(x2, state=st2, out=y2)
-        res, tv = measure_config(torch, F, prog, x2, y2, st2, None, ns2, T, t2, 200, key, do_tune=not args.no_autotune)
-        st2.zero_()
-        prog.run_block(x2, state=st2, out=y2, variant=tv)
-        ids = sample_ids(ns2, PARITY_STREAMS, 12)
-        from oracle import coracle, flowz_oracle as O
-        want = coracle.df1_cascade([W.STABLE] * 6, O.synth_input(SEED, ids, T))
-        res["parity"] = parity_string(ndiff_bits(gather_streams(torch, y2, ids, t2), want), len(ids), T)
-        res["workload"] = (f"6-stage DF1 cascade, {ns2} streams x {T}-sample block " + ("(BASELINE configs[1]), " if ns2 == 65536 else "(configs[1] with fewer streams than lanes), ")
-                           + (f"tiled:{t2}" if t2 else "time-major"))
-        # compatibility with round 1's keys: the best plan's figures at top level
-        res.update({k: res[res["best_plan"]][k] for k in ("avg_launch_ms", "Msamples_per_s", "achieved_GBs", "kernel")})
-        return res
+    # ---- the objects of the line besides the headline (rank 0, N == 1): each frees its buffers before the next -------------
+    def ragged_counts():
+        """odd shapes at scale, plain time-major frames, library default only"""
+        out = {}
+        counts = (1_000_000, 1_048_577, 786_432, 2_097_152) if big == (1 << 20) else (big * 1_000_000 // (1 << 20), big + 1, big * 3 // 4, big * 2)
+        for n in counts:
+            out[str(n)] = leg(cx, S[f"cascade6_{big}"].resized(n), "time_major", tune=False)
+            torch.cuda.empty_cache()
+        return out
 
-    def config3(fanout):
-        g = W.par4_sum_fanout() if fanout else W.par4_sum()
-        p3 = F.compile(F.from_sexpr(g))
-        # the 4-wire sum on stream tiles (its rows are wide: tiles stream best), the 1-wire fan-out variant on plain time-major
-        # frames like the headline (CU-wide lockstep workgroups, XCD-wide synchronised: 0.80 against 0.77-0.78 on tiles)
-        t3 = 0 if fanout else pick_tile(ns3, p3.recommended_tile_streams())
-        x3, y3 = frames(torch, dev, ns3, T, p3.n_in, t3), frames(torch, dev, ns3, T, 1, t3)
-        st3 = torch.zeros((p3.n_state, ns3), dtype=torch.float32, device=dev)
-        F.synth_fill(x3, SEED)
-        key = ("par4f_" if fanout else "par4_") + f"{ns3}x{T}_" + (f"tile{t3}" if t3 else "timemajor")
-        if args.only:
-            for _ in range(3):
-                p3.run_block(x3, state=st3, out=y3, variant=variant)
-            ms = event_ms(torch, lambda: p3.run_block(x3, state=st3, out=y3, variant=variant), 5)
-            return {"kernel": p3.kernel_name(variant, ns3, T, t3), "avg_launch_ms": round(ms, 4)}
-        res, tv = measure_config(torch, F, p3, x3, y3, st3, None, ns3, T, t3, 10, key, do_tune=not args.no_autotune)
-        st3.zero_()
-        p3.run_block(x3, state=st3, out=y3, variant=tv)
-        ids = sample_ids(ns3, PARITY_STREAMS, 13)
-        from oracle import coracle, flowz_oracle as O
-        xh = O.synth_input(SEED, ids, T, n_wires=p3.n_in)
-        nd_in = ndiff_bits(gather_streams(torch, x3, ids, t3), xh)
-        want = coracle.par4_sum(W.PAR4_SETS, xh, fanout=fanout)
-        nd = ndiff_bits(gather_streams(torch, y3, ids, t3), want)
-        res["parity"] = parity_string(nd + nd_in, len(ids), T)
-        res["workload"] = (("(_1,_1,_1,_1) |= " if fanout else "") + f"(bq|bq|bq|bq) |= (_1+_2+_3+_4), {p3.n_in} input wire(s), {ns3} streams x {T}-sample "
-                           f"block (BASELINE configs[2]), " + (f"tiled:{t3}" if t3 else "time-major"))
-        return res
+    def reference_topologies():
+        """test/benchmark.cpp:157-262: the four single-stage forms at full size on time-major frames (noise drive, oracle parity) and
+        their dirac responses against the vectors built from the reference's own filters"""
+        out = {}
+        for name in ("df1", "df2", "df1t", "df2t"):
+            r = leg(cx, S[name], "time_major", tune=do_tune)
+            r["dirac_201"] = dirac_check(cx, name, S[name].graph)
+            out[name] = r
+            torch.cuda.empty_cache()
+        return out
 
-    def config4():
-        p4 = F.compile(F.from_sexpr(W.osc_chain(6)))
-        t4 = pick_tile(ns3, args.secondary_tile)
-        x4, y4 = frames(torch, dev, ns3, T, 1, t4), frames(torch, dev, ns3, T, 1, t4)
-        st4 = torch.zeros((p4.n_state, ns3), dtype=torch.float32, device=dev)
-        P = W.osc_chain_params(SEED + 1, np.arange(ns3))
-        pd = torch.from_numpy(P).to(dev)
-        x4.zero_()                                           # a dirac at t = 0 on every stream
-        (x4[:, 0] if t4 else x4[0]).fill_(1.0)
-        key = f"osc6_{ns3}x{T}_" + (f"tile{t4}" if t4 else "timemajor")
-        if args.only:
-            for _ in range(3):
-                p4.run_block(x4, state=st4, params=pd, out=y4, variant=variant)
-            ms = event_ms(torch, lambda: p4.run_block(x4, state=st4, params=pd, out=y4, variant=variant), 10)
-            return {"kernel": p4.kernel_name(variant, ns3, T, t4), "avg_launch_ms": round(ms, 4)}
-        res, tv = measure_config(torch, F, p4, x4, y4, st4, pd, ns3, T, t4, 20, key, do_tune=not args.no_autotune)
-        st4.zero_()
-        p4.run_block(x4, state=st4, params=pd, out=y4, variant=tv)
-        ids = sample_ids(ns3, PARITY_STREAMS, 14)
-        from oracle import coracle
-        xh = np.zeros((T, len(ids), 1), np.float32)
-        xh[0] = 1.0
-        want = coracle.osc_chain(np.ascontiguousarray(P[:, ids]), xh)
-        res["parity"] = parity_string(ndiff_bits(gather_streams(torch, y4, ids, t4), want), len(ids), T)
-        res["workload"] = (f"resonator oscillator -> 6 x DF1, 31 per-stream coefficients, dirac drive, {ns3} streams x {T}-sample block "
-                           f"(BASELINE configs[3]), " + (f"tiled:{t4}" if t4 else "time-major"))
-        return res
+    def next_rows():
+        out = {}
+        for name in ("lds_ring", "far_ring", "blocks64", "modulated", "double_biquad", "complex_one_pole"):
+            out[name] = leg(cx, S[name], "time_major", tune=do_tune and name != "blocks64")
+            torch.cuda.empty_cache()
+        out["double_biquad"]["bound_note"] = ("FP64 issue: 9 double operations per sample (v_mul_f64 / v_add_f64 issue at a quarter of the packed-FP32 rate per lane) "
+                                              "next to 12 frame bytes per sample")
+        return out
 
-    def frame_layout_leg(tl):
-        """The headline workload on the OTHER frame layout -- stream tiles when the headline runs on plain time-major frames
-        [t][stream] (SURVEY 8d's device layout, the default), time-major frames when it was asked to run on tiles: library default and tuned."""
-        tl = pick_tile(ns, tl)
-        x2, y2 = frames(torch, dev, ns, T, 1, tl), frames(torch, dev, ns, T, 1, tl)
-        st2 = torch.zeros((prog.n_state, ns), dtype=torch.float32, device=dev)
-        F.synth_fill(x2, SEED)
-        key = f"cascade6_{ns}x{T}_" + (f"tile{tl}" if tl else "timemajor")
-        res, tv = measure_config(torch, F, prog, x2, y2, st2, None, ns, T, tl, max(5, args.steps // 2), key, do_tune=not args.no_autotune)
-        st2.zero_()
-        prog.run_block(x2, state=st2, out=y2, variant=tv)
-        ids = sample_ids(ns, PARITY_STREAMS, 15)
-        from oracle import coracle, flowz_oracle as O
-        want = coracle.df1_cascade([W.STABLE] * 6, O.synth_input(SEED, ids, T))
-        res["parity"] = parity_string(ndiff_bits(gather_streams(torch, y2, ids, tl), want), len(ids), T)
-        res["workload"] = (f"6-stage DF1 cascade, {ns} streams x {T}-sample block, " +
-                           (f"stream-tiled frames [tile][t][{tl} streams]" if tl else "plain time-major frames [t][stream] (SURVEY 8d)"))
-        return res
+    def stream_major_shapes():
+        """the cascade on stream-major buffers at 262 144 streams and with 1024-sample blocks"""
+        out = {}
+        out[f"{min(262144, big)}_streams_x_{T}"] = leg(cx, S["cascade6_262144"] if big >= 262144 else S[f"cascade6_{big}"], "stream_major", tune=do_tune)
+        torch.cuda.empty_cache()
+        Ts = max(256, T // 4)
+        out[f"{big}_streams_x_{Ts}"] = leg(cx, S[f"cascade6_{big}"].resized(big, Ts), "stream_major", tune=do_tune)
+        torch.cuda.empty_cache()
+        return out
 
-    def stream_major_leg():
-        """The headline workload on stream-major buffers [stream][t] -- one contiguous sample buffer per closure, the reference's
-        calling convention (test/benchmark.cpp:137-147): fz_run_block_stream_major, library default and the best of SM_CANDIDATES."""
-        xf = frames(torch, dev, ns, T, 1, tile)
-        F.synth_fill(xf, SEED)
-        xs = torch.empty((ns, T, 1), dtype=torch.float32, device=dev)
-        F.frames_to_stream_major(xf, out=xs)
-        del xf
-        ys = torch.empty((ns, T, 1), dtype=torch.float32, device=dev)
-        st2 = torch.zeros((prog.n_state, ns), dtype=torch.float32, device=dev)
-        b = b_alg_of(prog, ns, T)
-        reps = max(5, args.steps // 2)
-        SMF = F.C.FZ_VF_STREAM_MAJOR
-
-        def one(v):
-            vv = None if v is None else F.make_variant(v[0], v[1], v[2], v[3])
-            for _ in range(2):
-                prog.run_block_stream_major(xs, state=st2, out=ys, variant=vv)
-            torch.cuda.synchronize()
-            ms = event_ms(torch, lambda: prog.run_block_stream_major(xs, state=st2, out=ys, variant=vv), reps)
-            q = v or (0, 0, 0, 0)
-            k = prog.kernel_name(F.make_variant(q[0], q[1], q[2], q[3] | SMF), ns, T)
-            return {"kernel": k, "avg_launch_ms": round(ms, 4), "Msamples_per_s": round(ns * T / ms / 1e3, 1),
-                    "achieved_GBs": round(b / ms / 1e6, 1), "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4),
-                    "traffic": traffic_of(k, f"cascade6_{ns}x{T}_streammajor")}
-
-        res = {"library_default": one(None)}
-        best_v = None
-        if not args.no_autotune:
-            cands = {}
-            for v in W.SM_CANDIDATES:
-                try:
-                    cands[v] = one(v)
-                except F.FlowzError:
-                    pass
-            best_v = min(cands, key=lambda v: cands[v]["avg_launch_ms"])
-            # (as in fz_program_tune: a candidate replaces the default only when it wins by more than the scatter of repeats)
-            if cands[best_v]["avg_launch_ms"] > 0.985 * res["library_default"]["avg_launch_ms"]:
-                best_v = (0, 0, 0, 0)
-            res["tuned"] = one(best_v)
-            res["candidates_ms"] = {f"{v[0]},{v[1]},{v[2]},{v[3]}": c["avg_launch_ms"] for v, c in cands.items()}
-        st2.zero_()
-        prog.run_block_stream_major(xs, state=st2, out=ys, variant=None if best_v is None else F.make_variant(*best_v))
-        ids = sample_ids(ns, PARITY_STREAMS, 16)
-        idt = torch.as_tensor(ids, device=dev, dtype=torch.long)
-        got = ys[idt].permute(1, 0, 2).contiguous().cpu().numpy()
-        from oracle import coracle, flowz_oracle as O
-        want = coracle.df1_cascade([W.STABLE] * 6, O.synth_input(SEED, ids, T))
-        res["parity"] = parity_string(ndiff_bits(got, want), len(ids), T)
-        res["algorithmic_bytes_per_launch"] = b
-        best = max((k for k in ("library_default", "tuned") if k in res), key=lambda k: res[k]["frac"])
-        res["frac"], res["best_plan"] = res[best]["frac"], best
-        res["workload"] = (f"6-stage DF1 cascade, {ns} streams x {T}-sample block, stream-major buffers [stream][t] "
-                           f"(the reference's calling convention, test/benchmark.cpp:137-147), no layout pass")
-        return res
-
-    ns3 = args.streams
+    OBJECTS = {
+        "config2": lambda: obj_layouts(cx, S["cascade6_65536"], "tiled", args.secondary_tile, tune=do_tune),
+        "config2h": lambda: leg(cx, S["cascade6_32768"], "tiled", args.secondary_tile, tune=do_tune),
+        "config2q": lambda: leg(cx, S["cascade6_16384"], "tiled", args.secondary_tile, tune=do_tune),
+        "config3": lambda: obj_layouts(cx, S["par4"], "tiled", S["par4"].program(F).recommended_tile_streams(), tune=do_tune),
+        "config3f": lambda: leg(cx, S["par4f"], "time_major", tune=do_tune),
+        "config4": lambda: obj_layouts(cx, S["osc6"], "tiled", args.secondary_tile, tune=do_tune),
+        "tiled": lambda: leg(cx, S[f"cascade6_{big}"], "tiled", args.secondary_tile, tune=do_tune),
+        "timemajor": lambda: leg(cx, S[f"cascade6_{big}"], "time_major", tune=do_tune),
+        "streammajor": lambda: leg(cx, S[f"cascade6_{big}"], "stream_major", tune=do_tune, energy=not args.no_sustained),
+        "streammajor_shapes": stream_major_shapes,
+        "ragged": ragged_counts,
+        "reftopo": reference_topologies,
+        "next_rows": next_rows,
+    }
     if args.only:
-        fn = {"config2": config2, "config2h": lambda: config2(32768), "config2q": lambda: config2(16384), "config3": lambda: config3(False), "config3f": lambda: config3(True),
-              "config4": config4, "timemajor": lambda: frame_layout_leg(0), "tiled": lambda: frame_layout_leg(args.secondary_tile),
-              "streammajor": stream_major_leg}[args.only]
-        print(json.dumps({args.only: fn()}), flush=True)
+        name, _, sub = args.only.partition(":")
+        if name in S and sub:                                # one workload on one layout, forced or default variant: <spec>:<layout>[:tile]
+            lay_, _, t_ = sub.partition(":")
+            v = (args.lanes, args.unroll, args.block, args.flags) if forced else None
+            r = leg(cx, S[name], lay_, int(t_ or 0), tune=False, forced=v)
+        else:
+            r = OBJECTS[name]()
+        print(json.dumps({args.only: r}), flush=True)
         return
 
     # ---- the headline workload ------------------------------------------------------------------------------------------
@@ -617,7 +840,7 @@ def main():
     # variants for this shape on THIS board (fz_program_tune, the FFTW_MEASURE of this library; which one
     # wins differs from board to board) -- later launches without a variant use the winner
     tuned = None
-    if not args.no_autotune and not forced:
+    if do_tune and not forced:
         variant, _ = prog.tune(x, state=state, out=y)
         tuned = prog.kernel_name(variant, ns, T, tile)
         state.zero_()
@@ -626,7 +849,7 @@ def main():
     prog.run_block(x, state=state, out=y, variant=variant)
     torch.cuda.synchronize()
     par_ids = sample_ids(ns, PARITY_STREAMS, 11) if rank == 0 else None
-    first_block = gather_streams(torch, y, par_ids, tile) if rank == 0 else None
+    first_block = gather(torch, y, par_ids, "tiled" if tile else "time_major", tile) if rank == 0 else None
     for _ in range(max(args.warmup - 1, 0)):
         prog.run_block(x, state=state, out=y, variant=variant)
 
@@ -645,62 +868,69 @@ def main():
 
     checksum = zdist.bits_checksum(y[:, -1] if tile else y[-1])      # last time step of every stream: exact, shard-independent
     stats = zdist.reduce_stats(wall, float(ns) * T * args.steps, checksum, device=stats_dev)
-    b_alg = b_alg_of(prog, ns, T)
+    b_alg = ns * (4 * T * (prog.n_in + prog.n_out) + 8 * prog.n_state + 4 * prog.n_param)
 
     # the same launches back to back for >= 2 s: whatever the power management does to the clocks has happened by then
     sustained = None
     if rank == 0 and world == 1 and not args.no_sustained:
-        # batches of launches (one HIP-event pair each) until >= 2 s of GPU time have gone by
-        batch = max(args.steps, int(math.ceil(0.25 / max(kern_avg_s, 1e-6))))
-        n_sus, ms_tot = 0, 0.0
-        sampler = PowerSampler(dev.index or 0)
-        sampler.start()
-        while ms_tot < 2000.0 and n_sus < 4_000_000:
-            ms_tot += event_ms(torch, lambda: prog.run_block(x, state=state, out=y, variant=variant), batch) * batch
-            n_sus += batch
+        n_sus, ms_tot, board = sustained_run(torch, lambda: prog.run_block(x, state=state, out=y, variant=variant), kern_avg_s * 1e3, dev.index or 0,
+                                             seconds=2.0, min_batch=args.steps)
         ms_sus = ms_tot / n_sus
+        cx.head_board = board
         sustained = {"launches": n_sus, "seconds": round(ms_tot / 1e3, 3), "avg_launch_ms": round(ms_sus, 4),
                      "achieved_GBs": round(b_alg / ms_sus / 1e6, 1), "frac": round(b_alg / ms_sus / 1e6 / HBM_PEAK_GBS, 4),
-                     "board": sampler.stop()}
+                     "board": board, "joules_per_launch": round(board["package_W"] * ms_sus / 1e3, 3) if board else None}
 
-    # copy-kernel yardstick (same bytes in + out), rank 0 only
-    copy_gbs = None
+    # yardsticks, rank 0 only: (1) the arithmetic-free row walk -- the identity graph `_1` through the same launch path (same
+    # lockstep / XCD-synchronised skeleton, same frames): what this layout gives a kernel that only moves the rows; (2) the plain
+    # one-shot float4 copy kernel (fz_copy_probe)
+    copy_gbs = walk_gbs = walk_kernel = None
     if rank == 0:
         F.copy_probe(x, y)
         torch.cuda.synchronize()
         copy_gbs = 2.0 * x.numel() * 4 / (event_ms(torch, lambda: F.copy_probe(x, y), 3) / 1e3) / 1e9
+        ident = F.compile(F.from_sexpr(W.IN(1)))
+        st0 = torch.zeros((1, ns), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            ident.run_block(x, state=st0, out=y)
+        torch.cuda.synchronize()
+        walk_ms = event_ms(torch, lambda: ident.run_block(x, state=st0, out=y), max(5, args.steps // 2))
+        walk_gbs = 2.0 * x.numel() * 4 / (walk_ms / 1e3) / 1e9
+        walk_kernel = ident.kernel_name(ident.plan(ns, tile), ns, T, tile)
 
     secondary = {}
     if rank == 0 and world == 1:
         del x, y, state
         torch.cuda.empty_cache()
         if not args.no_layout_legs:
-            if tile:
-                secondary["time_major_layout"] = frame_layout_leg(0)
-            else:
-                secondary["tiled_layout"] = frame_layout_leg(args.secondary_tile)
+            secondary["time_major_layout" if tile else "tiled_layout"] = OBJECTS["timemajor" if tile else "tiled"]()
             torch.cuda.empty_cache()
-            secondary["stream_major_layout"] = stream_major_leg()
+            secondary["stream_major_layout"] = OBJECTS["streammajor"]()
             torch.cuda.empty_cache()
+            if not args.no_extras:
+                secondary["stream_major_layout"]["other_shapes"] = stream_major_shapes()
         if not args.no_config2 and ns != 65536:
-            secondary["config2_65536_streams"] = config2()
-            torch.cuda.empty_cache()
-            secondary["cascade6_32768_streams"] = config2(32768)    # below one wave per SIMD: the wave-split kernel (two parts)
-            torch.cuda.empty_cache()
-            secondary["cascade6_16384_streams"] = config2(16384)    # a quarter of a wave per SIMD: three parts
+            secondary["config2_65536_streams"] = OBJECTS["config2"]()
+            secondary["cascade6_32768_streams"] = OBJECTS["config2h"]()    # below one wave per SIMD: the wave-split kernel (two parts)
+            secondary["cascade6_16384_streams"] = OBJECTS["config2q"]()    # a quarter of a wave per SIMD: three parts
             torch.cuda.empty_cache()
         if not args.no_config34:
-            secondary["config3_par4_sum"] = config3(False)
+            secondary["config3_par4_sum"] = OBJECTS["config3"]()
+            secondary["config3_par4_sum_fanout"] = OBJECTS["config3f"]()
+            secondary["config4_osc_chain"] = OBJECTS["config4"]()
             torch.cuda.empty_cache()
-            secondary["config3_par4_sum_fanout"] = config3(True)
-            torch.cuda.empty_cache()
-            secondary["config4_osc_chain"] = config4()
-            torch.cuda.empty_cache()
+        if not args.no_extras:
+            secondary["ragged_counts"] = ragged_counts()
+            secondary["reference_benchmark_topologies"] = reference_topologies()
+        if not args.no_next_rows:
+            secondary["next_rows"] = next_rows()
 
     if rank == 0:
         achieved = b_alg / kern_avg_s / 1e9
         kname = prog.kernel_name(variant if variant is not None else prog.plan(ns, tile), ns, T, tile)
-        traffic = traffic_of(kname, f"cascade6_{ns}x{T}_{lay}")
+        wkey = f"cascade6_{ns}x{T}_{lay}"
+        traffic = traffic_of(kname, wkey)
+        share = issue_share_of(kname, wkey)
         line = {
             "metric": "Msamples/sec/GPU + achieved HBM GB/s, 6-biquad cascade, 1M streams",
             "value": round(stats["samples"] / stats["seconds"] / 1e6, 1),
@@ -725,8 +955,12 @@ def main():
                          "traffic_kernel": kname if traffic is not None else None,
                          "kernel": kname, "algorithmic_bytes_per_launch": b_alg,
                          "avg_launch_ms": round(kern_avg_s * 1e3, 4),
+                         "measured_row_walk_GBs": round(walk_gbs, 1) if walk_gbs else None,
+                         "row_walk_kernel": walk_kernel,
+                         "frac_of_row_walk": round(achieved / walk_gbs, 4) if walk_gbs else None,
                          "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
-                         "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None},
+                         "issue_share": round(share, 3) if share is not None else None,
+                         "limiter": limiter_of(share, (sustained or {}).get("board"), achieved / walk_gbs if walk_gbs else None)},
             "checksum": stats["checksum"],
         }
         if sustained is not None:

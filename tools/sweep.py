@@ -21,10 +21,12 @@ def main():
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--tile", type=int, default=0, help="streams per frame tile (0 = time-major)")
+    ap.add_argument("--prebuild", action="store_true", help="no GPU: build the variants' kernels into the cache (run without torch: the installation's compiler)")
     ap.add_argument("variants", nargs="*", default=["1,8", "2,8", "4,4"])
     a = ap.parse_args()
     import numpy as np
-    import torch
+    if not a.prebuild:
+        import torch
 
     from zignal_amd import workloads as G
     W = G
@@ -34,9 +36,24 @@ def main():
               "osc": lambda: G.osc_chain(6), "df1": G.df1, "df2": G.df2, "df1t": G.df1t, "df2t": G.df2t,
               "gain": lambda: G.mul(G.lit(0.5), G.IN(1)), "cascade2": lambda: G.df1_cascade(2), "cascade4": lambda: G.df1_cascade(4),
               "cascade6g": lambda: G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1))),
-              "cascade12": lambda: G.df1_cascade(12), "cascade24": lambda: G.df1_cascade(24)}
+              "cascade12": lambda: G.df1_cascade(12), "cascade24": lambda: G.df1_cascade(24),
+              "mod6": lambda: G.df1_cascade_modulated(6), "ldsring": G.lds_ring_comb, "farring": lambda: G.far_comb(300), "ident": lambda: G.IN(1),
+              "params6": lambda: G.df1_cascade_params(6)}
     prog = F.compile(F.from_sexpr(graphs[a.graph]()))
     ns, T = a.streams, a.samples
+    if a.prebuild:
+        for s in a.variants:
+            if s == "tune":
+                vs = prog.tune_candidates(ns, T, a.tile)
+            else:
+                t = [int(v) for v in s.split(",")]
+                vs = [F.make_variant(*(t + [0] * (4 - len(t))))]
+            for v in vs:
+                try:
+                    prog.build(v, ns, T, a.tile)
+                except F.FlowzError as e:
+                    print(f"# {a.graph} {ns} {s}: refused: {str(e)[:100]}")
+        return
     if a.tile:
         x = torch.empty((ns // a.tile, T, a.tile, max(prog.n_in, 1)), dtype=torch.float32, device="cuda")
         y = torch.empty((ns // a.tile, T, a.tile, prog.n_out), dtype=torch.float32, device="cuda")
@@ -46,7 +63,10 @@ def main():
     F.synth_fill(x, 20160512)
     params = None
     if prog.n_param:
-        params = torch.from_numpy(W.osc_chain_params(20160513, np.arange(ns))).cuda()
+        P = W.osc_chain_params(20160513, np.arange(ns))
+        params = torch.from_numpy(np.ascontiguousarray(P[:prog.n_param] if a.graph == "osc" else P[1:1 + prog.n_param])).cuda()
+    if prog.n_mod:
+        prog.set_modulation((0.2 + 0.1 * torch.rand((prog.n_mod, T), device="cuda")).contiguous())
     state = torch.zeros((max(prog.n_state, 1), ns), dtype=torch.float32, device="cuda")
     b_alg = ns * (4 * T * (prog.n_in + prog.n_out) + 8 * prog.n_state + 4 * prog.n_param)
     vs = []

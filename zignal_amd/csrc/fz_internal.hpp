@@ -146,7 +146,8 @@ inline uint32_t ws_waves(uint32_t flags) { return ws_parts(flags) + (ws_parts(fl
 
 // internal variant flag (never set by callers): FZ_VF_GRID_SYNC with more blocks than the chip holds workgroups -> persistent launch
 constexpr uint32_t FZ_VF_PERSIST = 1u << 27;
-constexpr uint32_t kChipCUs = 256;       // MI355X (gfx950): 8 XCDs x 32 CUs
+constexpr uint32_t kChipCUs = 256;       // MI355X (gfx950): 8 XCDs x 32 CUs -- what chip_cus() answers on a box without a GPU
+unsigned chip_cus();                     // compute units of the current device (fz_launch.cpp)
 
 // register-resident delay lines up to this depth; deeper ones become LDS rings
 constexpr uint32_t kRegMaxDepth = 8;
@@ -187,6 +188,8 @@ struct KernelResources {
 };
 
 struct Kernel {
+   std::mutex mu;                 // cache lookup / build / module loading of THIS variant (the program mutex is not held meanwhile)
+   std::atomic<bool> built{false};
    KernelResources res;
    struct Loaded {
       int device;
@@ -196,7 +199,7 @@ struct Kernel {
    std::vector<char> code;        // code object (device independent: gfx950)
    std::string cache_path;        // on-disk cache file it came from / went to ("" = none)
    std::vector<Loaded> loaded;    // one module per device the kernel ran on
-   void* function_on_current_device(const std::string& symbol);   // loads on first use (caller holds the program mutex)
+   void* function_on_current_device(const std::string& symbol);   // loads on first use (caller holds `mu`)
    ~Kernel();                     // unloads the modules (fz_kernel_cache.cpp)
 };
 
@@ -215,6 +218,7 @@ struct fz_program {
    // FZ_VF_GRID_SYNC: arrival counters per device: 16 slices of `second` bytes, handed to the launches in turn (launches on
    // different streams may overlap and must not share counters; a slice comes round again after 15 other launches)
    std::map<int, std::pair<void*, size_t>> sync_dev;              // device -> (buffer, bytes per slice)
+   std::vector<void*> sync_retired;                                // counter buffers that were outgrown: a captured hipGraph may still use them
    uint32_t sync_next = 0;
    const float* mod_dev = nullptr;                                 // fz_program_set_modulation
    uint32_t mod_stride = 0;

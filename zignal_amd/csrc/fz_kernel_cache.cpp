@@ -3,10 +3,14 @@
 #include <hip/hiprtc.h>
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <limits.h>
-#include <link.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
+
+#include <cerrno>
 
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +19,8 @@
 #include <sstream>
 
 #include "fz_runtime.hpp"
+
+extern char** environ;
 
 namespace fz {
 
@@ -198,32 +204,23 @@ static void cache_store(const std::string& dir, const std::string& path, const s
 // ---- which hiprtc compiles the kernels ----------------------------------------------------------------------------------
 // The library links libhiprtc.so.7 of the ROCm installation it was built against.  A host process that has ANOTHER copy with that
 // soname loaded already -- a PyTorch wheel bundles the ROCm release it was built with, hiprtc and comgr (the compiler) included --
-// binds us to that copy instead, and the code then depends on who imported what first: the wheel's older compiler needs 22 more
+// binds us to that copy instead, and the code would then depend on who imported what first: the wheel's older compiler needs 22 more
 // registers for the four-streams-per-lane headline kernel, which therefore "has scratch" and the library steps down to two
-// (0.73 instead of 0.77 of peak).  Two rules keep that from leaking:
-//  * every cache name carries the identity of the compiler that built the object, and a lookup tries the INSTALLATION's name
-//    first (what `build()` pre-builds in a process of its own), then this process's compiler's name; what a foreign compiler
-//    builds is stored under its own name and never stands in for the installation's;
-//  * FLOWZ_HIP_ISOLATED_HIPRTC=1: the installation's hiprtc is loaded into a link-map namespace of its own (dlmopen: its
-//    dlopen("libamd_comgr.so.3") resolves inside that namespace, to the comgr next to it) and builds everything -- byte-identical
-//    code objects with and without `import torch`.  Opt-in: one of five full GPU test runs with it ended in a segmentation
-//    fault that the other four (under a backtrace handler, tools/segv_backtrace.c) and 4000 builds in a fuzz run did not reproduce.
+// (0.73 instead of 0.77 of peak).  Round 4 closes that: a library that finds itself bound to a foreign hiprtc hands every build
+// to fz_rtc_worker (fz_rtc_worker.cpp, installed next to the library): a fresh process whose only hiprtc is the installation's.
+// Same compiler, same options, same text: the code objects are byte-identical to what a process without torch builds, and they
+// are cached under the installation's name.  Only when the worker cannot be run (not installed, not executable, bound to
+// something else itself) does the host process's compiler build the kernel -- under a cache name of its own, never standing in
+// for the installation's, and with ONE warning on stderr (FLOWZ_HIP_QUIET=1 silences it).
+// (Round 3 tried the same with dlmopen -- the installation's hiprtc in a link-map namespace of its own inside the host process;
+//  one of five full test runs ended in a segmentation fault nobody could explain.  A process boundary has no such failure mode.)
 #ifndef FZ_ROCM_LIB_DIR
 #define FZ_ROCM_LIB_DIR "/opt/rocm/lib"
 #endif
 struct Rtc {
-   decltype(&hiprtcCreateProgram) create = &hiprtcCreateProgram;
-   decltype(&hiprtcCompileProgram) compile = &hiprtcCompileProgram;
-   decltype(&hiprtcGetProgramLogSize) log_size = &hiprtcGetProgramLogSize;
-   decltype(&hiprtcGetProgramLog) log = &hiprtcGetProgramLog;
-   decltype(&hiprtcGetCodeSize) code_size = &hiprtcGetCodeSize;
-   decltype(&hiprtcGetCode) code = &hiprtcGetCode;
-   decltype(&hiprtcDestroyProgram) destroy = &hiprtcDestroyProgram;
-   decltype(&hiprtcGetErrorString) error_string = &hiprtcGetErrorString;
-   decltype(&hiprtcVersion) version = &hiprtcVersion;
    std::string identity;                               // part of every cache key
-   std::string path;                                   // the library the entry points come from
-   bool isolated = false;
+   std::string path;                                   // the hiprtc that builds the kernels
+   std::string worker;                                 // "" : in-process; else the fz_rtc_worker executable
 };
 
 static std::string real_path(const std::string& p)
@@ -243,6 +240,53 @@ static const std::string& preferred_identity()
    return id;
 }
 
+static std::string library_dir()
+{
+   Dl_info info;
+   if (!dladdr((const void*)&library_dir, &info) || !info.dli_fname) return "";
+   std::string p = info.dli_fname;                   // .../zignal_amd/lib/libflowz_hip.so
+   const size_t s = p.rfind('/');
+   return s == std::string::npos ? std::string(".") : p.substr(0, s);
+}
+
+// run the worker: argv = {worker, request, output}; environment without LD_LIBRARY_PATH / LD_PRELOAD; its stdout goes to out_path
+static int run_worker(const std::string& worker, const std::string& request, const std::string& output, const std::string& stdout_path)
+{
+   std::vector<std::string> envs;
+   for (char** e = environ; e && *e; ++e)
+      if (std::strncmp(*e, "LD_LIBRARY_PATH=", 16) != 0 && std::strncmp(*e, "LD_PRELOAD=", 11) != 0) envs.push_back(*e);
+   std::vector<char*> envp;
+   for (std::string& e : envs) envp.push_back(&e[0]);
+   envp.push_back(nullptr);
+   std::string a0 = worker, a1 = request, a2 = output;
+   char* argv[] = {&a0[0], &a1[0], output.empty() ? nullptr : &a2[0], nullptr};
+   posix_spawn_file_actions_t fa;
+   posix_spawn_file_actions_init(&fa);
+   posix_spawn_file_actions_addopen(&fa, 1, stdout_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+   pid_t pid = 0;
+   const int rc = posix_spawn(&pid, worker.c_str(), &fa, nullptr, argv, envp.data());
+   posix_spawn_file_actions_destroy(&fa);
+   if (rc != 0) return -1;
+   int status = 0;
+   while (waitpid(pid, &status, 0) < 0)
+      if (errno != EINTR) return -1;
+   return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
+}
+
+static std::string slurp(const std::string& path)
+{
+   std::ifstream f(path, std::ios::binary);
+   return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+// a private scratch directory for the worker's request / output files
+static std::string worker_tmp_dir()
+{
+   const char* t = std::getenv("TMPDIR");
+   std::string tmpl = std::string(t && *t ? t : "/tmp") + "/fz_rtc_XXXXXX";
+   return ::mkdtemp(&tmpl[0]) ? tmpl : std::string();
+}
+
 static const Rtc& rtc()
 {
    static const Rtc r = [] {
@@ -250,69 +294,112 @@ static const Rtc& rtc()
       Dl_info info;
       const std::string bound = dladdr((const void*)&hiprtcCompileProgram, &info) && info.dli_fname ? real_path(info.dli_fname) : std::string("?");
       const std::string ours = real_path(std::string(FZ_ROCM_LIB_DIR) + "/libhiprtc.so.7");
+      const bool debug = std::getenv("FLOWZ_HIP_DEBUG") != nullptr;
       t.path = bound;
       bool foreign = bound != ours && ::access(ours.c_str(), R_OK) == 0;
-      const char* iso_env = std::getenv("FLOWZ_HIP_ISOLATED_HIPRTC");
-      if (foreign && iso_env && *iso_env && std::strcmp(iso_env, "0") != 0) {
-         if (void* h = dlmopen(LM_ID_NEWLM, ours.c_str(), RTLD_NOW | RTLD_LOCAL)) {
-            Rtc iso;
-#define FZ_RTC_SYM(field, name) iso.field = reinterpret_cast<decltype(iso.field)>(dlsym(h, name))
-            FZ_RTC_SYM(create, "hiprtcCreateProgram");
-            FZ_RTC_SYM(compile, "hiprtcCompileProgram");
-            FZ_RTC_SYM(log_size, "hiprtcGetProgramLogSize");
-            FZ_RTC_SYM(log, "hiprtcGetProgramLog");
-            FZ_RTC_SYM(code_size, "hiprtcGetCodeSize");
-            FZ_RTC_SYM(code, "hiprtcGetCode");
-            FZ_RTC_SYM(destroy, "hiprtcDestroyProgram");
-            FZ_RTC_SYM(error_string, "hiprtcGetErrorString");
-            FZ_RTC_SYM(version, "hiprtcVersion");
-#undef FZ_RTC_SYM
-            if (iso.create && iso.compile && iso.log_size && iso.log && iso.code_size && iso.code && iso.destroy && iso.error_string && iso.version) {
-               iso.path = ours;
-               iso.isolated = true;
-               t = iso;
-               foreign = false;
+      std::string why;
+      if (foreign) {
+         // the worker must exist, run, and be bound to the installation's hiprtc itself
+         const std::string w = library_dir() + "/fz_rtc_worker";
+         if (::access(w.c_str(), X_OK) != 0) (void)::chmod(w.c_str(), 0755);   // (a snapshot that dropped the mode bits)
+         if (::access(w.c_str(), X_OK) != 0) why = w + " is missing or not executable";
+         else {
+            const std::string d = worker_tmp_dir();
+            if (d.empty()) why = "no temporary directory";
+            else {
+               const int rc = run_worker(w, "--identify", "", d + "/stdout");
+               const std::string said = slurp(d + "/stdout");
+               ::unlink((d + "/stdout").c_str());
+               ::rmdir(d.c_str());
+               if (rc != 0 || said.rfind("hiprtc ", 0) != 0) why = "the worker did not start (exit " + std::to_string(rc) + ")";
+               else if (real_path(said.substr(7, said.find('\n') - 7)) != ours) why = "the worker is bound to " + said.substr(7, said.find('\n') - 7);
+               else {
+                  t.worker = w;
+                  t.path = ours;
+                  foreign = false;
+               }
             }
-         } else if (std::getenv("FLOWZ_HIP_DEBUG")) {
-            std::fprintf(stderr, "[flowz_hip] dlmopen(%s): %s -- building with the host process's hiprtc (%s)\n", ours.c_str(), dlerror(), bound.c_str());
          }
       }
       // identity: the installation's hiprtc by its versioned file name (computable without loading it: see preferred_identity),
       // any other by path and size
       struct stat st;
       t.identity = foreign ? "foreign:" + bound + ":" + std::to_string(::stat(bound.c_str(), &st) == 0 ? (long long)st.st_size : -1LL) : preferred_identity();
-      if (std::getenv("FLOWZ_HIP_DEBUG"))
-         std::fprintf(stderr, "[flowz_hip] kernels are built by %s%s\n", t.path.c_str(), t.isolated ? " (in a link-map namespace of its own: the host process is bound to another hiprtc)" : "");
+      if (foreign && !std::getenv("FLOWZ_HIP_QUIET"))
+         std::fprintf(stderr, "[flowz_hip] warning: kernels that are not in the cache will be built by %s, the hiprtc the host process loaded first, not by the "
+                              "ROCm installation's (%s): %s.  Such kernels may need more registers (a spilling variant steps down to a slower one); "
+                              "objects pre-built by the installation's compiler are still preferred.\n", bound.c_str(), ours.c_str(), why.c_str());
+      if (debug)
+         std::fprintf(stderr, "[flowz_hip] kernels are built by %s%s\n", t.path.c_str(), t.worker.empty() ? "" : " in a process of its own (fz_rtc_worker: the host process is bound to another hiprtc)");
       return t;
    }();
    return r;
 }
 
+static std::vector<char> jit_compile_in_process(const std::string& cfg, const std::string& body, const std::vector<const char*>& opts)
+{
+   const char* headers[2] = {cfg.c_str(), body.c_str()};
+   const char* names[2] = {"fz_graph_config.h", "fz_graph_body.h"};
+   hiprtcProgram prog;
+   if (hiprtcCreateProgram(&prog, skeleton_source(), "fz_block_kernel.hip", 2, headers, names) != HIPRTC_SUCCESS)
+      fail(FZ_E_COMPILE, "hiprtcCreateProgram failed");
+   hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), const_cast<const char**>(opts.data()));
+   if (r != HIPRTC_SUCCESS) {
+      size_t n = 0;
+      hiprtcGetProgramLogSize(prog, &n);
+      std::string log(n, ' ');
+      if (n) hiprtcGetProgramLog(prog, &log[0]);
+      hiprtcDestroyProgram(&prog);
+      fail(FZ_E_COMPILE, std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log);
+   }
+   size_t n = 0;
+   hiprtcGetCodeSize(prog, &n);
+   std::vector<char> code(n);
+   hiprtcGetCode(prog, code.data());
+   hiprtcDestroyProgram(&prog);
+   return code;
+}
+
+static std::vector<char> jit_compile_in_worker(const std::string& worker, const std::string& cfg, const std::string& body, const std::vector<const char*>& opts)
+{
+   const std::string d = worker_tmp_dir();
+   if (d.empty()) fail(FZ_E_COMPILE, "fz_rtc_worker: no temporary directory for the request");
+   const std::string req = d + "/request", out = d + "/code", so = d + "/stdout";
+   {
+      std::ofstream f(req, std::ios::binary);
+      auto section = [&](const char* kind, const char* name, const std::string& data) {
+         f << kind << ' ' << name << ' ' << data.size() << '\n';
+         f.write(data.data(), (std::streamsize)data.size());
+         f << '\n';
+      };
+      f << "FZRTC1 " << (3 + opts.size()) << '\n';
+      section("source", "fz_block_kernel.hip", skeleton_source());
+      section("header", "fz_graph_config.h", cfg);
+      section("header", "fz_graph_body.h", body);
+      for (const char* o : opts) section("option", "-", o);
+   }
+   const int rc = run_worker(worker, req, out, so);
+   std::vector<char> code;
+   std::string log;
+   if (rc == 0) {
+      const std::string bytes = slurp(out);
+      code.assign(bytes.begin(), bytes.end());
+   } else if (rc == 3) {
+      log = slurp(out + ".log");
+   }
+   for (const char* n : {"/request", "/code", "/code.log", "/stdout"}) ::unlink((d + n).c_str());
+   ::rmdir(d.c_str());
+   if (rc == 3) fail(FZ_E_COMPILE, log);
+   if (rc != 0 || code.size() < 64) fail(FZ_E_COMPILE, "fz_rtc_worker failed (exit " + std::to_string(rc) + ")");
+   return code;
+}
+
 static std::vector<char> jit_compile(const Graph& g, const Variant& v)
 {
    const std::string cfg = gen_config(g, v), body = gen_body(g, v);
-   const char* headers[2] = {cfg.c_str(), body.c_str()};
-   const char* names[2] = {"fz_graph_config.h", "fz_graph_body.h"};
+   const std::vector<const char*> opts = build_options(g, v);
    const Rtc& R = rtc();
-   hiprtcProgram prog;
-   if (R.create(&prog, skeleton_source(), "fz_block_kernel.hip", 2, headers, names) != HIPRTC_SUCCESS)
-      fail(FZ_E_COMPILE, "hiprtcCreateProgram failed");
-   std::vector<const char*> opts = build_options(g, v);
-   hiprtcResult r = R.compile(prog, (int)opts.size(), opts.data());
-   if (r != HIPRTC_SUCCESS) {
-      size_t n = 0;
-      R.log_size(prog, &n);
-      std::string log(n, ' ');
-      if (n) R.log(prog, &log[0]);
-      R.destroy(&prog);
-      fail(FZ_E_COMPILE, std::string("hiprtc: ") + R.error_string(r) + "\n" + log);
-   }
-   size_t n = 0;
-   R.code_size(prog, &n);
-   std::vector<char> code(n);
-   R.code(prog, code.data());
-   R.destroy(&prog);
-   return code;
+   return R.worker.empty() ? jit_compile_in_process(cfg, body, opts) : jit_compile_in_worker(R.worker, cfg, body, opts);
 }
 
 // One field of the kernel's metadata map (code object v3+: an ELF note holding msgpack; one kernel per code object here).
@@ -412,7 +499,7 @@ bool kernel_at_hand(fz_program* p, const Variant& v)
    {
       std::lock_guard<std::mutex> lock(p->mu);
       auto it = p->kernels.find(v);
-      if (it != p->kernels.end() && it->second) return true;
+      if (it != p->kernels.end() && it->second && it->second->built.load()) return true;
    }
    const std::string dir = cache_dir(), pkg = package_cache_dir();
    if (!cache_in_use(dir)) return false;
@@ -424,12 +511,19 @@ bool kernel_at_hand(fz_program* p, const Variant& v)
    return false;
 }
 
+// The program mutex is held only to find (or create) the variant's slot; cache lookup, the hiprtc build (seconds) and module
+// loading happen under the SLOT's own mutex, so other launches of the program -- other variants, other threads -- go on.
 std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out)
 {
-   std::lock_guard<std::mutex> lock(p->mu);
-   auto& slot = p->kernels[v];
-   if (!slot) {
-      auto k = std::make_shared<Kernel>();
+   std::shared_ptr<Kernel> k;
+   {
+      std::lock_guard<std::mutex> lock(p->mu);
+      auto& slot = p->kernels[v];
+      if (!slot) slot = std::make_shared<Kernel>();
+      k = slot;
+   }
+   std::lock_guard<std::mutex> build_lock(k->mu);
+   if (!k->built.load()) {
       const std::string dir = cache_dir(), pkg = package_cache_dir(), path = dir + cache_file_of(p, v, rtc().identity);   // (path: where a build of THIS process goes)
       const bool use_cache = cache_in_use(dir);
       // (a package cache this user cannot write to -- installed by root, pre-filled by build() -- is still read)
@@ -454,12 +548,12 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
          }
       }
       k->res = read_resources(k->code);
-      slot = k;
+      k->built.store(true);
    }
    if (fn_out) {
       require_device();
       try {
-         *fn_out = slot->function_on_current_device(kernel_name(p->g, v));
+         *fn_out = k->function_on_current_device(kernel_name(p->g, v));
       } catch (const Error& er) {
          // a cached code object the DRIVER refuses to load (built for another code-object version, damaged in a way the trailer
          // does not see): delete it, build afresh, store that, try once more.  Anything else -- out of memory, no device, a
@@ -467,16 +561,16 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
          const bool image = er.msg.find("hipModuleLoadData") != std::string::npos &&
                             (er.msg.find("invalid") != std::string::npos || er.msg.find("binary") != std::string::npos ||
                              er.msg.find("image") != std::string::npos || er.msg.find("shared object") != std::string::npos);
-         if (slot->cache_path.empty() || !image) throw;
-         ::unlink(slot->cache_path.c_str());
-         slot->code = jit_compile(p->g, v);
-         slot->res = read_resources(slot->code);
-         slot->cache_path = cache_dir() + cache_file_of(p, v, rtc().identity);   // (under the name of the compiler that built it)
-         cache_store(cache_dir(), slot->cache_path, slot->code);
-         *fn_out = slot->function_on_current_device(kernel_name(p->g, v));
+         if (k->cache_path.empty() || !image) throw;
+         ::unlink(k->cache_path.c_str());
+         k->code = jit_compile(p->g, v);
+         k->res = read_resources(k->code);
+         k->cache_path = cache_dir() + cache_file_of(p, v, rtc().identity);   // (under the name of the compiler that built it)
+         cache_store(cache_dir(), k->cache_path, k->code);
+         *fn_out = k->function_on_current_device(kernel_name(p->g, v));
       }
    }
-   return slot;
+   return k;
 }
 
 }  // namespace fz

@@ -12,11 +12,81 @@ fz_program::~fz_program()
 {
    for (auto& kv : sync_dev)
       if (kv.second.first) (void)hipFree(kv.second.first);   // (hipFree waits for whatever still runs on the device)
+   for (void* q : sync_retired) (void)hipFree(q);
 }
 
 namespace fz {
 
 // ---- launch ------------------------------------------------------------------------------------------------
+// compute units of the current device (hipDeviceAttributeMultiprocessorCount, asked once per device; 256 -- the MI355X -- on a
+// box without a GPU, where only names and resources are asked for)
+unsigned chip_cus()
+{
+   static std::mutex mu;
+   static std::map<int, unsigned> known;
+   int dev = 0;
+   if (hipGetDevice(&dev) != hipSuccess) {
+      (void)hipGetLastError();
+      return kChipCUs;
+   }
+   std::lock_guard<std::mutex> lock(mu);
+   unsigned& c = known[dev];
+   if (!c) {
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) {
+         (void)hipGetLastError();
+         cus = (int)kChipCUs;
+      }
+      c = (unsigned)cus;
+   }
+   return c;
+}
+
+// workgroups of this kernel the chip holds at a time: occupancy x CUs, in whole eights (the XCDs); asked once per kernel and device
+static unsigned resident_workgroups(void* fn, int threads)
+{
+   static std::mutex mu;
+   static std::map<std::pair<void*, int>, unsigned> known;
+   int dev = 0;
+   FZ_HIP(hipGetDevice(&dev));
+   std::lock_guard<std::mutex> lock(mu);
+   unsigned& r = known[{fn, dev}];
+   if (!r) {
+      int per_cu = 0;
+      if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (hipFunction_t)fn, threads, 0) != hipSuccess || per_cu < 1) {
+         (void)hipGetLastError();
+         per_cu = 1;
+      }
+      r = std::max(8u, chip_cus() * (unsigned)per_cu / 8u * 8u);
+   }
+   return r;
+}
+
+// FZ_VF_GRID_SYNC: `bytes` of arrival counters for one launch -- a slice of a small buffer the program owns per device, 16 slices
+// handed out in turn (launches on different streams may overlap and must not share counters; a slice comes round again after 15
+// other launches).  A buffer that turns out too small is REPLACED, never freed before the program is: a hipGraph captured earlier
+// may still hold its slices.
+static unsigned int* sync_counters(fz_program* p, size_t bytes, void* stream)
+{
+   int dev = 0;
+   FZ_HIP(hipGetDevice(&dev));
+   std::lock_guard<std::mutex> lock(p->mu);
+   auto& slot = p->sync_dev[dev];
+   if (slot.second < bytes) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) (void)hipGetLastError();
+      if (cap != hipStreamCaptureStatusNone)
+         fail(FZ_E_INVALID, "FZ_VF_GRID_SYNC: the arrival counters cannot be allocated while the stream is being captured: launch this "
+                            "shape once before the capture");
+      if (slot.first) p->sync_retired.push_back(slot.first);        // (freed with the program)
+      slot = {nullptr, 0};
+      const size_t per = std::max<size_t>((bytes + 4095) / 4096 * 4096, 16384);
+      FZ_HIP(hipMalloc(&slot.first, per * 16));
+      slot.second = per;
+   }
+   return reinterpret_cast<unsigned int*>(static_cast<char*>(slot.first) + (size_t)(p->sync_next++ % 16u) * slot.second);
+}
+
 struct ArgsHeader {
    const float* in;
    float* out;
@@ -33,8 +103,10 @@ struct ArgsHeader {
    unsigned int row0;
    unsigned int mod_stride;
    unsigned int n_blocks;
+   unsigned int block0;
+   unsigned int reserved0;
 };
-static_assert(sizeof(ArgsHeader) % 8 == 0 && sizeof(ArgsHeader) == 6 * 8 + 8 + 8 * 4, "ArgsHeader must match the head of the kernel's fz_args without padding");
+static_assert(sizeof(ArgsHeader) % 8 == 0 && sizeof(ArgsHeader) == 6 * 8 + 8 + 10 * 4, "ArgsHeader must match the head of the kernel's fz_args without padding");
 
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
            uint32_t n_samples, const fz_variant* uv, void* stream, uint32_t tile_streams, uint32_t rows_total, uint32_t row0,
@@ -189,69 +261,52 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       mod_dev += mod_row0;
    }
    const unsigned n_blocks = (unsigned)(((unsigned int)(n_streams / v.P) + v.block - 1) / v.block);
-   unsigned grid = n_blocks;
    // (wave split: v.block counts the 64 streams of a workgroup; two waves evaluate them)
    const unsigned threads = ws_parts(v.flags) ? v.block * ws_waves(v.flags) : v.block;
-   unsigned int* sync_dev = nullptr;
+   // FZ_VF_GRID_SYNC needs every workgroup that synchronises RUNNING: with more blocks than the chip holds workgroups of this
+   // kernel (occupancy x CUs) the block is cut into LAPS -- contiguous stream ranges of at most one workgroup per resident slot,
+   // the same number of blocks in every lap (whole eights: the XCDs) -- and every lap is a launch of its own (round 4; the one-lap
+   // kernel has no loop to pay registers for: four streams per lane fit where the persistent kernel of round 3 stepped down).
+   // FZ_VF_PERSIST (internal, FLOWZ_HIP_LAPS=kernel): one launch of `resident` workgroups that loop over the laps themselves.
+   unsigned laps = 1, per_lap = n_blocks, grid = n_blocks;
+   size_t sync_bytes = 0;
    if (v.flags & FZ_VF_GRID_SYNC) {
-      // persistent launch: the grid is what the chip holds of THIS kernel at a time (occupancy x CUs, whole laps over the 8 XCDs);
-      // per-(lap, XCD) arrival counters, zeroed in stream order before the launch
-      int dev = 0;
-      FZ_HIP(hipGetDevice(&dev));
-      unsigned resident = 0;
-      {  // (asked once per kernel and device: the launch path stays free of driver queries)
-         static std::mutex mu;
-         static std::map<std::pair<void*, int>, unsigned> known;
-         std::lock_guard<std::mutex> lock(mu);
-         unsigned& r = known[{fn, dev}];
-         if (!r) {
-            int per_cu = 0, cus = 0;
-            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (hipFunction_t)fn, (int)threads, 0) != hipSuccess || per_cu < 1) {
-               (void)hipGetLastError();
-               per_cu = 1;
-            }
-            FZ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            r = std::max(8u, (unsigned)(cus * per_cu) / 8u * 8u);
-         }
-         resident = r;
+      const unsigned resident = resident_workgroups(fn, (int)threads);
+      if (n_blocks > resident) {
+         laps = (n_blocks + resident - 1) / resident;
+         per_lap = std::min(resident, ((n_blocks + laps - 1) / laps + 7u) / 8u * 8u);
+         grid = per_lap;
       }
-      if ((v.flags & FZ_VF_PERSIST) && n_blocks > resident) grid = resident;   // (one lap: the waits of workgroups that are not running yet are bounded)
-      const size_t bytes = (size_t)((n_blocks + grid - 1) / grid) * 8 * 128;
-      {
-         std::lock_guard<std::mutex> lock(p->mu);
-         auto& slot = p->sync_dev[dev];
-         if (slot.second < bytes) {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) (void)hipGetLastError();
-            if (cap != hipStreamCaptureStatusNone)
-               fail(FZ_E_INVALID, "FZ_VF_GRID_SYNC: the arrival counters cannot be allocated while the stream is being captured: launch this "
-                                  "shape once before the capture");
-            if (slot.first) FZ_HIP(hipFree(slot.first));   // (synchronises: nothing in flight uses the old counters)
-            slot = {nullptr, 0};
-            const size_t per = std::max<size_t>((bytes + 4095) / 4096 * 4096, 16384);
-            FZ_HIP(hipMalloc(&slot.first, per * 16));
-            slot.second = per;
-         }
-         sync_dev = reinterpret_cast<unsigned int*>(static_cast<char*>(slot.first) + (size_t)(p->sync_next++ % 16u) * slot.second);
-      }
-      FZ_HIP(hipMemsetAsync(sync_dev, 0, bytes, (hipStream_t)stream));
+      sync_bytes = (size_t)((v.flags & FZ_VF_PERSIST) ? laps : 1u) * 8 * 128;   // per-(lap, XCD) arrival counters, zeroed in stream order before the launch
+      if (v.flags & FZ_VF_PERSIST) laps = 1;                                     // (the kernel loops)
    }
-   ArgsHeader h{in, out, state, params, mod_dev, sync_dev, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
-                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0, mod_stride, n_blocks};
-   std::memcpy(kbuf, &h, sizeof h);
+   ArgsHeader h{in, out, state, params, mod_dev, nullptr, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
+                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0, mod_stride, n_blocks, 0u, 0u};
    {
       std::lock_guard<std::mutex> lock(p->mu);
       if (!g.consts.empty()) std::memcpy(kbuf + sizeof h, g.consts.data(), sizeof(float) * g.consts.size());
       if (!g.consts64.empty()) std::memcpy(kbuf + off64, g.consts64.data(), sizeof(double) * g.consts64.size());
    }
-   size_t size = kbytes;
-   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, kbuf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-   FZ_HIP(hipModuleLaunchKernel((hipFunction_t)fn, grid, 1, 1, threads, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
+   for (unsigned lap = 0; lap < laps; ++lap) {
+      if (laps > 1) {
+         h.block0 = lap * per_lap;
+         grid = std::min(per_lap, n_blocks - h.block0);
+      }
+      if (sync_bytes) {
+         h.sync = sync_counters(p, sync_bytes, stream);
+         FZ_HIP(hipMemsetAsync(h.sync, 0, sync_bytes, (hipStream_t)stream));
+      }
+      std::memcpy(kbuf, &h, sizeof h);
+      size_t size = kbytes;
+      void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, kbuf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+      FZ_HIP(hipModuleLaunchKernel((hipFunction_t)fn, grid, 1, 1, threads, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
+   }
+   const size_t size = kbytes;
    static const bool debug = std::getenv("FLOWZ_HIP_DEBUG") != nullptr;
    if (debug) {
       FZ_HIP(hipStreamSynchronize((hipStream_t)stream));
-      std::fprintf(stderr, "[flowz_hip] launched grid=%u block=%u P=%u U=%u flags=%u n_streams=%llu n_samples=%u kernarg=%zu B vgprs=%u scratch=%u B/lane\n",
-                   grid, v.block, v.P, v.U, v.flags, (unsigned long long)n_streams, n_samples, size, k->res.vgprs + k->res.agprs, k->res.scratch_bytes);
+      std::fprintf(stderr, "[flowz_hip] launched %u lap(s) grid=%u block=%u P=%u U=%u flags=%u n_streams=%llu n_samples=%u kernarg=%zu B vgprs=%u scratch=%u B/lane\n",
+                   laps, grid, v.block, v.P, v.U, v.flags, (unsigned long long)n_streams, n_samples, size, k->res.vgprs + k->res.agprs, k->res.scratch_bytes);
    }
    return FZ_OK;
 }

@@ -159,8 +159,8 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // exp_r03pair_threshold.py): 131 072 streams 0.775 against 0.804-0.815 ms, 262 144 1.69 against 1.67 (level), 393 216 2.28
       // against 2.41, 524 288 3.00 against 3.20; at 65 536 its 128 workgroups would leave half of the CUs idle
       auto fill = [](uint64_t ns, uint64_t per_wg) {
-         const uint64_t wg = (ns + per_wg - 1) / per_wg, rounds = (wg + kChipCUs - 1) / kChipCUs;
-         return (double)wg / (double)(rounds * kChipCUs);
+         const uint64_t cus = chip_cus(), wg = (ns + per_wg - 1) / per_wg, rounds = (wg + cus - 1) / cus;
+         return (double)wg / (double)(rounds * cus);
       };
       const bool enough = n_streams >= (1u << 19) || (n_streams >= (1u << 17) && fill(n_streams, 512) >= fill(n_streams, 256) - 0.02);
       if (!uv_has_shape(uv) && g.n_in == 1 && g.n_out == 1 && g.n_lds_slots == 0 && g.far_lines.empty() && g.n_param == 0 && g.n_mod == 0 &&
@@ -306,10 +306,12 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
          }
          if (row_bytes * v.U >= (1ull << 32)) fail(FZ_E_UNSUPPORTED, "rows too wide for this kernel variant (unroll x row bytes must stay below 4 GiB): tile the streams");
       }
-      // XCD-wide synchronisation needs every workgroup running: with more blocks than CUs (1024-lane workgroups: one per CU;
-      // smaller ones: a few, the launch asks the occupancy) the launch is persistent -- a kernel of its own
+      // XCD-wide synchronisation needs every workgroup running: with more blocks than the chip holds workgroups the launch path
+      // cuts the block into laps, one launch each (fz_launch.cpp).  FLOWZ_HIP_LAPS=kernel keeps round 3's alternative for
+      // comparison: ONE persistent launch whose workgroups loop over the laps (FZ_VF_PERSIST, a kernel of its own)
+      static const bool kernel_laps = [] { const char* e = std::getenv("FLOWZ_HIP_LAPS"); return e && std::strcmp(e, "kernel") == 0; }();
       v.flags &= ~FZ_VF_PERSIST;
-      if ((v.flags & FZ_VF_GRID_SYNC) && (n_streams / v.P + v.block - 1) / v.block > kChipCUs) v.flags |= FZ_VF_PERSIST;
+      if (kernel_laps && (v.flags & FZ_VF_GRID_SYNC) && (n_streams / v.P + v.block - 1) / v.block > chip_cus()) v.flags |= FZ_VF_PERSIST;
       return settle ? settle_variant(p, v) : v;
    };
    const Variant want = resolve_variant(g, uv, n_streams, n_samples, tile_streams);

@@ -174,6 +174,58 @@ def osc_chain(n=6):
 
 
 
+# ---- the graphs bench.py's `next_rows` object times ------------------------------------
+def mod(k):
+    return ("mod", k)
+
+
+def litc(re, im):
+    return ("litc", float(F32(re)), float(F32(im)))
+
+
+def lds_ring_comb():
+    """f1: `(_1 + 0.5*_1[_40]) |= ~(0.7*_1[_23] + _2)` -- a feed-forward and a feedback comb whose lines (40 and 23 samples) are
+    LDS ring buffers, one column per lane (the `long_delay_lds` graph of the parity tests)."""
+    return seq(add(IN(1), mul(lit(0.5), DEL(1, 40))), fb(add(mul(lit(0.7), DEL(1, 23)), IN(2))))
+
+
+def far_comb(depth=300):
+    """f1: `~(0.5*_1[_300] + _2)` -- a feedback comb whose line is a ring in HBM (deeper than the 256 samples LDS rings hold):
+    one appended row and one far read per sample, i.e. 16 algorithmic bytes per stream-sample."""
+    return fb(add(mul(lit(0.5), DEL(1, depth)), IN(2)))
+
+
+def df1_cascade_params(n=6):
+    """f2: n x DF1 whose 5n coefficients are per-stream parameters (std::ref terminals at block rate, flowz/README.md:42-61):
+    the graph fz_bank_process_blocks runs with one coefficient set per 64-sample window."""
+    return seq(*[df1_param(5 * j) for j in range(n)])
+
+
+def df1_mod(k, b=(F32(0.2 * 0.25), F32(-0.3 * 0.25), F32(1.1 * 0.25)), a2=F32(-0.8)):
+    """DF1 whose recursion coefficient a1 is the sample-rate modulator k (the std::ref(a) of flowz/README.md:52, re-read every sample)"""
+    f = add(add(mul(lit(b[0]), IN(1)), mul(lit(b[1]), DEL(1, 1))), mul(lit(b[2]), DEL(1, 2)))
+    r = fb(add(add(IN(2), mul(mod(k), DEL(1, 1))), mul(lit(a2), DEL(1, 2))))
+    return seq(f, r)
+
+
+def df1_cascade_modulated(n=6):
+    """f2: n x DF1, every stage's a1 read from sample-rate modulator 0 (one value per sample, the same for all streams)"""
+    return seq(*[df1_mod(0) for _ in range(n)])
+
+
+def df1_double():
+    """f3: one DF1 biquad whose coefficients are C++ `double` literals: under fz_compile_typed every wire, both delay lines and the
+    output frame are double (ResultType, flowz.hpp:585-644; test/tests.cpp:222-231)."""
+    f = add(add(mul(lit64(0.05), IN(1)), mul(lit64(-0.075), DEL(1, 1))), mul(lit64(0.275), DEL(1, 2)))
+    r = fb(add(add(IN(2), mul(lit64(0.2), DEL(1, 1))), mul(lit64(-0.8), DEL(1, 2))))
+    return seq(f, r)
+
+
+def complex_one_pole(c=(0.6, 0.7)):
+    """f3: `~( c*_1[_1] + _2 )` with a std::complex<float> coefficient (test/tests.cpp:206-207): complex wire, complex delay line"""
+    return fb(add(mul(litc(*c), DEL(1, 1)), IN(2)))
+
+
 # ---- synthetic inputs and per-stream coefficients (SURVEY 8d) -------------------------------------------
 SEED = 20160512
 
