@@ -487,6 +487,7 @@ def leg(cx, sp, layout, tile=0, tune=True, forced=None, energy=False, reps_ms=60
         torch.cuda.synchronize()
         ms1 = event_ms(torch, lambda: run(v), 1)
         reps = max(5, min(400, int(math.ceil(reps_ms / max(ms1, 1e-3)))))
+        event_ms(torch, lambda: run(v), max(3, reps // 2))   # warm-up of the same kind as the timed region (sub-millisecond kernels: clocks and queues settle over dozens of launches)
         ms = event_ms(torch, lambda: run(v), reps)
         k = name_of(v)
         return {"kernel": k, "avg_launch_ms": round(ms, 4), "Msamples_per_s": round(ns * T / ms / 1e3, 1), "achieved_GBs": round(b / ms / 1e6, 1),

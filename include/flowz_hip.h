@@ -309,6 +309,20 @@ long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap
  * n_samples == 0 or n_streams == 0 is an empty block: FZ_OK, nothing is touched.
  * Asynchronous on `hip_stream` (hipStream_t, NULL = default stream); the caller synchronises.
  * `v` may be NULL (all defaults).  A program may run concurrently on different state buffers.
+ *
+ * FIRST BIG LAUNCH OF A SHAPE (v == NULL, the block is the whole buffer, n_streams * n_samples >= 2^26): which kernel variant
+ * streams fastest differs from board to board, so such a launch MEASURES the plan once per (n_streams, tile_streams, device) before
+ * it runs -- what fz_program_tune does, without the call (FLOWZ_HIP_AUTOTUNE=0 turns it off: the static choice).  What a caller
+ * should know about that one launch:
+ *   - it synchronises `hip_stream` and takes the time of a few dozen blocks (>= 100 ms of warm-up, every candidate timed twice);
+ *   - it allocates a copy of `state` (n_state * n_streams floats), runs the candidates on the caller's in / out / state buffers and
+ *     puts the state back; a state that cannot be put back is FZ_E_HIP (the message says so), never a silent advance; without room
+ *     for the copy nothing is measured;
+ *   - only candidates whose code objects are already built (in memory or in the kernel cache) take part, nothing is compiled for
+ *     it; a candidate that fails -- a HIP error included -- is skipped, and if the measurement itself fails the library's static
+ *     choice runs: the launch fails only where a plain launch would;
+ *   - it is skipped while `hip_stream` is being captured into a hipGraph, when `in` and `out` overlap, and for windows;
+ *   - other launches of the same shape on this program wait until the plan is known (they then use it).
  * ---------------------------------------------------------------------------------------- */
 int fz_run_block(fz_program* p, const float* in, float* out, float* state, const float* params,
                  uint64_t n_streams, uint32_t n_samples, const fz_variant* v, void* hip_stream);

@@ -1613,21 +1613,24 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     monkeypatch.setenv("FLOWZ_HIP_NO_PLAN_CACHE", "1")
     prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
     LG = _capi.FZ_VF_LOCKSTEP | _capi.FZ_VF_GRID_SYNC
-    PERSIST = 1 << 27                                            # (internal: more blocks than CUs -> a persistent launch, a kernel of its own)
-    # four streams per lane where their kernel fits the 128 registers of a 1024-lane workgroup: it does with the ROCm installation's
-    # compiler (what build() pre-builds), not with the older one bundled with the PyTorch wheel (this process is bound to that one
-    # for whatever is not in the cache: INTEGRATION.md "Which compiler builds the kernels") -- then the library steps down to two
+    # streams per lane, lanes per workgroup and laps follow from the CU count (time_major_geometry): four streams per lane
+    # where their kernel fits the registers a lane of that workgroup gets (any host process builds with the installation's compiler
+    # now: fz_rtc_worker), else the library steps down
     fits4 = prog.kernel_resources(F.make_variant(4, 1, 1024, LG | _capi.FZ_VF_PREFETCH3), 1 << 20, 4096, as_launched=False)["scratch_bytes"] == 0
-    assert prog.kernel_name(None, 1 << 20, 4096, 0) == ("fz_block_kernel_p4u1b1024f%d" % (LG | _capi.FZ_VF_PREFETCH3) if fits4 else
-                                                        "fz_block_kernel_p2u2b1024f%d" % (LG | PERSIST))
+    assert fits4
+    assert prog.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p4u1b1024f%d" % (LG | _capi.FZ_VF_PREFETCH3)
     assert prog.kernel_name(None, 1 << 19, 4096, 0) == "fz_block_kernel_p2u2b1024f%d" % LG
-    assert prog.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p1u4b1024f%d" % LG
-    assert prog.kernel_name(None, 1 << 21, 4096, 0) == "fz_block_kernel_p2u2b1024f%d" % (LG | PERSIST)   # (four streams per lane do not fit the persistent kernel's registers)
+    assert prog.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p2u4b512f%d" % LG          # two streams per lane, 512-lane workgroups: 0.74 against 0.65 for one x 1024
+    assert prog.kernel_name(None, 3 << 18, 4096, 0) == "fz_block_kernel_p4u1b768f%d" % (LG | _capi.FZ_VF_PREFETCH3)   # 786 432 = 256 workgroups x 768 lanes x 4
+    assert prog.kernel_name(None, 1 << 21, 4096, 0) == "fz_block_kernel_p2u2b1024f%d" % LG          # four laps, one launch each (no persistent kernel any more)
     assert prog.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % _capi.FZ_VF_MAX_WG(2)
     assert "b1024" not in prog.kernel_name(None, 1 << 17, 4096, 0)
-    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024f%d" % (LG | PERSIST)   # (1024 blocks on 256 CUs: four laps)
+    # a register-heavy graph steps down: the oscillator chain (31 per-stream coefficients) runs two streams per lane with one row per
+    # chunk buffer (114 registers); a graph that ends at one stream per lane runs stage-packed there
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p2u1b1024f%d" % (LG | _capi.FZ_VF_PREFETCH3)
+    assert F.compile(F.from_sexpr(G.osc_chain(12))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s12f%d" % (LG | _capi.FZ_VF_STAGE_PACK)
     assert F.compile(F.from_sexpr(G.par4_sum())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u32b256f0"
-    # more blocks than the chip holds workgroups (300 of 1024 lanes): a persistent launch, two laps with counters of their own
+    # more blocks than the chip holds workgroups (300 of 1024 lanes): two laps, a launch each with counters of its own
     ns, T = 300 * 1024 + 64, 40
     x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
     F.synth_fill(x, SEED + 34)
@@ -1643,6 +1646,60 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     ids = np.array([0, 1, 63, 64, 1023, 1024, ns - 1])
     want = C.df1_cascade([G.STABLE] * 6, O.synth_input(SEED + 33, ids, T))
     assert ndiff(y[:, torch.as_tensor(ids, device="cuda")].cpu().numpy(), want) == 0
+
+
+@pytest.mark.parametrize("ns", [1027, 2050, 4101, 1023])
+def test_ragged_stream_counts_in_lockstep_workgroups(torch_cuda, F, ns):
+    """FZ_VF_RAGGED (round 4): a stream count that is not a multiple of the streams per lane in the lockstep frame kernel.  The last lane's
+    accesses run past the end of every row (rows of an odd count are only 4-byte aligned): the per-row buffer descriptors return zeros
+    there and drop the writes (raw buffers are range-checked per dword, tools/oob_probe.hip).  Frames, state rows, per-stream
+    coefficient rows; vs the oracle and the ordinary kernel, state included; chained blocks."""
+    torch = torch_cuda
+    from zignal_amd import _capi
+    L, GS, P3 = _capi.FZ_VF_LOCKSTEP, _capi.FZ_VF_GRID_SYNC, _capi.FZ_VF_PREFETCH3
+    for g, with_params in ((G.df1_cascade(2), False), (G.cross_wire(), False), (G.osc_chain(2), True)):
+        prog = F.compile(F.from_sexpr(g))
+        T = 41
+        x = O.synth_input(SEED + 131, np.arange(ns), T, n_wires=max(prog.n_in, 1))
+        params = W.osc_chain_params(SEED + 132, np.arange(ns), 2) if with_params else None
+        want = O.compile(g, ns, params=params).run(x)
+        got0, st0 = run_gpu(torch, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK), params=params)
+        assert ndiff(got0, want) == 0
+        for v in ((4, 1, 256, L | GS | P3), (4, 2, 128, L), (2, 2, 256, L | GS), (2, 4, 64, L)):
+            if ns % v[0] == 0:
+                continue
+            assert prog.kernel_name(F.make_variant(*v), ns, T).endswith("f%d" % (v[3] | (1 << 28)))        # (internal flag: FZ_VF_RAGGED)
+            got, st = run_gpu(torch, F, prog, x, variant=F.make_variant(*v), params=params)
+            assert ndiff(got, want) == 0 and torch.equal(st, st0), (ns, v)
+            a, st1 = run_gpu(torch, F, prog, x[:17], variant=F.make_variant(*v), params=params)
+            b, st2 = run_gpu(torch, F, prog, x[17:], variant=F.make_variant(1, 8, 256, NO_STAGE_PACK), params=params, state=st1)
+            assert ndiff(np.concatenate([a, b]), want) == 0 and torch.equal(st2, st0)
+    with pytest.raises(F.FlowzError):                            # only the lockstep frame kernel on plain time-major rows takes such counts
+        F.compile(F.from_sexpr(G.df1_cascade(2))).run_block(torch.zeros((8, 1027, 1), device="cuda"), variant=F.make_variant(2, 8, 256))
+
+
+@pytest.mark.parametrize("ns", [(1 << 18) + 1, (1 << 18) + 515, 3 * (1 << 18) + 2, (1 << 20) + 1, 3 << 19, 1_000_001])
+def test_time_major_laps_remainders_and_ragged_defaults(torch_cuda, F, ns, monkeypatch):
+    """What the library's own choice does with stream counts that are not whole workgroups x CUs (time_major_geometry): whole laps as
+    launches of their own, the few streams beyond them as a remainder launch of the few-stream kernels, a count that is not a multiple
+    of the streams per lane through FZ_VF_RAGGED.  Same bits as the ordinary kernel on every stream, state included; sampled streams
+    (the first, the last, both sides of the main / remainder seam) against the oracle."""
+    torch = torch_cuda
+    monkeypatch.setenv("FLOWZ_HIP_NO_PLAN_CACHE", "1")
+    for g, with_params in ((G.df1_cascade(6), False), (G.osc_chain(6), True)):
+        prog = F.compile(F.from_sexpr(g))
+        T = 24 if ns > (1 << 20) else 72
+        x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+        F.synth_fill(x, SEED + 140)
+        pd = torch.from_numpy(W.osc_chain_params(SEED + 141, np.arange(ns))).cuda() if with_params else None
+        y, st = prog.run_block(x, params=pd)                     # (too small a block for the first-launch measurement)
+        y0, st0 = prog.run_block(x, params=pd, variant=F.make_variant(1, 16, 256, NO_STAGE_PACK))
+        assert torch.equal(y, y0) and torch.equal(st, st0), (ns, with_params)
+        seam = (ns // (1 << 18)) * (1 << 18)
+        ids = np.unique(np.clip(np.array([0, 1, 1023, 1024, seam - 1, seam, seam + 1, ns - 2, ns - 1]), 0, ns - 1))
+        xh = O.synth_input(SEED + 140, ids, T)
+        want = C.osc_chain(np.ascontiguousarray(pd[:, torch.as_tensor(ids, device="cuda")].cpu().numpy()), xh) if with_params else C.df1_cascade([G.STABLE] * 6, xh)
+        assert ndiff(y[:, torch.as_tensor(ids, device="cuda")].cpu().numpy(), want) == 0
 
 
 def test_grid_sync_survives_a_busy_gpu_and_overlapping_streams(torch_cuda, F, monkeypatch):

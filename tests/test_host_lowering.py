@@ -499,13 +499,14 @@ def test_no_headline_kernel_uses_scratch_memory_and_unroll_is_lowered_until_noth
     assert p.kernel_name(v, 200, 61).startswith("fz_block_kernel_p4u8b256")
 
 
-def test_code_objects_carry_their_compiler_and_the_installations_are_preferred(tmp_path):
-    """A process that imported PyTorch first is bound to the hiprtc / comgr bundled with the wheel (an older ROCm whose code
-    for the four-streams-per-lane headline kernel needs scratch memory).  (1) What such a process builds is cached under a
-    name of its own, and an object the installation's compiler built (build() pre-builds them in a process without torch) is
-    found first.  (2) FLOWZ_HIP_ISOLATED_HIPRTC=1: the installation's compiler in a link-map namespace of its own --
-    byte-identical code objects with and without torch."""
+def test_any_host_process_builds_with_the_installations_compiler(tmp_path):
+    """A process that imported PyTorch first is bound to the hiprtc / comgr bundled with the wheel (an older ROCm whose code for the
+    four-streams-per-lane headline kernel needs scratch memory).  The library notices and hands every build to fz_rtc_worker -- the
+    installation's hiprtc in a process of its own: same kernel symbol, same registers, byte-identical code objects under the same
+    cache names with and without torch, for a graph nobody pre-built.  Only without the worker does the host's compiler build
+    (under names of its own, with a warning) -- and objects the installation's compiler built are still found first."""
     import hashlib
+    import shutil
     import subprocess
     import sys
     prog = (
@@ -517,30 +518,62 @@ def test_code_objects_carry_their_compiler_and_the_installations_are_preferred(t
         "v = F.make_variant(4, 1, 1024, C.FZ_VF_LOCKSTEP | C.FZ_VF_GRID_SYNC | C.FZ_VF_PREFETCH3)\n"
         "r = p.kernel_resources(v, 1 << 20, 4096, as_launched=False)\n"
         "print(r['scratch_bytes'], r['vgprs'], p.kernel_name(None, 1 << 20, 4096, 0))\n"
+        "q = F.compile(F.from_sexpr(G.seq(G.df1_cascade(3), G.mul(G.lit(0.37), G.IN(1)), G.df2())))\n"      # (in nobody's cache)
+        "r = q.kernel_resources(None, 1 << 20, 4096)\n"
+        "print(r['scratch_bytes'], r['vgprs'], q.kernel_name(None, 1 << 20, 4096, 0))\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     want = ["0", "128", "fz_block_kernel_p4u1b1024f%d" % (F.C.FZ_VF_LOCKSTEP | F.C.FZ_VF_GRID_SYNC | F.C.FZ_VF_PREFETCH3)]
 
     def run(who, cache, **extra):
         env = dict(os.environ, FLOWZ_HIP_CACHE=str(tmp_path / cache), FLOWZ_HIP_NO_PLAN_CACHE="1", **extra)
-        if "FLOWZ_HIP_ISOLATED_HIPRTC" not in extra:
-            env.pop("FLOWZ_HIP_ISOLATED_HIPRTC", None)
-        r = subprocess.run([sys.executable, "-c", prog, who], env=env, capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", prog, who], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         files = {n: hashlib.sha1(open(tmp_path / cache / n, "rb").read()).hexdigest() for n in os.listdir(tmp_path / cache) if n.endswith(".hsaco")}
-        return r.stdout.split(), files
+        return r.stdout.split(), files, r.stderr
 
-    # the wheel's compiler on its own: the headline kernel does not fit, the default steps down -- under names of its own
-    torch_out, torch_files = run("torch", "a")
-    plain_out, plain_files = run("plain", "b")
-    assert plain_out == want
-    if torch_out != want:                                       # (a wheel built with the installation's ROCm would not differ)
-        assert int(torch_out[0]) > 0 and torch_out[2] != want[2] and not set(torch_files) & set(plain_files)
-        # ... and next to pre-built objects it uses those
-        both_out, both_files = run("torch", "b")
-        assert both_out == want and set(plain_files) <= set(both_files) and all(both_files[n] == h for n, h in plain_files.items())
-    # the isolated compiler: the same names, the same bytes as without torch
-    iso_out, iso_files = run("torch", "c", FLOWZ_HIP_ISOLATED_HIPRTC="1")
-    assert iso_out == want and iso_files == plain_files
+    plain_out, plain_files, _ = run("plain", "a")
+    torch_out, torch_files, torch_err = run("torch", "b")
+    assert plain_out[:3] == want
+    assert torch_out == plain_out and torch_files == plain_files           # the same symbols, registers, file names and BYTES
+    assert "warning" not in torch_err
+    # without the worker: the host's compiler, under names of its own, and it says so once; pre-built objects still come first
+    lib_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zignal_amd", "lib")
+    moved = os.path.join(lib_dir, "fz_rtc_worker.away")
+    shutil.move(os.path.join(lib_dir, "fz_rtc_worker"), moved)
+    try:
+        lone_out, lone_files, lone_err = run("torch", "c")
+        if lone_out != plain_out:                                # (a wheel built with the installation's ROCm would not differ)
+            assert "warning" in lone_err and not set(lone_files) & set(plain_files)
+            both_out, both_files, _ = run("torch", "a")
+            assert both_out == plain_out and set(plain_files) <= set(both_files) and all(both_files[n] == h for n, h in plain_files.items())
+    finally:
+        shutil.move(moved, os.path.join(lib_dir, "fz_rtc_worker"))
+
+
+def test_time_major_geometry_follows_the_cu_count():
+    """Plain time-major frames of many streams (host side of time_major_geometry): streams per lane x lanes per workgroup x laps are
+    derived from the CU count (256 on a box without a GPU) and the measured table; counts just above whole laps run whole laps + a
+    remainder launch; counts that are not a multiple of the streams per lane set the internal FZ_VF_RAGGED."""
+    p = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    L, GS, P3, RAGGED = F.C.FZ_VF_LOCKSTEP, F.C.FZ_VF_GRID_SYNC, F.C.FZ_VF_PREFETCH3, 1 << 28
+    name = lambda n: p.kernel_name(None, n, 4096, 0)                                   # noqa: E731
+    assert name(1 << 18) == "fz_block_kernel_p2u4b512f%d" % (L | GS)
+    assert name(3 << 17) == "fz_block_kernel_p2u2b768f%d" % (L | GS)                   # 393 216 = 256 x 768 x 2
+    assert name(1 << 19) == "fz_block_kernel_p2u2b1024f%d" % (L | GS)
+    assert name(3 << 18) == "fz_block_kernel_p4u1b768f%d" % (L | GS | P3)              # 786 432 = 256 x 768 x 4
+    assert name(1_000_000) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)           # 245 workgroups of 1024 lanes
+    assert name(1 << 20) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)
+    assert name((1 << 20) + 1) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)       # one lap + a remainder launch of one stream: not ragged
+    assert name(1_000_001) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | RAGGED)  # fits the workgroups: the last lane is partial
+    assert name(1 << 21) == "fz_block_kernel_p2u2b1024f%d" % (L | GS)                  # four laps of two streams per lane (0.75 against 0.70 for two laps of four)
+    assert "b1024" not in name(1 << 17) and "f%d" % (L | GS) not in name((1 << 18) - 1024)   # below one wave per SIMD and CU: the few-stream kernels
+    # nothing of this on tiles, wide frames, LDS rings
+    assert p.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % F.C.FZ_VF_MAX_WG(2)
+    assert F.compile(F.from_sexpr(G.par4_sum())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u32b256f0"
+    # a register-heavy graph steps down: the oscillator chain (31 per-stream coefficients) runs two streams per lane with one row per
+    # chunk buffer (114 registers); a graph that ends at one stream per lane runs stage-packed there
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p2u1b1024f%d" % (L | GS | P3)
+    assert F.compile(F.from_sexpr(G.osc_chain(12))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s12f%d" % (L | GS | F.C.FZ_VF_STAGE_PACK)
 
 
 def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorphic_halves():

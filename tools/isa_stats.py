@@ -17,6 +17,7 @@ from zignal_amd import flowz as F  # noqa: E402
 
 GRAPHS = {"cascade6": lambda: G.df1_cascade(6), "par4": G.par4_sum, "par4f": G.par4_sum_fanout,
           "osc": lambda: G.osc_chain(6), "gain": lambda: G.mul(G.lit(0.5), G.IN(1)), "cascade2": lambda: G.df1_cascade(2), "cascade4": lambda: G.df1_cascade(4), "df1": G.df1, "integrator": G.integrator,
+          "mod6": lambda: G.df1_cascade_modulated(6), "ldsring": G.lds_ring_comb,
           "ring": lambda: G.seq(G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 40))), G.fb(G.add(G.mul(G.lit(0.7), G.DEL(1, 23)), G.IN(2))))}
 
 

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -146,6 +147,9 @@ inline uint32_t ws_waves(uint32_t flags) { return ws_parts(flags) + (ws_parts(fl
 
 // internal variant flag (never set by callers): FZ_VF_GRID_SYNC with more blocks than the chip holds workgroups -> persistent launch
 constexpr uint32_t FZ_VF_PERSIST = 1u << 27;
+// internal variant flag: the stream count is not a multiple of the streams per lane -- the last lane's accesses run past the rows' ends,
+// where the per-row buffer descriptors return zeros / drop the writes (frame kernel in lockstep, plain time-major rows)
+constexpr uint32_t FZ_VF_RAGGED = 1u << 28;
 constexpr uint32_t kChipCUs = 256;       // MI355X (gfx950): 8 XCDs x 32 CUs -- what chip_cus() answers on a box without a GPU
 unsigned chip_cus();                     // compute units of the current device (fz_launch.cpp)
 
@@ -213,6 +217,8 @@ struct fz_program {
    // caller passes none
    std::map<std::tuple<uint64_t, uint32_t, int>, fz_variant> plans;
    std::set<std::tuple<uint64_t, uint32_t, int>> tuned_default;   // shapes measured already (FLOWZ_HIP_AUTOTUNE)
+   std::set<std::tuple<uint64_t, uint32_t, int>> measuring;       // shapes whose first big launch is measuring its plan right now (other launches of the shape wait)
+   std::condition_variable measured;
    std::set<std::tuple<uint64_t, uint32_t, int>> plan_looked_up;  // shapes whose persisted plan (plans.txt of the kernel cache) was consulted
    uint64_t graph_hash = 0;                                        // structure of the lowered graph (no coefficient values)
    // FZ_VF_GRID_SYNC: arrival counters per device: 16 slices of `second` bytes, handed to the launches in turn (launches on
@@ -230,6 +236,15 @@ namespace fz {
 // allow_lockstep: the most streams per lane the CU-wide lockstep workgroups of plain time-major frames may use (0: not chosen at all)
 Variant resolve_variant(const Graph& g, const fz_variant* v, uint64_t n_streams, uint32_t n_samples = 1u << 20, uint32_t tile_streams = 0,
                         uint32_t allow_lockstep = 4);
+// plain time-major frames of many streams: streams per lane, lanes per workgroup, laps (one launch each), rows per chunk buffer, and
+// the streams those laps cover (the rest: a remainder launch) -- fz_plan.cpp
+struct TmGeometry {
+   uint32_t P = 0, lanes = 0, laps = 0, U = 0;
+   uint64_t main_streams = 0;
+   double score = 0.0;
+};
+TmGeometry time_major_geometry(uint64_t n_streams, uint32_t max_p, bool heavy_ops, bool ragged_ok, uint32_t only_p = 0);
+uint64_t lockstep_streams(const Graph& g, const fz_variant* uv, const Variant& v, uint64_t n_streams);
 // the kernel a launch of that shape runs: resolved, fitted to the tile / the 4 GiB chunk limit, unroll lowered until nothing spills
 Variant finalize_variant(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, bool settle = true);
 // builds (or fetches from the caches) the kernel of variant v; fn_out != null: also load it on the
@@ -248,6 +263,13 @@ uint64_t graph_structure_hash(const Graph& g);
 // the plan a launch without a variant would use for this shape on the current device: in memory, else persisted, else {0,0,0,0}
 fz_variant planned_variant(fz_program* p, uint64_t n_streams, uint32_t tile_streams);
 void drop_plan(fz_program* p, uint64_t n_streams, uint32_t tile_streams);
+// while one of these lives on a thread, get_kernel on that thread refuses to BUILD (FZ_E_UNSUPPORTED): cached objects only
+extern thread_local bool tl_no_jit;
+struct NoJitScope {
+   bool before;
+   explicit NoJitScope(bool on) : before(tl_no_jit) { tl_no_jit = on || before; }
+   ~NoJitScope() { tl_no_jit = before; }
+};
 // is the kernel's code object at hand (in memory or in the on-disk cache), i.e. can it run without a hiprtc build?
 bool kernel_at_hand(fz_program* p, const Variant& v);
 }  // namespace fz

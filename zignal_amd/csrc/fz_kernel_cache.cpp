@@ -511,6 +511,8 @@ bool kernel_at_hand(fz_program* p, const Variant& v)
    return false;
 }
 
+thread_local bool tl_no_jit = false;
+
 // The program mutex is held only to find (or create) the variant's slot; cache lookup, the hiprtc build (seconds) and module
 // loading happen under the SLOT's own mutex, so other launches of the program -- other variants, other threads -- go on.
 std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out)
@@ -541,6 +543,8 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
             if (found) break;
          }
       if (!found) {
+         // (the plan measurement a first big launch makes by itself never waits for a build: NoJitScope)
+         if (tl_no_jit) fail(FZ_E_UNSUPPORTED, "kernel not at hand (it would have to be built)");
          k->code = jit_compile(p->g, v);
          if (use_cache) {
             cache_store(dir, path, k->code);

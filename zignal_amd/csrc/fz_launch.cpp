@@ -103,7 +103,7 @@ struct ArgsHeader {
    unsigned int row0;
    unsigned int mod_stride;
    unsigned int n_blocks;
-   unsigned int block0;
+   unsigned int group0;
    unsigned int reserved0;
 };
 static_assert(sizeof(ArgsHeader) % 8 == 0 && sizeof(ArgsHeader) == 6 * 8 + 8 + 10 * 4, "ArgsHeader must match the head of the kernel's fz_args without padding");
@@ -149,7 +149,10 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       bool known = false;
       (void)planned_variant(p, n_streams, tile_streams);      // first launch of this shape: a plan persisted by an earlier process?
       {
-         std::lock_guard<std::mutex> lock(p->mu);
+         // (another thread's first big launch of this shape may be measuring the plan right now, on ITS buffers: wait for the
+         //  result instead of racing it -- the measuring thread's own launches carry explicit variants and never come here)
+         std::unique_lock<std::mutex> lock(p->mu);
+         p->measured.wait(lock, [&] { return p->measuring.count(key) == 0; });
          auto it = p->plans.find(key);
          known = it != p->plans.end() || p->tuned_default.count(key) != 0;
          // (a plan is measured on blocks of thousands of samples: the wave-split kernels pay several masked rounds per launch and
@@ -183,40 +186,63 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
          {
             std::lock_guard<std::mutex> lock(p->mu);
             p->tuned_default.insert(key);                   // (also stops the recursion through tune -> launch)
+            p->measuring.insert(key);                       // other launches of this shape wait until the plan is known
          }
-         const size_t sb = (size_t)g.n_state * n_streams * 4;
-         // the state is saved before and restored after the measurement ON EVERY EXIT PATH
-         struct Saved {
-            float* copy = nullptr;
-            float* state;
-            size_t bytes;
-            hipStream_t st;
-            ~Saved()
+         struct Done {                                      // ... on every exit path
+            fz_program* p;
+            decltype(key) k;
+            ~Done()
             {
-               if (!copy) return;
-               (void)hipMemcpyAsync(state, copy, bytes, hipMemcpyDeviceToDevice, st);
-               (void)hipStreamSynchronize(st);
-               (void)hipFree(copy);
+               {
+                  std::lock_guard<std::mutex> lock(p->mu);
+                  p->measuring.erase(k);
+               }
+               p->measured.notify_all();
             }
-         } saved{nullptr, state, sb, (hipStream_t)stream};
+         } done{p, key};
+         const size_t sb = (size_t)g.n_state * n_streams * 4;
+         // The candidates run on the caller's buffers: the state is saved before and restored after the measurement, and the
+         // restore is CHECKED -- a state that could not be put back is an error of this launch, never a silent one.  A failure
+         // inside the measurement itself (a candidate's HIP error) is not the caller's problem: the default launch below goes ahead.
+         float* copy = nullptr;
          bool have_copy = true;
          if (sb) {
-            if (hipMalloc((void**)&saved.copy, sb) != hipSuccess) {      // no room for the snapshot (multi-GiB state): do not tune
+            if (hipMalloc((void**)&copy, sb) != hipSuccess) {           // no room for the snapshot (multi-GiB state): do not tune
                (void)hipGetLastError();
-               saved.copy = nullptr;
+               copy = nullptr;
                have_copy = false;
-            } else {
-               FZ_HIP(hipMemcpyAsync(saved.copy, state, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            } else if (hipMemcpyAsync(copy, state, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+               (void)hipGetLastError();
+               (void)hipFree(copy);
+               copy = nullptr;
+               have_copy = false;
             }
          }
          if (have_copy) {
             fz_variant chosen{0, 0, 0, 0};
-            const int rc = tune(p, in, out, state, params, n_streams, n_samples, tile_streams, stream, &chosen, nullptr, true);
-            if (rc != FZ_OK) return rc;
-            if (chosen.streams_per_lane || chosen.unroll || chosen.block_threads || chosen.flags) {
+            int rc = FZ_E_INVALID;
+            std::string why;
+            try {
+               rc = tune(p, in, out, state, params, n_streams, n_samples, tile_streams, stream, &chosen, nullptr, true);
+            } catch (const Error& er) {
+               rc = er.code;
+               why = er.msg;
+               if (er.code == FZ_E_HIP) (void)hipGetLastError();
+            }
+            if (copy) {
+               hipError_t e1 = hipMemcpyAsync(state, copy, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+               hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+               (void)hipFree(copy);
+               if (e1 != hipSuccess || e2 != hipSuccess)
+                  fail(FZ_E_HIP, std::string("the closure state could not be restored after the plan measurement of this shape (") +
+                                    hipGetErrorString(e1 != hipSuccess ? e1 : e2) + "): `state` is advanced by the measurement's blocks -- reset it; FLOWZ_HIP_AUTOTUNE=0 turns the measurement off");
+            }
+            if (rc == FZ_OK && (chosen.streams_per_lane || chosen.unroll || chosen.block_threads || chosen.flags)) {
                planned = chosen;
                uv = &planned;
                from_plan = true;
+            } else if (rc != FZ_OK && std::getenv("FLOWZ_HIP_DEBUG")) {
+               std::fprintf(stderr, "[flowz_hip] plan measurement of this shape failed (%s): the library default runs\n", why.c_str());
             }
          }
       }
@@ -238,16 +264,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       one.streams_per_lane = 1;
       v = finalize_variant(p, &one, n_streams, n_samples, tile_streams);
    }
-   void* fn = nullptr;
-   auto k = get_kernel(p, v, &fn);
-
-   // kernarg image of `struct fz_args` (8-byte aligned: pad the coefficient tail)
-   // (built on the stack for ordinary graphs: no allocation on the launch path)
-   const size_t off64 = (sizeof(ArgsHeader) + sizeof(float) * std::max<size_t>(g.consts.size(), 1) + 7) & ~size_t(7);
-   const size_t kbytes = off64 + sizeof(double) * std::max<size_t>(g.consts64.size(), 1);
-   alignas(8) char small[1024];
-   std::vector<char> big;
-   char* const kbuf = kbytes <= sizeof small ? small : (big.resize(kbytes), big.data());
+   // sample-rate modulators: one array for all streams
    const float* mod_dev = nullptr;
    uint32_t mod_stride = 0;
    if (g.n_mod) {
@@ -260,53 +277,81 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       if ((uint64_t)mod_row0 + row0 + n_samples > mod_stride) fail(FZ_E_INVALID, "fz_program_set_modulation: stride is shorter than the rows of this launch");
       mod_dev += mod_row0;
    }
-   const unsigned n_blocks = (unsigned)(((unsigned int)(n_streams / v.P) + v.block - 1) / v.block);
-   // (wave split: v.block counts the 64 streams of a workgroup; two waves evaluate them)
-   const unsigned threads = ws_parts(v.flags) ? v.block * ws_waves(v.flags) : v.block;
-   // FZ_VF_GRID_SYNC needs every workgroup that synchronises RUNNING: with more blocks than the chip holds workgroups of this
-   // kernel (occupancy x CUs) the block is cut into LAPS -- contiguous stream ranges of at most one workgroup per resident slot,
-   // the same number of blocks in every lap (whole eights: the XCDs) -- and every lap is a launch of its own (round 4; the one-lap
-   // kernel has no loop to pay registers for: four streams per lane fit where the persistent kernel of round 3 stepped down).
-   // FZ_VF_PERSIST (internal, FLOWZ_HIP_LAPS=kernel): one launch of `resident` workgroups that loop over the laps themselves.
-   unsigned laps = 1, per_lap = n_blocks, grid = n_blocks;
-   size_t sync_bytes = 0;
-   if (v.flags & FZ_VF_GRID_SYNC) {
-      const unsigned resident = resident_workgroups(fn, (int)threads);
-      if (n_blocks > resident) {
-         laps = (n_blocks + resident - 1) / resident;
-         per_lap = std::min(resident, ((n_blocks + laps - 1) / laps + 7u) / 8u * 8u);
-         grid = per_lap;
-      }
-      sync_bytes = (size_t)((v.flags & FZ_VF_PERSIST) ? laps : 1u) * 8 * 128;   // per-(lap, XCD) arrival counters, zeroed in stream order before the launch
-      if (v.flags & FZ_VF_PERSIST) laps = 1;                                     // (the kernel loops)
-   }
-   ArgsHeader h{in, out, state, params, mod_dev, nullptr, (unsigned long long)n_streams, n_samples, (unsigned int)(n_streams / v.P),
-                (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (v.P * v.block)) : 0u, rows_total, row0, mod_stride, n_blocks, 0u, 0u};
+   // kernarg image of `struct fz_args` (8-byte aligned: pad the coefficient tail)
+   // (built on the stack for ordinary graphs: no allocation on the launch path)
+   const size_t off64 = (sizeof(ArgsHeader) + sizeof(float) * std::max<size_t>(g.consts.size(), 1) + 7) & ~size_t(7);
+   const size_t kbytes = off64 + sizeof(double) * std::max<size_t>(g.consts64.size(), 1);
+   alignas(8) char small[1024];
+   std::vector<char> big;
+   char* const kbuf = kbytes <= sizeof small ? small : (big.resize(kbytes), big.data());
    {
       std::lock_guard<std::mutex> lock(p->mu);
-      if (!g.consts.empty()) std::memcpy(kbuf + sizeof h, g.consts.data(), sizeof(float) * g.consts.size());
+      if (!g.consts.empty()) std::memcpy(kbuf + sizeof(ArgsHeader), g.consts.data(), sizeof(float) * g.consts.size());
       if (!g.consts64.empty()) std::memcpy(kbuf + off64, g.consts64.data(), sizeof(double) * g.consts64.size());
    }
-   for (unsigned lap = 0; lap < laps; ++lap) {
-      if (laps > 1) {
-         h.block0 = lap * per_lap;
-         grid = std::min(per_lap, n_blocks - h.block0);
-      }
-      if (sync_bytes) {
-         h.sync = sync_counters(p, sync_bytes, stream);
-         FZ_HIP(hipMemsetAsync(h.sync, 0, sync_bytes, (hipStream_t)stream));
-      }
-      std::memcpy(kbuf, &h, sizeof h);
-      size_t size = kbytes;
-      void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, kbuf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-      FZ_HIP(hipModuleLaunchKernel((hipFunction_t)fn, grid, 1, 1, threads, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
-   }
-   const size_t size = kbytes;
    static const bool debug = std::getenv("FLOWZ_HIP_DEBUG") != nullptr;
-   if (debug) {
-      FZ_HIP(hipStreamSynchronize((hipStream_t)stream));
-      std::fprintf(stderr, "[flowz_hip] launched %u lap(s) grid=%u block=%u P=%u U=%u flags=%u n_streams=%llu n_samples=%u kernarg=%zu B vgprs=%u scratch=%u B/lane\n",
-                   laps, grid, v.block, v.P, v.U, v.flags, (unsigned long long)n_streams, n_samples, size, k->res.vgprs + k->res.agprs, k->res.scratch_bytes);
+
+   // One kernel variant over the streams [first, first + count) of the block (the pointers and the row pitch stay the block's:
+   // the kernel adds the first stream group itself).
+   auto run_part = [&](const Variant& w, uint64_t first, uint64_t count) {
+      void* fn = nullptr;
+      auto k = get_kernel(p, w, &fn);
+      const unsigned group0 = (unsigned)(first / w.P);
+      const unsigned groups = (unsigned)((count + ((w.flags & FZ_VF_RAGGED) ? w.P - 1 : 0)) / w.P);   // lanes of work (FZ_VF_RAGGED: the last one is partial)
+      const unsigned n_blocks = (groups + w.block - 1) / w.block;
+      // (wave split: w.block counts the 64 streams of a workgroup; two waves evaluate them)
+      const unsigned threads = ws_parts(w.flags) ? w.block * ws_waves(w.flags) : w.block;
+      // FZ_VF_GRID_SYNC needs every workgroup that synchronises RUNNING: with more blocks than the chip holds workgroups of this
+      // kernel (occupancy x CUs) the streams are cut into LAPS -- contiguous ranges of at most one workgroup per resident slot,
+      // the same number of blocks in every lap (whole eights: the XCDs) -- and every lap is a launch of its own (round 4; the
+      // one-lap kernel has no loop to pay registers for: four streams per lane fit where the persistent kernel of round 3 stepped
+      // down).  FZ_VF_PERSIST (internal, FLOWZ_HIP_LAPS=kernel): one launch of `resident` workgroups that loop over the laps.
+      unsigned laps = 1, per_lap = n_blocks, grid = n_blocks;
+      size_t sync_bytes = 0;
+      if (w.flags & FZ_VF_GRID_SYNC) {
+         const unsigned resident = resident_workgroups(fn, (int)threads);
+         if (n_blocks > resident) {
+            laps = (n_blocks + resident - 1) / resident;
+            per_lap = std::min(resident, ((n_blocks + laps - 1) / laps + 7u) / 8u * 8u);
+            grid = per_lap;
+         }
+         sync_bytes = (size_t)((w.flags & FZ_VF_PERSIST) ? laps : 1u) * 8 * 128;   // per-(lap, XCD) arrival counters, zeroed in stream order before the launch
+         if (w.flags & FZ_VF_PERSIST) laps = 1;                                     // (the kernel loops)
+      }
+      ArgsHeader h{in, out, state, params, mod_dev, nullptr, (unsigned long long)n_streams, n_samples, group0 + groups,
+                   (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (w.P * w.block)) : 0u, rows_total, row0, mod_stride, n_blocks, group0, 0u};
+      for (unsigned lap = 0; lap < laps; ++lap) {
+         if (laps > 1) {
+            h.group0 = group0 + lap * per_lap * w.block;
+            grid = std::min(per_lap, n_blocks - lap * per_lap);
+         }
+         if (sync_bytes) {
+            h.sync = sync_counters(p, sync_bytes, stream);
+            FZ_HIP(hipMemsetAsync(h.sync, 0, sync_bytes, (hipStream_t)stream));
+         }
+         std::memcpy(kbuf, &h, sizeof h);
+         size_t size = kbytes;
+         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, kbuf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+         FZ_HIP(hipModuleLaunchKernel((hipFunction_t)fn, grid, 1, 1, threads, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
+      }
+      if (debug) {
+         FZ_HIP(hipStreamSynchronize((hipStream_t)stream));
+         std::fprintf(stderr, "[flowz_hip] launched streams [%llu, %llu) of %llu: %u lap(s) grid=%u block=%u P=%u U=%u flags=%u n_samples=%u kernarg=%zu B vgprs=%u scratch=%u B/lane\n",
+                      (unsigned long long)first, (unsigned long long)(first + count), (unsigned long long)n_streams, laps, grid, w.block, w.P, w.U, w.flags, n_samples, kbytes,
+                      k->res.vgprs + k->res.agprs, k->res.scratch_bytes);
+      }
+   };
+   // the library's own lockstep choice may cover whole laps only and leave the last few streams to a launch of their own
+   // (time_major_geometry): those run what a block of that few streams runs by itself
+   const uint64_t main_streams = stream_major ? n_streams : lockstep_streams(g, uv, v, n_streams);
+   run_part(v, 0, main_streams);
+   if (main_streams < n_streams) {
+      const uint64_t rem = n_streams - main_streams;
+      Variant r = resolve_variant(g, nullptr, rem, n_samples, 0, 0);
+      // (never the grid-synchronised walk for the few: allow_lockstep = 0 above; a spilling kernel steps down as always)
+      while ((uint64_t)row_streams * std::max(wmax, out_w) * 4u * r.U >= (1ull << 32) && r.U > (ws_parts(r.flags) ? 8u : 1u)) r.U /= 2;   // (a chunk of U rows: one 4 GiB descriptor)
+      r = settle_variant(p, r);
+      run_part(r, main_streams, rem);
    }
    return FZ_OK;
 }

@@ -18,6 +18,7 @@
 //   4. no algebra  -- nothing is re-associated, folded or simplified: one float32 rounding per
 //                     node of the user's tree (proto::_default, :769-772).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <tuple>
@@ -628,7 +629,12 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
       if (f64 && l.far)
          fail(FZ_E_UNSUPPORTED, "a double delay line deeper than " + std::to_string(kLdsMaxDepth) + " samples (the rings in HBM hold floats)");
       if (l.in_lds) {
-         uint32_t sz = 1;
+         // ring slots: exactly the depth (round 4).  A power of two makes the ring index one scalar AND, but the rings of a workgroup
+         // share the CU's 160 KiB with every other workgroup on it: lines of 40 and 23 samples rounded up to 64 + 32 slots let 426
+         // streams be resident per CU, exact sizes 650 -- occupancy is what bounds a graph whose every step waits for LDS reads
+         // (FLOWZ_HIP_LDS_POW2=1 keeps the power-of-two sizes for comparison; the index of an exact ring is a wave-uniform modulo)
+         static const bool pow2 = std::getenv("FLOWZ_HIP_LDS_POW2") != nullptr;
+         uint32_t sz = pow2 ? 1u : l.depth;
          while (sz < l.depth) sz <<= 1;
          l.lds_slot0 = lds;
          l.lds_size = sz;

@@ -24,6 +24,67 @@ static bool uv_has_shape(const fz_variant* uv)
    return uv && (uv->streams_per_lane || uv->unroll || uv->block_threads || (uv->flags & ~(uint32_t)FZ_VF_STREAM_MAJOR));
 }
 
+// ---- plain time-major frames of many streams: the launch geometry ------------------------------------------------------------
+// The row walk in lockstep (FZ_VF_LOCKSTEP + FZ_VF_GRID_SYNC: one workgroup per CU that meets at a barrier after every chunk, the
+// workgroups of an XCD in step through arrival counters) has three knobs: streams per lane P, lanes per workgroup, and -- with
+// more work than one workgroup per CU -- LAPS, each a launch over a contiguous stream range.  They follow from the chip (CUs,
+// 1024 lanes per workgroup, whole waves per SIMD: lanes in multiples of 256 -- 960 lanes measured 0.50 of peak against 0.74 for
+// 1024) and from what each (P, lanes) pair streams, measured on the 6-biquad cascade x 4096 samples with every workgroup filled
+// (profiles/r04/sweep_time_major_geometry.txt; fraction of 8 TB/s):
+//        lanes      256     512     768    1024
+//        P = 4     0.64    0.76    0.76    0.76        (U = 4 / 2 / 1 / 1: the rows ahead per CU stay >= 16 KiB)
+//        P = 2     0.61    0.74    0.72    0.78
+//        P = 1      --      --      --     0.65 (the cascade is VALU-bound there: 54 scalar operations per sample; light graphs 0.72)
+// A block of several laps loses about 5 % (2 097 152 streams: 0.75 in four laps of P = 2, 0.70 in two of P = 4; 1 572 864: 0.76 either
+// way).  The choice is the candidate with the best  table value x fill (streams / (laps x CUs x lanes x P)) x lap penalty.
+// A stream count just above whole laps (1 048 577: one stream more than 256 workgroups of 1024 lanes x 4 hold) would pay a whole extra
+// lap for its last few streams; such a block runs as whole laps plus a REMAINDER launch (at most 65 536 streams: the few-stream
+// kernels, ~0.35 ms per 4096 samples whatever the count -- 6 % of a lap of a million streams).  A count that is not a multiple of P
+// but fits the workgroups is no obstacle either: FZ_VF_RAGGED.
+TmGeometry time_major_geometry(uint64_t n_streams, uint32_t max_p, bool heavy_ops, bool ragged_ok, uint32_t only_p)
+{
+   static const double eff[3][4] = {{0.55, 0.60, 0.62, 0.72}, {0.61, 0.74, 0.72, 0.78}, {0.64, 0.76, 0.76, 0.76}};   // [P = 1, 2, 4][lanes / 256 - 1]
+   constexpr double kRemainderMs = 0.35, kBytesPerMs = 8.0e9, kBytesPerStream = 32880.0;   // (per 4096-sample block: the unit of the comparison)
+   constexpr uint64_t kRemainderMax = 65536;
+   const uint64_t cus = chip_cus();
+   TmGeometry best;
+   auto consider = [&](uint32_t P, uint64_t lanes, uint64_t laps, uint64_t main_streams, double ms) {
+      const double sc = (double)n_streams * kBytesPerStream / (ms * kBytesPerMs);
+      if (sc <= best.score) return;
+      best.P = P;
+      best.lanes = (uint32_t)lanes;
+      best.laps = (uint32_t)laps;
+      best.main_streams = main_streams;
+      best.score = sc;
+      // rows ahead per CU: a CU's piece of a row is lanes x P x 4 bytes -- 12 KiB and more: one row per buffer, three buffers (two
+      // rows ahead); 6-8 KiB: chunks of two rows; 4 KiB: of four
+      const uint64_t piece = lanes * P * 4u;
+      best.U = piece >= 12288 ? 1u : piece >= 6144 ? 2u : 4u;
+   };
+   for (uint32_t P = 4, pi = 2; P >= 1; P /= 2, --pi) {
+      if (P > max_p || (only_p && P != only_p)) continue;
+      auto ms_of = [&](uint64_t lanes, uint64_t laps) {
+         double e = eff[pi][lanes / 256 - 1] * (laps > 1 ? 0.95 : 1.0);
+         if (P == 1 && heavy_ops) e *= 0.9;
+         return (double)(laps * cus * lanes * P) * kBytesPerStream / (e * kBytesPerMs);
+      };
+      if (n_streams % P == 0 || ragged_ok) {                 // all streams in laps of equal size
+         const uint64_t groups = (n_streams + P - 1) / P;
+         const uint64_t laps = std::max<uint64_t>(1, (groups + cus * 1024 - 1) / (cus * 1024));
+         const uint64_t lanes = std::min<uint64_t>(std::max<uint64_t>(((groups + laps * cus - 1) / (laps * cus) + 255) / 256 * 256, 256), 1024);
+         consider(P, lanes, laps, n_streams, ms_of(lanes, laps));
+      }
+      for (uint64_t lanes = 1024; lanes >= 256; lanes -= 256) {   // whole laps of full workgroups + a remainder launch
+         const uint64_t per_lap = cus * lanes * P, laps = n_streams / per_lap;
+         if (laps == 0) continue;
+         const uint64_t rem = n_streams - laps * per_lap;
+         if (rem == 0 || rem > kRemainderMax) continue;
+         consider(P, lanes, laps, laps * per_lap, ms_of(lanes, laps) + kRemainderMs);
+      }
+   }
+   return best;
+}
+
 Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, uint32_t allow_lockstep)
 {
    if (tile_streams >= n_streams) tile_streams = 0;
@@ -69,7 +130,9 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       return v;
    }
    if (reqP) {
-      if (n_streams % reqP) fail(FZ_E_INVALID, "n_streams must be a multiple of streams_per_lane");
+      // (the lockstep frame kernel on plain time-major rows takes any count: FZ_VF_RAGGED)
+      if (n_streams % reqP && !((v.flags & FZ_VF_LOCKSTEP) && !tile_streams && !g.typed && g.far_lines.empty() && g.n_lds_slots == 0))
+         fail(FZ_E_INVALID, "n_streams must be a multiple of streams_per_lane");
       v.P = reqP;
    } else {
       // fill the chip first (256 CUs x 4 SIMDs, several waves each), then pack two streams per lane
@@ -77,6 +140,40 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // -- unless the frames are already wide (>= 3 wires: 12+ bytes per lane with one stream)
       // (measured crossover on the 6-biquad cascade: 2^18 streams, profiles/r01/sweep_stream_counts.txt)
       v.P = (n_streams >= (1u << 18) && n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) ? 2 : 1;
+   }
+   // PLAIN TIME-MAJOR frames of many streams (round 3): consecutive rows are n_streams * wires * 4 bytes apart -- megabytes,
+   // i.e. every row a wave has in flight is another 2 MiB page, and waves that drift apart in time multiply the pages a CU
+   // touches (160 x the L1-TLB misses of tiled frames, profiles/r01/pmc_tlb_tiled_vs_timemajor.txt).  So the whole CU walks
+   // the rows together: ONE workgroup per CU that meets at a barrier after every chunk (FZ_VF_LOCKSTEP), few rows in flight per
+   // lane, and the workgroups of an XCD walk the rows together too (FZ_VF_GRID_SYNC): 0.76-0.79 of peak against 0.61-0.67 for
+   // four-wave workgroups that run free.  From one wave per SIMD and CU of work on (CUs x 1024 streams); narrow frames (4-wire
+   // frames gain nothing: their rows are wide already); register delay lines only.
+   // allow_lockstep caps the streams per lane: fz_finalize_variant steps it down (4 -> 2 -> 1) until the kernel fits the registers a
+   // lane of that workgroup gets; a graph that reaches one stream per lane and is a series of isomorphic segments runs STAGE-PACKED
+   // there -- packing by stages costs no registers per stream (the oscillator chain with its 31 per-stream coefficients: 0.70 of
+   // peak against 0.65 un-packed, where two streams per lane would need 155 registers).
+   // A stream count that is not a multiple of the streams per lane is no obstacle (FZ_VF_RAGGED, round 4): the last lane's
+   // accesses run past the end of the row, where the buffer descriptors of the rows return zeros and drop the writes (raw
+   // buffers are range-checked per dword, tools/oob_probe.hip), and rows that are only 4-byte aligned are fine for b64 / b128.
+   {
+      const bool nothing_asked = !reqP && !reqU && !reqB && !(v.flags & ~(uint32_t)FZ_VF_OUT_F64);
+      if (allow_lockstep && nothing_asked && !tile_streams && n_streams >= (uint64_t)chip_cus() * 1024u && g.n_in <= 2 && g.n_out <= 2 &&
+          g.far_lines.empty() && g.n_lds_slots == 0 && !(g.typed && (n_streams % 4))) {
+         const uint32_t cap = allow_lockstep >= 3 ? 4u : allow_lockstep;
+         const TmGeometry geo = time_major_geometry(n_streams, cap, g.n_ops > 30, !g.typed);
+         v.P = geo.P;
+         v.U = geo.U;
+         v.block = geo.lanes;
+         v.flags |= FZ_VF_LOCKSTEP | (geo.U == 1 ? (uint32_t)FZ_VF_PREFETCH3 : 0u);
+         // (blocks of a few rows are not worth zeroing the counters for)
+         if (n_samples >= 64) v.flags |= FZ_VF_GRID_SYNC;
+         if (v.P == 1 && g.split.ok && n_samples >= 16u * (g.split.atoms() - 1)) {
+            v.flags |= FZ_VF_STAGE_PACK;
+            v.flags &= ~(uint32_t)FZ_VF_PREFETCH3;
+            v.U = std::max(v.U, 4u);
+         }
+         return v;
+      }
    }
    // deep graphs: keep the register-resident delay lines + prefetch buffers inside the 512-entry
    // VGPR/AGPR file (measured: a 24-stage cascade needs ~300 VGPRs at 2 streams per lane)
@@ -232,43 +329,22 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       return v;
    }
    const bool plain_auto = !reqP && !reqU && !reqB && !(v.flags & ~(uint32_t)FZ_VF_OUT_F64);   // nothing asked for: the library's choice
-   // PLAIN TIME-MAJOR frames of many streams (round 3): consecutive rows are n_streams * wires * 4 bytes apart -- megabytes,
-   // i.e. every row a wave has in flight is another 2 MiB page, and waves that drift apart in time multiply the pages a CU
-   // touches (160 x the L1-TLB misses of tiled frames, profiles/r01/pmc_tlb_tiled_vs_timemajor.txt).  So the whole CU walks
-   // the rows together: ONE workgroup of 1024 lanes per CU that meets at a barrier after every chunk (FZ_VF_LOCKSTEP), few
-   // rows in flight per lane, and its sixteen waves read one contiguous 8-16 KiB piece of each row.  Measured on three boards,
-   // 6-biquad cascade, 1 M streams x 4096: 6.06 / 6.06 / 6.85 ms against 6.43 / 6.49 / 7.02 ms for four-wave workgroups that
-   // run free (0.71 / 0.71 / 0.63 of peak against 0.67 / 0.66 / 0.61); 262 144 streams: 1.53 ms against 1.79 ms
-   // (gpurun_out/r03a-c -> profiles/r03/sweep_time_major_lockstep.txt).  Needs >= 256 such workgroups (else CUs idle: 4 streams
-   // per lane at 262 144 streams ran 2.2 x slower), narrow frames (4-wire frames gain nothing: their rows are wide already)
-   // and a graph whose registers fit the 128 a lane of a 1024-lane workgroup gets (fz_finalize_variant falls back otherwise).
-   if (allow_lockstep && plain_auto && !tile_streams && n_streams >= (1u << 18) && g.n_in <= 2 && g.n_out <= 2 && g.far_lines.empty() &&
-       g.n_lds_slots == 0 && !(v.flags & FZ_VF_STAGE_PACK)) {
-      // streams per lane: as many as still give 256 workgroups (a CU's piece of a row: 16 / 8 / 4 KiB), fewer rows in flight
-      // the wider the lane -- four streams per lane: one row per buffer and three buffers (the loads run two rows ahead):
-      // 0.72 / 0.69 of peak against 0.71 / 0.64 for two streams per lane on the two boards that ran both.  allow_lockstep
-      // caps the packing: fz_finalize_variant steps down when the kernel does not fit the 128 registers of a lane.
-      uint32_t P = (n_streams >= (1u << 20) && n_streams % 4 == 0) ? 4 : (n_streams >= (1u << 19) && n_streams % 2 == 0) ? 2 : 1;
-      P = std::min(P, allow_lockstep >= 3 ? 4u : allow_lockstep);
-      if (P == 3) P = 2;
-      v.P = P;
-      v.U = P == 4 ? 1 : P == 2 ? 2 : 4;
-      v.block = 1024;
-      v.flags |= FZ_VF_LOCKSTEP | (P == 4 ? (uint32_t)FZ_VF_PREFETCH3 : 0u);
-      // ... and the workgroups of an XCD walk the rows together too (FZ_VF_GRID_SYNC: a persistent launch, see the kernel
-      // source): 1 M streams 5.43-5.60 ms against 6.09-6.25 ms without (0.77-0.79 of peak: faster than stream tiles on the same
-      // boards), 524 288 streams 2.74 against 3.16 ms, 262 144 streams 1.58 against 1.84 ms
-      // (gpurun_out/r03n -> profiles/r03/sweep_time_major_grid_sync.txt)
-      // (blocks of a few rows are not worth zeroing the counters for)
-      if (n_samples >= 64) v.flags |= FZ_VF_GRID_SYNC;
-      return v;
-   }
    // stream-tiled frames, packed lanes, chip oversubscribed: two workgroups per CU (262 144 streams in flight keep fewer tiles
    // open in DRAM: +2 % on the boards of round 3, level on those of round 2; profiles/r01/sweep_occupancy_cap.txt)
    if (plain_auto && tile_streams && v.P == 2 && n_streams >= (1u << 19) && !g.n_lds_slots) v.flags |= FZ_VF_MAX_WG(2);
    if (g.n_lds_slots) {
       // LDS rings: slots * block * 4P bytes must fit the CU's 160 KiB of LDS (one workgroup may take it all)
       auto bytes = [&](const Variant& w) { return (uint64_t)g.n_lds_slots * w.block * 4u * w.P; };
+      // Every step of such a graph waits for its ring reads (~64+ cycles each), so what counts is how many waves a CU holds, and
+      // the rings decide that: one stream per lane (a wave's rings are half the size) in small workgroups (a quarter of the LDS
+      // at most: the CU's waves come and go in finer steps) -- the two combs of 40 and 23 samples at 1 M streams: 0.64 of peak
+      // with 128-lane workgroups of one stream per lane against 0.60 for the two-streams-per-lane default before
+      // (profiles/r04/sweep_next_rows.txt)
+      if (!reqP && !reqB) {
+         v.P = 1;
+         v.block = 128;
+         while (bytes(v) > kMaxLdsBytes / 4 && v.block > 64) v.block /= 2;
+      }
       while (bytes(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
       while (bytes(v) > kMaxLdsBytes && !reqP && v.P > 1) v.P /= 2;
       if (bytes(v) > kMaxLdsBytes)
@@ -276,6 +352,14 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
                                    std::to_string(g.n_lds_slots) + " slots)");
    }
    return v;
+}
+
+// the streams the (first) lockstep launch of a block covers: all of them -- except for the library's own choice on plain time-major
+// frames when time_major_geometry peels a remainder off the end (its launch runs the few-stream kernels)
+uint64_t lockstep_streams(const Graph& g, const fz_variant* uv, const Variant& v, uint64_t n_streams)
+{
+   if (uv_has_shape(uv) || !(v.flags & FZ_VF_LOCKSTEP)) return n_streams;
+   return time_major_geometry(n_streams, v.P, g.n_ops > 30, !g.typed).main_streams;
 }
 
 // The kernel a launch of this shape runs: the variant resolved for the layout, fitted to the tile size and the 4 GiB chunk limit,
@@ -309,9 +393,11 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
       // XCD-wide synchronisation needs every workgroup running: with more blocks than the chip holds workgroups the launch path
       // cuts the block into laps, one launch each (fz_launch.cpp).  FLOWZ_HIP_LAPS=kernel keeps round 3's alternative for
       // comparison: ONE persistent launch whose workgroups loop over the laps (FZ_VF_PERSIST, a kernel of its own)
+      v.flags &= ~FZ_VF_RAGGED;
+      if ((v.flags & FZ_VF_LOCKSTEP) && !tile_streams && !stream_major && lockstep_streams(p->g, uv, v, n_streams) % v.P) v.flags |= FZ_VF_RAGGED;
       static const bool kernel_laps = [] { const char* e = std::getenv("FLOWZ_HIP_LAPS"); return e && std::strcmp(e, "kernel") == 0; }();
       v.flags &= ~FZ_VF_PERSIST;
-      if (kernel_laps && (v.flags & FZ_VF_GRID_SYNC) && (n_streams / v.P + v.block - 1) / v.block > chip_cus()) v.flags |= FZ_VF_PERSIST;
+      if (kernel_laps && (v.flags & FZ_VF_GRID_SYNC) && ((n_streams + v.P - 1) / v.P + v.block - 1) / v.block > chip_cus()) v.flags |= FZ_VF_PERSIST;
       return settle ? settle_variant(p, v) : v;
    };
    const Variant want = resolve_variant(g, uv, n_streams, n_samples, tile_streams);
@@ -324,6 +410,18 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
       for (uint32_t level = want.P; level > 0;) {
          const auto k = get_kernel(p, v, nullptr);
          if (k->res.scratch_bytes == 0 && v.U >= w.U) break;
+         // before giving up streams per lane: the same packing with ONE row per chunk buffer and three buffers needs fewer
+         // registers than chunks of two or four rows (the oscillator chain, two streams per lane, 1024 lanes: 114 against 128 + spills)
+         if (w.U > 1 && !(w.flags & FZ_VF_STAGE_PACK)) {
+            Variant one = w;
+            one.U = 1;
+            one.flags |= FZ_VF_PREFETCH3;
+            const Variant f1 = fit(one);
+            if (f1.U == 1 && get_kernel(p, f1, nullptr)->res.scratch_bytes == 0) {
+               v = f1;
+               break;
+            }
+         }
          level = level == 4 ? 2 : level - 1;
          w = resolve_variant(g, uv, n_streams, n_samples, tile_streams, level);
          v = fit(w);
@@ -400,6 +498,10 @@ static bool plan_load(const fz_program* p, uint64_t n_streams, uint32_t tile, fz
       if (std::sscanf(ln.c_str(), "%15s %llx %llu %u %63s %u %u %u %u %f %u", tag, &h, &ns, &t, idbuf, &P, &U, &B, &fl, &ms, &T) != 11) continue;
       if (std::strcmp(tag, kPlanTag) != 0 || h != p->graph_hash || ns != n_streams || t != tile || id != idbuf) continue;
       if ((P != 0 && P != 1 && P != 2 && P != 4) || U > 128 || B > 1024 || (B % 64)) continue;   // (a damaged line)
+      // only what tune_candidates can emit: a stale or damaged line must not turn a default launch into another LAYOUT or output type
+      // (FZ_VF_STREAM_MAJOR / FZ_VF_OUT_F64 would write past a float32 time-major `out`)
+      constexpr unsigned kPlanFlags = FZ_VF_STAGE_PACK | FZ_VF_WAVE_SPLIT | FZ_VF_WAVE_SPLIT3 | FZ_VF_IO_WAVE | FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC | FZ_VF_PREFETCH3 | FZ_VF_MAX_WG(7);
+      if (fl & ~kPlanFlags) continue;
       *out = fz_variant{P, U, B, fl};
       found = true;
    }
@@ -462,16 +564,22 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
       cands.push_back(fz_variant{1, 32, 0, FZ_VF_STAGE_PACK});
       // (the single stage-packed wave per SIMD with XCD-wide synchronisation was measured and LOSES 8 % at 65 536 streams -- 0.62
       //  against 0.67 of peak, gpurun_out/r03r: not a candidate)
-   } else if (d.flags & FZ_VF_LOCKSTEP) {   // plain time-major frames, many streams: the CU-wide workgroups in lockstep against four-wave workgroups running free
+   } else if (d.flags & FZ_VF_LOCKSTEP) {   // plain time-major frames, many streams: the walk in lockstep against its neighbours in the geometry table
       const uint32_t G = d.flags & FZ_VF_GRID_SYNC;
-      cands.push_back(fz_variant{std::min(d.P, 2u), 16, 256, 0});
-      if (G) cands.push_back(fz_variant{d.P, d.U, 1024, (d.flags & ~(uint32_t)FZ_VF_GRID_SYNC)});   // the same without the XCD-wide synchronisation
-      if (d.P == 4) cands.push_back(fz_variant{2, 2, 1024, FZ_VF_LOCKSTEP | G});
-      if (d.P >= 2) cands.push_back(fz_variant{2, 8, 1024, FZ_VF_LOCKSTEP});
-      if (d.P >= 2) cands.push_back(fz_variant{4, 8, 512, FZ_VF_LOCKSTEP});
-      if (d.P >= 2) cands.push_back(fz_variant{1, 8, 1024, FZ_VF_LOCKSTEP});
-      if (d.P == 1) cands.push_back(fz_variant{1, 16, 1024, FZ_VF_LOCKSTEP});
-      if (d.P == 1) cands.push_back(fz_variant{1, 4, 1024, FZ_VF_LOCKSTEP});
+      cands.push_back(fz_variant{std::min(d.P, 2u), 16, 256, 0});                                  // four-wave workgroups running free
+      if (G) cands.push_back(fz_variant{d.P, d.U, d.block, (d.flags & ~(uint32_t)FZ_VF_GRID_SYNC)});   // the same without the XCD-wide synchronisation
+      if (!(d.flags & FZ_VF_STAGE_PACK)) {
+         for (uint32_t P : {d.P * 2, d.P / 2}) {                                                    // the next packing up and down, each at its own geometry
+            if (P < 1 || P > 4 || n_streams % P) continue;
+            const TmGeometry o = time_major_geometry(n_streams, P, g.n_ops > 30, false, P);
+            if (o.P != P || o.main_streams != n_streams) continue;
+            cands.push_back(fz_variant{P, o.U, o.lanes, FZ_VF_LOCKSTEP | G | (o.U == 1 ? (uint32_t)FZ_VF_PREFETCH3 : 0u)});
+         }
+         if (d.U > 1) cands.push_back(fz_variant{d.P, 1, d.block, FZ_VF_LOCKSTEP | G | FZ_VF_PREFETCH3});   // one row per buffer, three buffers
+         else if (d.P * d.block * 4u < 16384u) cands.push_back(fz_variant{d.P, 2, d.block, FZ_VF_LOCKSTEP | G});
+      }
+      if (g.split.ok && n_samples >= 16u * (g.split.atoms() - 1) && !(d.flags & FZ_VF_STAGE_PACK))
+         cands.push_back(fz_variant{1, 4, 1024, FZ_VF_LOCKSTEP | G | FZ_VF_STAGE_PACK});           // one stream per lane, packed by stages (register-heavy graphs)
    } else if (d.P == 2) {            // many streams, narrow frames: lane packing x prefetch depth x workgroups per CU
       cands.push_back(fz_variant{2, 16, 256, (d.flags & FZ_VF_MAX_WG(7)) ? 0u : FZ_VF_MAX_WG(2)});
       // CU-wide workgroups in lockstep, XCD-wide synchronised (the time-major default): +2 % on tiled frames on one board
@@ -543,8 +651,10 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
          const size_t c = pass == 0 ? k : cands.size() - 1 - k;
          if (pass == 1 && reps_of[c] == 0) continue;
          try {
+            // (implicit: a candidate takes part only when every kernel its resolution touches -- the variant itself and whatever a
+            //  spilling one settles down to -- is in memory or in the on-disk cache; nothing is built for the measurement)
+            NoJitScope no_jit(implicit && c != 0);
             if (pass == 0) {
-               if (implicit && c != 0 && !kernel_at_hand(p, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams, false))) continue;
                // (a candidate that would run from scratch memory even with its unroll lowered -- a 1024-lane lockstep workgroup of a
                //  register-heavy graph -- is not measured: no kernel of this library runs from scratch, see DESIGN "Register budget")
                if (c != 0 && get_kernel(p, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams), nullptr)->res.scratch_bytes != 0) continue;
@@ -566,11 +676,14 @@ int tune(fz_program* p, const float* in, float* out, float* state, const float* 
                             kernel_name(g, finalize_variant(p, &cands[c], n_streams, n_samples, tile_streams)).c_str(), (unsigned long long)n_streams,
                             tile_streams, cands[c].streams_per_lane, cands[c].unroll, cands[c].block_threads, cands[c].flags, ms, pass + 1);
          } catch (const Error& er) {                          // a candidate this graph / shape does not allow
-            if (er.code == FZ_E_HIP || er.code == FZ_E_NO_DEVICE) {
+            // a HIP error (no memory for a candidate's arrival counters ...) takes the measurement down only when it is the
+            // DEFAULT that failed: the caller's launch would fail the same way.  Any other candidate is skipped.
+            if ((er.code == FZ_E_HIP && c == 0) || er.code == FZ_E_NO_DEVICE) {
                (void)hipEventDestroy(e0);
                (void)hipEventDestroy(e1);
                throw;
             }
+            if (er.code == FZ_E_HIP) (void)hipGetLastError();
             reps_of[c] = 0;
             if (first_error.empty()) first_error = er.msg;
          }
