@@ -42,3 +42,16 @@ def test_cpp_block_api_routes_agree_on_gpu():
     out = subprocess.run([build("test_block_api_gpu", ("-L/opt/rocm/lib", "-lamdhip64"))], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all block API checks passed" in out.stdout
+
+
+def test_cpp_two_devices_compiles():
+    build("test_two_devices_gpu", ("-L/opt/rocm/lib", "-lamdhip64", "-pthread"))
+
+
+@pytest.mark.gpu
+def test_cpp_shards_on_several_devices_from_one_process():
+    """SURVEY 8e from ONE host process: contiguous stream shards, a host thread + hipSetDevice + bank + stream per shard, the
+    compiled program shared; every shard equals the single-device result.  On a one-GPU box both threads share device 0."""
+    out = subprocess.run([build("test_two_devices_gpu", ("-L/opt/rocm/lib", "-lamdhip64", "-pthread"))], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all multi-device checks passed" in out.stdout

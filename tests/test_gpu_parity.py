@@ -1628,7 +1628,7 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     # a register-heavy graph steps down: the oscillator chain (31 per-stream coefficients) runs two streams per lane with one row per
     # chunk buffer (114 registers); a graph that ends at one stream per lane runs stage-packed there
     assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p2u1b1024f%d" % (LG | _capi.FZ_VF_PREFETCH3)
-    assert F.compile(F.from_sexpr(G.osc_chain(12))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s12f%d" % (LG | _capi.FZ_VF_STAGE_PACK)
+    assert F.compile(F.from_sexpr(G.osc_chain(8))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s8f%d" % (LG | _capi.FZ_VF_STAGE_PACK)
     assert F.compile(F.from_sexpr(G.par4_sum())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u32b256f0"
     # more blocks than the chip holds workgroups (300 of 1024 lanes): two laps, a launch each with counters of its own
     ns, T = 300 * 1024 + 64, 40
@@ -1637,10 +1637,11 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     yg, stg = prog.run_block(x, variant=F.make_variant(1, 4, 1024, LG))
     y0, st0 = prog.run_block(x, variant=F.make_variant(2, 16, 256))
     assert torch.equal(yg, y0) and torch.equal(stg, st0)
-    ns, T = (1 << 18) + 8, 24                                   # ragged on purpose
+    monkeypatch.setenv("FLOWZ_HIP_AUTOTUNE", "0")
+    ns, T = (1 << 18) + 8, 300                                  # ragged on purpose (whole laps + a remainder launch of 8 streams)
     x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
     F.synth_fill(x, SEED + 33)
-    y, st = prog.run_block(x)                                   # (too small a block for the first-launch measurement)
+    y, st = prog.run_block(x)
     y0, st0 = prog.run_block(x, variant=F.make_variant(2, 16, 256))
     assert torch.equal(y, y0) and torch.equal(st, st0)
     ids = np.array([0, 1, 63, 64, 1023, 1024, ns - 1])
@@ -1686,13 +1687,14 @@ def test_time_major_laps_remainders_and_ragged_defaults(torch_cuda, F, ns, monke
     (the first, the last, both sides of the main / remainder seam) against the oracle."""
     torch = torch_cuda
     monkeypatch.setenv("FLOWZ_HIP_NO_PLAN_CACHE", "1")
+    monkeypatch.setenv("FLOWZ_HIP_AUTOTUNE", "0")               # the library's static choice is what is under test
     for g, with_params in ((G.df1_cascade(6), False), (G.osc_chain(6), True)):
         prog = F.compile(F.from_sexpr(g))
-        T = 24 if ns > (1 << 20) else 72
+        T = 256 + 7                                              # (the walk in lockstep is the library's choice from 256 rows on)
         x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
         F.synth_fill(x, SEED + 140)
         pd = torch.from_numpy(W.osc_chain_params(SEED + 141, np.arange(ns))).cuda() if with_params else None
-        y, st = prog.run_block(x, params=pd)                     # (too small a block for the first-launch measurement)
+        y, st = prog.run_block(x, params=pd)
         y0, st0 = prog.run_block(x, params=pd, variant=F.make_variant(1, 16, 256, NO_STAGE_PACK))
         assert torch.equal(y, y0) and torch.equal(st, st0), (ns, with_params)
         seam = (ns // (1 << 18)) * (1 << 18)

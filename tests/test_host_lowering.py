@@ -573,7 +573,7 @@ def test_time_major_geometry_follows_the_cu_count():
     # a register-heavy graph steps down: the oscillator chain (31 per-stream coefficients) runs two streams per lane with one row per
     # chunk buffer (114 registers); a graph that ends at one stream per lane runs stage-packed there
     assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p2u1b1024f%d" % (L | GS | P3)
-    assert F.compile(F.from_sexpr(G.osc_chain(12))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s12f%d" % (L | GS | F.C.FZ_VF_STAGE_PACK)
+    assert F.compile(F.from_sexpr(G.osc_chain(8))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s8f%d" % (L | GS | F.C.FZ_VF_STAGE_PACK)
 
 
 def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorphic_halves():

@@ -209,6 +209,14 @@ struct Kernel {
 
 }  // namespace fz
 
+namespace fz {
+struct SideStream {        // hipStream_t / hipEvent_t, opaque here
+   void* stream = nullptr;
+   void* fork = nullptr;
+   void* join = nullptr;
+};
+}  // namespace fz
+
 struct fz_program {
    fz::Graph g;
    std::mutex mu;
@@ -226,6 +234,7 @@ struct fz_program {
    std::map<int, std::pair<void*, size_t>> sync_dev;              // device -> (buffer, bytes per slice)
    std::vector<void*> sync_retired;                                // counter buffers that were outgrown: a captured hipGraph may still use them
    uint32_t sync_next = 0;
+   std::map<int, fz::SideStream> side;                             // device -> side stream for remainder launches next to the laps (fz_launch.cpp)
    const float* mod_dev = nullptr;                                 // fz_program_set_modulation
    uint32_t mod_stride = 0;
    ~fz_program();                                                  // frees the counters (fz_launch.cpp)

@@ -13,6 +13,11 @@ fz_program::~fz_program()
    for (auto& kv : sync_dev)
       if (kv.second.first) (void)hipFree(kv.second.first);   // (hipFree waits for whatever still runs on the device)
    for (void* q : sync_retired) (void)hipFree(q);
+   for (auto& kv : side) {
+      if (kv.second.stream) (void)hipStreamDestroy((hipStream_t)kv.second.stream);
+      if (kv.second.fork) (void)hipEventDestroy((hipEvent_t)kv.second.fork);
+      if (kv.second.join) (void)hipEventDestroy((hipEvent_t)kv.second.join);
+   }
 }
 
 namespace fz {
@@ -106,6 +111,26 @@ struct ArgsHeader {
    unsigned int group0;
    unsigned int reserved0;
 };
+// the program's side stream on the current device and the two events that fork it from / join it to a caller's stream (created on
+// first use, destroyed with the program; the calls that use them are made under no lock: event record / wait take the state of the
+// moment, so launches of several host threads may share them)
+static SideStream side_stream(fz_program* p)
+{
+   int dev = 0;
+   FZ_HIP(hipGetDevice(&dev));
+   std::lock_guard<std::mutex> lock(p->mu);
+   SideStream& s = p->side[dev];
+   if (!s.stream) {
+      hipStream_t st;
+      hipEvent_t a, b;
+      FZ_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      FZ_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+      FZ_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+      s = SideStream{st, a, b};
+   }
+   return s;
+}
+
 static_assert(sizeof(ArgsHeader) % 8 == 0 && sizeof(ArgsHeader) == 6 * 8 + 8 + 10 * 4, "ArgsHeader must match the head of the kernel's fz_args without padding");
 
 int launch(fz_program* p, const float* in, float* out, float* state, const float* params, uint64_t n_streams,
@@ -169,7 +194,8 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       // caller's buffers (the state is saved and restored around it, `out` is recomputed below), takes the candidates whose
       // code objects are at hand (build() pre-builds them for the BASELINE graphs; nothing is JIT-compiled for it) and
       // costs about ten launches each; blocks below 2^26 stream-samples (a few hundred microseconds) never trigger it.
-      static const bool autotune = [] { const char* e = std::getenv("FLOWZ_HIP_AUTOTUNE"); return !(e && *e == '0'); }();
+      const char* const at_env = std::getenv("FLOWZ_HIP_AUTOTUNE");      // (read at every launch: a process may turn it off for some of its work)
+      const bool autotune = !(at_env && *at_env == '0');
       bool can_tune = autotune && !known && rows_total == n_samples && row0 == 0 && n_streams * (uint64_t)n_samples >= (1ull << 26);
       if (can_tune) {
          // not while the stream is being captured into a hipGraph (the measurement allocates and synchronises), and not
@@ -293,7 +319,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
 
    // One kernel variant over the streams [first, first + count) of the block (the pointers and the row pitch stay the block's:
    // the kernel adds the first stream group itself).
-   auto run_part = [&](const Variant& w, uint64_t first, uint64_t count) {
+   auto run_part = [&](const Variant& w, uint64_t first, uint64_t count, void* stream) {
       void* fn = nullptr;
       auto k = get_kernel(p, w, &fn);
       const unsigned group0 = (unsigned)(first / w.P);
@@ -344,15 +370,30 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    // the library's own lockstep choice may cover whole laps only and leave the last few streams to a launch of their own
    // (time_major_geometry): those run what a block of that few streams runs by itself
    const uint64_t main_streams = stream_major ? n_streams : lockstep_streams(g, uv, v, n_streams);
-   run_part(v, 0, main_streams);
-   if (main_streams < n_streams) {
-      const uint64_t rem = n_streams - main_streams;
-      Variant r = resolve_variant(g, nullptr, rem, n_samples, 0, 0);
-      // (never the grid-synchronised walk for the few: allow_lockstep = 0 above; a spilling kernel steps down as always)
-      while ((uint64_t)row_streams * std::max(wmax, out_w) * 4u * r.U >= (1ull << 32) && r.U > (ws_parts(r.flags) ? 8u : 1u)) r.U /= 2;   // (a chunk of U rows: one 4 GiB descriptor)
-      r = settle_variant(p, r);
-      run_part(r, main_streams, rem);
+   if (main_streams == n_streams) {
+      run_part(v, 0, n_streams, stream);
+      return FZ_OK;
    }
+   // The remainder runs NEXT TO the laps, not behind them: on a side stream of the program, forked from and joined to the caller's
+   // stream by events (capturable like any fork / join).  Its few waves walk all the rows of the block on their own -- every row
+   // another page, ~1.4 ms per 4096 rows for ONE stream behind a million (measured: 7.07 ms for 1 048 577 streams against 5.62 ms for
+   // 1 048 576 when it ran behind the lap) -- and the lap's workgroups leave room for them (92 of a SIMD's 128 registers per lane).
+   const uint64_t rem = n_streams - main_streams;
+   // one-wave workgroups of the ordinary frame kernel, one stream per lane, stage-packed where the graph allows: ~100 registers per
+   // lane, so that a wave of it fits a SIMD NEXT TO the four of a lap's workgroup (a fatter kernel would keep a lap's workgroup off
+   // its CU until the remainder is done); a spilling kernel steps down as always
+   const bool sp_ok = g.split.ok && n_samples >= 16u * (g.split.atoms() - 1);
+   const fz_variant rq{1, 16, 64, (sp_ok ? (uint32_t)FZ_VF_STAGE_PACK : (uint32_t)FZ_VF_NO_STAGE_PACK) | (uv ? (uv->flags & FZ_VF_OUT_F64) : 0u)};
+   Variant r = resolve_variant(g, &rq, rem, n_samples, 0, 0);
+   while ((uint64_t)row_streams * std::max(wmax, out_w) * 4u * r.U >= (1ull << 32) && r.U > (ws_parts(r.flags) ? 8u : 1u)) r.U /= 2;   // (a chunk of U rows: one 4 GiB descriptor)
+   r = settle_variant(p, r);
+   SideStream side = side_stream(p);
+   FZ_HIP(hipEventRecord((hipEvent_t)side.fork, (hipStream_t)stream));
+   FZ_HIP(hipStreamWaitEvent((hipStream_t)side.stream, (hipEvent_t)side.fork, 0));
+   run_part(r, main_streams, rem, side.stream);
+   FZ_HIP(hipEventRecord((hipEvent_t)side.join, (hipStream_t)side.stream));
+   run_part(v, 0, main_streams, stream);
+   FZ_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)side.join, 0));
    return FZ_OK;
 }
 

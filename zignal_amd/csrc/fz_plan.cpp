@@ -15,6 +15,7 @@ namespace fz {
 
 // ---- variant selection ---------------------------------------------------------------------------------
 constexpr uint64_t kMaxLdsBytes = 160 * 1024;
+constexpr uint32_t kLockstepMinRows = 256;
 
 // tile_streams: the frame layout the variant is for -- 0 (or >= n_streams) plain time-major rows, else stream tiles (stream-major
 // frames are named by FZ_VF_STREAM_MAJOR in the variant's flags).  allow_lockstep: see the time-major rule below.
@@ -157,7 +158,9 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    // buffers are range-checked per dword, tools/oob_probe.hip), and rows that are only 4-byte aligned are fine for b64 / b128.
    {
       const bool nothing_asked = !reqP && !reqU && !reqB && !(v.flags & ~(uint32_t)FZ_VF_OUT_F64);
-      if (allow_lockstep && nothing_asked && !tile_streams && n_streams >= (uint64_t)chip_cus() * 1024u && g.n_in <= 2 && g.n_out <= 2 &&
+      // (blocks of a few dozen rows -- control-rate windows -- run free: the walk in step needs a few hundred rows to pay for its
+      //  start: 64-sample windows of 1 M streams 0.73 of peak free-running against 0.56-0.63 in lockstep, profiles/r04/sweep_next_rows.txt)
+      if (allow_lockstep && nothing_asked && !tile_streams && n_samples >= kLockstepMinRows && n_streams >= (uint64_t)chip_cus() * 1024u && g.n_in <= 2 && g.n_out <= 2 &&
           g.far_lines.empty() && g.n_lds_slots == 0 && !(g.typed && (n_streams % 4))) {
          const uint32_t cap = allow_lockstep >= 3 ? 4u : allow_lockstep;
          const TmGeometry geo = time_major_geometry(n_streams, cap, g.n_ops > 30, !g.typed);
@@ -165,8 +168,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
          v.U = geo.U;
          v.block = geo.lanes;
          v.flags |= FZ_VF_LOCKSTEP | (geo.U == 1 ? (uint32_t)FZ_VF_PREFETCH3 : 0u);
-         // (blocks of a few rows are not worth zeroing the counters for)
-         if (n_samples >= 64) v.flags |= FZ_VF_GRID_SYNC;
+         v.flags |= FZ_VF_GRID_SYNC;
          if (v.P == 1 && g.split.ok && n_samples >= 16u * (g.split.atoms() - 1)) {
             v.flags |= FZ_VF_STAGE_PACK;
             v.flags &= ~(uint32_t)FZ_VF_PREFETCH3;
