@@ -253,6 +253,12 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
        FZ_VF_GRID_SYNC = 8388608u, /* with FZ_VF_LOCKSTEP: the workgroups of one XCD (one contiguous 1/8 of every row) also walk the rows together:
                                    arrival counters in device memory (zeroed in stream order before the launch), bounded waits -- never a
                                    hang, never a different bit; chosen automatically when the chip holds all workgroups at once      */
+       FZ_VF_CROSS_PAIR = 16777216u, /* with FZ_VF_WAVES(W) and FZ_VF_IO_WAVE, a chain of exactly 2 W isomorphic segments: wave w evaluates segments w AND
+                                   w + W as one packed pair (every node one v_pk_* instruction), so that every hand-off between waves carries a
+                                   whole register pair -- ring entries of two steps x (low, high), read and written with one b128 LDS access
+                                   per two steps, no pack / unpack moves: 10 instructions per step and wave where the split into consecutive
+                                   stages issues 12.8.  The samples travel twice round the ring of waves (low halves, then high halves).
+                                   Chosen automatically for few streams where the graph allows it                                       */
        FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
                                    float*): the results of graphs with double literals leave un-narrowed, float
                                    wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */

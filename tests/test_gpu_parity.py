@@ -719,6 +719,60 @@ def test_wave_split_kernel_vs_oracle(torch_cuda, F, name, T):
     assert tried >= 8
 
 
+CROSSABLE = {
+    "cascade4": (lambda: G.df1_cascade(4), 2),
+    "cascade6": (lambda: G.df1_cascade(6), 3),
+    "cascade8": (lambda: G.df1_cascade(8), 4),
+    "cascade6_distinct_coeffs": (lambda: G.df1_cascade(6, [G.STABLE, G.PAR4_SETS[0], G.PAR4_SETS[1], G.PAR4_SETS[2], G.PAR4_SETS[3], G.STABLE]), 3),
+    "df2_x4": (lambda: G.seq(G.seq(G.df2(*G.STABLE), G.df2(*G.PAR4_SETS[3])), G.seq(G.df2(*G.PAR4_SETS[1]), G.df2(*G.STABLE))), 2),
+    "cascade12_two_stages_per_segment": (lambda: G.df1_cascade(12), 3),
+}
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 5, 13, 16, 17, 33, 40, 64, 101, 300, 1000])
+@pytest.mark.parametrize("name", sorted(CROSSABLE))
+def test_cross_paired_wave_split_vs_oracle(torch_cuda, F, name, T):
+    """FZ_VF_CROSS_PAIR (round 4): wave w of a tuple evaluates segments w and w + W of a chain of 2 W as one packed pair; every hand-off
+    between waves is a register pair, a sample travels twice round the ring of waves.  Every block length (blocks shorter than the
+    pipeline, blocks that end inside a round, many rounds), ragged stream counts, unroll 8 / 16 / 32, one to four tuples per workgroup
+    -- outputs and the canonical state against the oracle / the plain kernel; two chained blocks across variants."""
+    mk, W = CROSSABLE[name]
+    g = mk()
+    prog = F.compile(F.from_sexpr(g))
+    ns = 133 if T < 1000 else 300
+    x = O.synth_input(SEED + 55, np.arange(ns), T)
+    want = O.compile(g, ns).run(x)
+    ref, st_ref = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+    assert ndiff(ref, want) == 0
+    fl = F.C.FZ_VF_WAVES(W) | F.C.FZ_VF_IO_WAVE | F.C.FZ_VF_CROSS_PAIR
+    assert "x" in prog.kernel_name(F.make_variant(1, 16, 0, fl), ns, T).split("w")[-1]
+    for U, B in ((8, 64), (16, 128), (32, 64), (16, 64), (8, 192)):
+        if B * (W + 1) > 1024:
+            continue
+        got, st = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, U, B, fl))
+        assert ndiff(got, want) == 0, (name, T, U, B)
+        assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0, (name, T, U, B)
+    if T >= 5:
+        k = T // 3 + 1
+        a, st1 = run_gpu(torch_cuda, F, prog, x[:k], variant=F.make_variant(1, 16, 64, fl))
+        b, st2 = run_gpu(torch_cuda, F, prog, x[k:], variant=F.make_variant(1, 8, 256, NO_STAGE_PACK), state=st1)
+        assert ndiff(np.concatenate([a, b]), want) == 0
+        a, st1 = run_gpu(torch_cuda, F, prog, x[:k], variant=F.make_variant(2, 8, 64))
+        b, st2 = run_gpu(torch_cuda, F, prog, x[k:], variant=F.make_variant(1, 16, 128, fl), state=st1)
+        assert ndiff(np.concatenate([a, b]), want) == 0 and ndiff(st2.cpu().numpy(), st_ref.cpu().numpy()) == 0
+
+
+def test_cross_pairing_refuses_what_it_cannot_do(torch_cuda, F):
+    fl3 = F.C.FZ_VF_WAVES(3) | F.C.FZ_VF_IO_WAVE | F.C.FZ_VF_CROSS_PAIR
+    x = torch_cuda.zeros((64, 128, 1), device="cuda")
+    for g, fl in ((G.df1_cascade(4), fl3),                                                        # four segments are two pairs, not three
+                  (G.df1_cascade(6), F.C.FZ_VF_WAVES(3) | F.C.FZ_VF_CROSS_PAIR),                   # no I/O wave
+                  (G.df1_cascade(7), fl3),                                                        # a scalar prefix stage
+                  (G.osc_chain(6), fl3)):
+        with pytest.raises(F.FlowzError):
+            F.compile(F.from_sexpr(g)).run_block(x, variant=F.make_variant(1, 16, 0, fl))
+
+
 @pytest.mark.parametrize("T", [1, 7, 64, 101, 300])
 @pytest.mark.parametrize("name", sorted(PACKABLE))
 def test_io_wave_kernel_vs_oracle(torch_cuda, F, name, T):
@@ -1638,7 +1692,7 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     y0, st0 = prog.run_block(x, variant=F.make_variant(2, 16, 256))
     assert torch.equal(yg, y0) and torch.equal(stg, st0)
     monkeypatch.setenv("FLOWZ_HIP_AUTOTUNE", "0")
-    ns, T = (1 << 18) + 8, 300                                  # ragged on purpose (whole laps + a remainder launch of 8 streams)
+    ns, T = (1 << 18) + 8, 1030                                 # ragged on purpose (whole laps + a remainder launch of 8 streams)
     x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
     F.synth_fill(x, SEED + 33)
     y, st = prog.run_block(x)
@@ -1690,7 +1744,7 @@ def test_time_major_laps_remainders_and_ragged_defaults(torch_cuda, F, ns, monke
     monkeypatch.setenv("FLOWZ_HIP_AUTOTUNE", "0")               # the library's static choice is what is under test
     for g, with_params in ((G.df1_cascade(6), False), (G.osc_chain(6), True)):
         prog = F.compile(F.from_sexpr(g))
-        T = 256 + 7                                              # (the walk in lockstep is the library's choice from 256 rows on)
+        T = 1024 + 7                                             # (the walk in lockstep is the library's choice from 1024 rows on)
         x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
         F.synth_fill(x, SEED + 140)
         pd = torch.from_numpy(W.osc_chain_params(SEED + 141, np.arange(ns))).cuda() if with_params else None

@@ -131,11 +131,17 @@ struct Graph {
    // W = 2, 3, 4; empty when the graph does not allow it.
    std::vector<std::vector<Graph>> wave_splits;
    // (W = 1: the graph itself, when it is stage-packable -- the compute wave next to an I/O wave)
+   std::vector<std::vector<StageSplit>> cross_splits;   // FZ_VF_CROSS_PAIR: cross_splits[W] = the W packed pairs (segments w, w + W), W = 2, 3, 4
+   const std::vector<StageSplit>* cross_parts(uint32_t W) const { return W < cross_splits.size() && cross_splits[W].size() == W ? &cross_splits[W] : nullptr; }
    const std::vector<Graph>* wave_roles(uint32_t W) const { return W && W < wave_splits.size() && wave_splits[W].size() == W ? &wave_splits[W] : nullptr; }
 };
 
 // max_atoms: upper bound for K * m (the wave-split hand-offs and the long-run stream-major body bound the total skew)
-StageSplit find_stage_split(const Graph& g, bool plain = false, uint32_t divisor = 0, uint32_t max_atoms = 13);
+// force_atoms: cut every segment into atoms even when the chain has three or more packed pairs (a wave that carries ONE pair needs them)
+StageSplit find_stage_split(const Graph& g, bool plain = false, uint32_t divisor = 0, uint32_t max_atoms = 13, bool force_atoms = false);
+// FZ_VF_CROSS_PAIR: the chain as 2 W segments, part w = the stage split of segments (w, w + W) as ONE packed pair (K = 2, node ids the
+// graph's own); {} when the graph is not exactly 2 W isomorphic segments input to output
+std::vector<StageSplit> find_cross_parts(const Graph& g, uint32_t W);
 std::vector<Graph> find_wave_roles(const Graph& g, uint32_t W);   // fz_split.cpp; {} or W graphs
 // number of waves per stream tuple a variant asks for (flags bits 10..11: 1024 -> 2, 2048 -> 3, 3072 -> 4), 0 = no wave split
 inline uint32_t wave_split_of(uint32_t flags) { const uint32_t b = (flags >> 10) & 3u; return b ? b + 1 : 0; }

@@ -15,7 +15,7 @@ namespace fz {
 
 // ---- variant selection ---------------------------------------------------------------------------------
 constexpr uint64_t kMaxLdsBytes = 160 * 1024;
-constexpr uint32_t kLockstepMinRows = 256;
+constexpr uint32_t kLockstepMinRows = 1024;
 
 // tile_streams: the frame layout the variant is for -- 0 (or >= n_streams) plain time-major rows, else stream tiles (stream-major
 // frames are named by FZ_VF_STREAM_MAJOR in the variant's flags).  allow_lockstep: see the time-major rule below.
@@ -104,6 +104,27 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // W compute waves per 64 streams, each evaluating one part of the serial graph (fz_split.cpp: find_wave_roles), and with
       // FZ_VF_IO_WAVE one more wave for the frame I/O
       const uint32_t waves = ws_waves(v.flags);
+      if (v.flags & FZ_VF_CROSS_PAIR) {
+         // pairs across the parts: W compute waves (segments w and w + W of a chain of exactly 2 W) + the I/O wave; per tuple W hand-off
+         // rings of 2 x U / 2 float4 per lane and the output ring: (W U + U / 2) KiB
+         if (wave_split_of(v.flags) < 2 || !ws_io(v.flags)) fail(FZ_E_INVALID, "FZ_VF_CROSS_PAIR goes with FZ_VF_WAVES(2..4) and FZ_VF_IO_WAVE");
+         if (!g.cross_parts(W)) fail(FZ_E_UNSUPPORTED, "FZ_VF_CROSS_PAIR: the graph is not a chain of exactly 2 x W isomorphic segments (1 in, 1 out, register delay lines, no scalar prefix / suffix)");
+         if (reqP > 1) fail(FZ_E_INVALID, "wave split needs streams_per_lane == 1");
+         if (reqU && reqU != 8 && reqU != 16 && reqU != 32) fail(FZ_E_INVALID, "wave split: unroll must be 8, 16 or 32");
+         if (reqB && (reqB % 64 || reqB * waves > 1024)) fail(FZ_E_INVALID, "wave split: block_threads counts the streams of a workgroup: a multiple of 64, at most 1024 / waves per tuple");
+         if (v.flags & (FZ_VF_STREAM_MAJOR | FZ_VF_OUT_F64 | FZ_VF_PREFETCH3)) fail(FZ_E_UNSUPPORTED, "wave split: time-major / tiled float32 frames, double buffering only");
+         v.P = 1;
+         // as many tuples per workgroup as it takes to put a compute wave on every SIMD of a CU that gets that many streams
+         v.block = reqB ? reqB : (n_streams <= 16384 ? 64u : n_streams <= 32768 ? 128u : 256u);
+         while (v.block * waves > 1024 && !reqB) v.block /= 2;
+         v.U = reqU ? reqU : 16;
+         auto lds = [&](const Variant& q) { return (uint64_t)(q.block / 64) * (W * q.U + q.U / 2) * 1024u; };
+         while (lds(v) > kMaxLdsBytes && !reqU && v.U > 8) v.U /= 2;
+         while (lds(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
+         if (lds(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_CROSS_PAIR: the hand-off rings do not fit the LDS with this unroll and block size");
+         v.flags &= ~(uint32_t)(FZ_VF_STAGE_PACK | FZ_VF_NO_STAGE_PACK | FZ_VF_SLP);
+         return v;
+      }
       if (!g.wave_roles(W))
          fail(FZ_E_UNSUPPORTED, W == 1 ? "FZ_VF_IO_WAVE: the graph is not stage-packable (1 in, 1 out, register delay lines)"
                                        : "wave split: the graph is not that many groups of isomorphic segments in series (1 in, 1 out, register delay lines)");
@@ -158,8 +179,9 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    // buffers are range-checked per dword, tools/oob_probe.hip), and rows that are only 4-byte aligned are fine for b64 / b128.
    {
       const bool nothing_asked = !reqP && !reqU && !reqB && !(v.flags & ~(uint32_t)FZ_VF_OUT_F64);
-      // (blocks of a few dozen rows -- control-rate windows -- run free: the walk in step needs a few hundred rows to pay for its
-      //  start: 64-sample windows of 1 M streams 0.73 of peak free-running against 0.56-0.63 in lockstep, profiles/r04/sweep_next_rows.txt)
+      // (short blocks -- control-rate windows -- run free: the walk in step needs about a thousand rows to pay for its start.  1 M
+      //  streams, lockstep against free-running four-wave workgroups: 64-sample windows 0.57 / 0.77 of peak, 256 rows 0.60 / 0.66,
+      //  512 rows 0.64 / 0.66, 1024 rows level, 4096 rows 0.76 / 0.66 -- profiles/r04/sweep_block_lengths.txt)
       if (allow_lockstep && nothing_asked && !tile_streams && n_samples >= kLockstepMinRows && n_streams >= (uint64_t)chip_cus() * 1024u && g.n_in <= 2 && g.n_out <= 2 &&
           g.far_lines.empty() && g.n_lds_slots == 0 && !(g.typed && (n_streams % 4))) {
          const uint32_t cap = allow_lockstep >= 3 ? 4u : allow_lockstep;
