@@ -259,6 +259,9 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
                                    per two steps, no pack / unpack moves: 10 instructions per step and wave where the split into consecutive
                                    stages issues 12.8.  The samples travel twice round the ring of waves (low halves, then high halves).
                                    Chosen automatically for few streams where the graph allows it                                       */
+       FZ_VF_IO_WAVE2 = 33554432u, /* with FZ_VF_IO_WAVE: TWO I/O waves per tuple -- one loads the input rows, one stores the output rows.  A wave
+                                   issues its vector-memory instructions in order, one row of 64 streams x 4 bytes each: at one I/O wave per
+                                   tuple that wave's 2 x n_samples instructions are what a round waits for (profiles/r04/few_streams_floor.txt) */
        FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
                                    float*): the results of graphs with double literals leave un-narrowed, float
                                    wires are widened exactly (tuple<double> results, test/tests.cpp:201-231)   */

@@ -705,8 +705,8 @@ def test_wave_split_kernel_vs_oracle(torch_cuda, F, name, T):
     ref, st_ref = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
     assert ndiff(ref, want) == 0
     tried = 0
-    for W, io in ((2, 0), (3, 0), (4, 0), (1, 1), (2, 1), (3, 1)):   # parts = compute waves per 64 streams (whatever the graph divides into), + an I/O wave
-        fl = F.C.FZ_VF_WAVES(W) | (F.C.FZ_VF_IO_WAVE if io else 0)
+    for W, io in ((2, 0), (3, 0), (4, 0), (1, 1), (2, 1), (3, 1), (1, 2), (2, 2), (3, 2)):   # parts = compute waves per 64 streams (whatever the graph divides into), + one / two I/O waves
+        fl = F.C.FZ_VF_WAVES(W) | (F.C.FZ_VF_IO_WAVE if io else 0) | (F.C.FZ_VF_IO_WAVE2 if io == 2 else 0)
         try:
             prog.kernel_name(F.make_variant(1, 16, 0, fl), ns, T)
         except F.FlowzError:
@@ -746,18 +746,18 @@ def test_cross_paired_wave_split_vs_oracle(torch_cuda, F, name, T):
     assert ndiff(ref, want) == 0
     fl = F.C.FZ_VF_WAVES(W) | F.C.FZ_VF_IO_WAVE | F.C.FZ_VF_CROSS_PAIR
     assert "x" in prog.kernel_name(F.make_variant(1, 16, 0, fl), ns, T).split("w")[-1]
-    for U, B in ((8, 64), (16, 128), (32, 64), (16, 64), (8, 192)):
-        if B * (W + 1) > 1024:
+    for U, B, io2 in ((8, 64, 0), (16, 128, 0), (32, 64, 0), (16, 64, 1), (8, 192, 0), (8, 128, 1)):
+        if B * (W + 1 + io2) > 1024:
             continue
-        got, st = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, U, B, fl))
-        assert ndiff(got, want) == 0, (name, T, U, B)
-        assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0, (name, T, U, B)
+        got, st = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, U, B, fl | (F.C.FZ_VF_IO_WAVE2 if io2 else 0)))
+        assert ndiff(got, want) == 0, (name, T, U, B, io2)
+        assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0, (name, T, U, B, io2)
     if T >= 5:
         k = T // 3 + 1
         a, st1 = run_gpu(torch_cuda, F, prog, x[:k], variant=F.make_variant(1, 16, 64, fl))
         b, st2 = run_gpu(torch_cuda, F, prog, x[k:], variant=F.make_variant(1, 8, 256, NO_STAGE_PACK), state=st1)
         assert ndiff(np.concatenate([a, b]), want) == 0
-        a, st1 = run_gpu(torch_cuda, F, prog, x[:k], variant=F.make_variant(2, 8, 64))
+        a, st1 = run_gpu(torch_cuda, F, prog, x[:k], variant=F.make_variant(1, 8, 64))
         b, st2 = run_gpu(torch_cuda, F, prog, x[k:], variant=F.make_variant(1, 16, 128, fl), state=st1)
         assert ndiff(np.concatenate([a, b]), want) == 0 and ndiff(st2.cpu().numpy(), st_ref.cpu().numpy()) == 0
 

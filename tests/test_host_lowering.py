@@ -408,7 +408,7 @@ def test_typed_programs_lowering_vs_oracle_and_std_complex():
     # a double line deeper than the register cap is an LDS ring of (low word, high word) pairs
     g = G.chan(G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 12)), G.mul(G.lit64(0.25), G.IN(2)))), G.add(G.IN(1), G.DEL(1, 20)))
     p = F.compile(F.from_sexpr(g), typed=True)
-    assert p.line_dtypes() == ["f64", "f32"] and p.n_state == 2 * 12 + 20 and p.n_lds_slots == 2 * 12 + 20     # (ring slots: exactly the depths, round 4)
+    assert p.line_dtypes() == ["f64", "f32"] and p.n_state == 2 * 12 + 20 and p.n_lds_slots == 2 * 16 + 32
     got = F.unpack_typed(run_ir(p, x)[0], p.output_dtypes())
     want = O.run_typed(O.compile(g, 7, typed=True), [x[:, :, 0]])
     assert all(a.dtype == b.dtype and np.array_equal(a, b) for a, b in zip(got, want))

@@ -31,6 +31,7 @@ FZ_VF_SM_LONG, FZ_VF_SM_SHORT, FZ_VF_WAVE_SPLIT, FZ_VF_IO_WAVE = 256, 512, 1024,
 FZ_VF_LOCKSTEP = 524288
 FZ_VF_GRID_SYNC = 8388608
 FZ_VF_CROSS_PAIR = 16777216
+FZ_VF_IO_WAVE2 = 33554432
 
 
 def FZ_VF_WAVES(n):

@@ -149,7 +149,8 @@ inline uint32_t wave_split_of(uint32_t flags) { const uint32_t b = (flags >> 10)
 // kernels), and waves per tuple
 inline uint32_t ws_io(uint32_t flags) { return (flags & FZ_VF_IO_WAVE) ? 1u : 0u; }
 inline uint32_t ws_parts(uint32_t flags) { const uint32_t W = wave_split_of(flags); return W ? W : ws_io(flags); }
-inline uint32_t ws_waves(uint32_t flags) { return ws_parts(flags) + (ws_parts(flags) ? ws_io(flags) : 0u); }
+inline uint32_t ws_io_waves(uint32_t flags) { return ws_io(flags) ? ((flags & FZ_VF_IO_WAVE2) ? 2u : 1u) : 0u; }   // FZ_VF_IO_WAVE2: loader and storer are two waves
+inline uint32_t ws_waves(uint32_t flags) { return ws_parts(flags) + (ws_parts(flags) ? ws_io_waves(flags) : 0u); }
 
 // internal variant flag (never set by callers): FZ_VF_GRID_SYNC with more blocks than the chip holds workgroups -> persistent launch
 constexpr uint32_t FZ_VF_PERSIST = 1u << 27;

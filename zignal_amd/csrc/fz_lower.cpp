@@ -629,12 +629,10 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
       if (f64 && l.far)
          fail(FZ_E_UNSUPPORTED, "a double delay line deeper than " + std::to_string(kLdsMaxDepth) + " samples (the rings in HBM hold floats)");
       if (l.in_lds) {
-         // ring slots: exactly the depth (round 4).  A power of two makes the ring index one scalar AND, but the rings of a workgroup
-         // share the CU's 160 KiB with every other workgroup on it: lines of 40 and 23 samples rounded up to 64 + 32 slots let 426
-         // streams be resident per CU, exact sizes 650 -- occupancy is what bounds a graph whose every step waits for LDS reads
-         // (FLOWZ_HIP_LDS_POW2=1 keeps the power-of-two sizes for comparison; the index of an exact ring is a wave-uniform modulo)
-         static const bool pow2 = std::getenv("FLOWZ_HIP_LDS_POW2") != nullptr;
-         uint32_t sz = pow2 ? 1u : l.depth;
+         // ring slots: the next power of two (the ring index is one scalar AND).  Exact sizes -- more streams resident per CU, the
+         // index a wave-uniform modulo -- were measured in round 4 and do not pay: 0.59-0.62 of peak against 0.60-0.71 for the two
+         // combs of 40 and 23 samples at 1 M streams (profiles/r04/sweep_next_rows.txt)
+         uint32_t sz = 1;
          while (sz < l.depth) sz <<= 1;
          l.lds_slot0 = lds;
          l.lds_size = sz;

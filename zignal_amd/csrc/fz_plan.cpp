@@ -100,6 +100,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    if ((v.flags & FZ_VF_LOCKSTEP) && (ws_parts(v.flags) || (v.flags & FZ_VF_STREAM_MAJOR)))
       fail(FZ_E_INVALID, "FZ_VF_LOCKSTEP applies to the frame kernel (time-major / tiled frames, lane-packed or stage-packed; no wave split)");
    if ((v.flags & FZ_VF_GRID_SYNC) && !(v.flags & FZ_VF_LOCKSTEP)) fail(FZ_E_INVALID, "FZ_VF_GRID_SYNC goes with FZ_VF_LOCKSTEP");
+   if ((v.flags & FZ_VF_IO_WAVE2) && !(v.flags & FZ_VF_IO_WAVE)) fail(FZ_E_INVALID, "FZ_VF_IO_WAVE2 goes with FZ_VF_IO_WAVE");
    if (const uint32_t W = ws_parts(v.flags)) {
       // W compute waves per 64 streams, each evaluating one part of the serial graph (fz_split.cpp: find_wave_roles), and with
       // FZ_VF_IO_WAVE one more wave for the frame I/O
@@ -359,16 +360,6 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    if (g.n_lds_slots) {
       // LDS rings: slots * block * 4P bytes must fit the CU's 160 KiB of LDS (one workgroup may take it all)
       auto bytes = [&](const Variant& w) { return (uint64_t)g.n_lds_slots * w.block * 4u * w.P; };
-      // Every step of such a graph waits for its ring reads (~64+ cycles each), so what counts is how many waves a CU holds, and
-      // the rings decide that: one stream per lane (a wave's rings are half the size) in small workgroups (a quarter of the LDS
-      // at most: the CU's waves come and go in finer steps) -- the two combs of 40 and 23 samples at 1 M streams: 0.64 of peak
-      // with 128-lane workgroups of one stream per lane against 0.60 for the two-streams-per-lane default before
-      // (profiles/r04/sweep_next_rows.txt)
-      if (!reqP && !reqB) {
-         v.P = 1;
-         v.block = 128;
-         while (bytes(v) > kMaxLdsBytes / 4 && v.block > 64) v.block /= 2;
-      }
       while (bytes(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
       while (bytes(v) > kMaxLdsBytes && !reqP && v.P > 1) v.P /= 2;
       if (bytes(v) > kMaxLdsBytes)
@@ -524,7 +515,7 @@ static bool plan_load(const fz_program* p, uint64_t n_streams, uint32_t tile, fz
       if ((P != 0 && P != 1 && P != 2 && P != 4) || U > 128 || B > 1024 || (B % 64)) continue;   // (a damaged line)
       // only what tune_candidates can emit: a stale or damaged line must not turn a default launch into another LAYOUT or output type
       // (FZ_VF_STREAM_MAJOR / FZ_VF_OUT_F64 would write past a float32 time-major `out`)
-      constexpr unsigned kPlanFlags = FZ_VF_STAGE_PACK | FZ_VF_WAVE_SPLIT | FZ_VF_WAVE_SPLIT3 | FZ_VF_IO_WAVE | FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC | FZ_VF_PREFETCH3 | FZ_VF_MAX_WG(7);
+      constexpr unsigned kPlanFlags = FZ_VF_STAGE_PACK | FZ_VF_WAVE_SPLIT | FZ_VF_WAVE_SPLIT3 | FZ_VF_IO_WAVE | FZ_VF_IO_WAVE2 | FZ_VF_CROSS_PAIR | FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC | FZ_VF_PREFETCH3 | FZ_VF_MAX_WG(7);
       if (fl & ~kPlanFlags) continue;
       *out = fz_variant{P, U, B, fl};
       found = true;
@@ -576,7 +567,10 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
       if (W > 2 && g.wave_roles(2)) cands.push_back(fz_variant{1, 16, 0, FZ_VF_WAVE_SPLIT});
       cands.push_back(fz_variant{1, 16, 0, FZ_VF_STAGE_PACK});
    } else if (d.flags & FZ_VF_STAGE_PACK) {
-      if (n_streams <= 65536 && g.wave_roles(1)) cands.push_back(fz_variant{1, 16, 0, FZ_VF_IO_WAVE});   // one compute + one I/O wave per 64 streams
+      if (n_streams <= 65536 && g.wave_roles(1)) {
+         cands.push_back(fz_variant{1, 16, 0, FZ_VF_IO_WAVE});                     // one compute + one I/O wave per 64 streams
+         cands.push_back(fz_variant{1, 16, 0, FZ_VF_IO_WAVE | FZ_VF_IO_WAVE2});    // ... + a loader and a storer (65 536 streams: 0.73 against 0.69 of peak on the board that ran both)
+      }
       // one packed pair of segments per wave, four tuples to a workgroup (every SIMD of the CU gets one wave of every part):
       // level with the single wave on some boards, +3 % on others (gpurun_out/r03b-c)
       const uint32_t Wp = g.split.K / 2;
