@@ -473,11 +473,11 @@ def leg(cx, sp, layout, tile=0, tune=True, forced=None, energy=False, reps_ms=60
 
     def name_of(v):
         if bank is not None:
-            return prog.kernel_name(mk(v), ns, sp.blocks[0], tile)
+            return prog.kernel_symbol(mk(v), ns, sp.blocks[0], tile)
         if sm:
             q = mk(v) or F.make_variant(0, 0, 0, 0)
-            return prog.kernel_name(F.make_variant(q.streams_per_lane, q.unroll, q.block_threads, q.flags | SMF), ns, T)
-        return prog.kernel_name(mk(v) if v is not None else prog.plan(ns, tile), ns, T, tile)
+            return prog.kernel_symbol(F.make_variant(q.streams_per_lane, q.unroll, q.block_threads, q.flags | SMF), ns, T)
+        return prog.kernel_symbol(mk(v) if v is not None else prog.plan(ns, tile), ns, T, tile)
 
     b = sp.b_alg(prog)
 
@@ -851,7 +851,7 @@ def main():
     tuned = None
     if do_tune and not forced:
         variant, _ = prog.tune(x, state=state, out=y)
-        tuned = prog.kernel_name(variant, ns, T, tile)
+        tuned = prog.kernel_symbol(variant, ns, T, tile)
         state.zero_()
 
     # first block from zero state: kept for the parity check (>= 1024 random streams across all tiles)
@@ -905,7 +905,7 @@ def main():
         torch.cuda.synchronize()
         walk_ms = event_ms(torch, lambda: ident.run_block(x, state=st0, out=y), max(5, args.steps // 2))
         walk_gbs = 2.0 * x.numel() * 4 / (walk_ms / 1e3) / 1e9
-        walk_kernel = ident.kernel_name(ident.plan(ns, tile), ns, T, tile)
+        walk_kernel = ident.kernel_symbol(ident.plan(ns, tile), ns, T, tile)
 
     secondary = {}
     if rank == 0 and world == 1:
@@ -936,7 +936,7 @@ def main():
 
     if rank == 0:
         achieved = b_alg / kern_avg_s / 1e9
-        kname = prog.kernel_name(variant if variant is not None else prog.plan(ns, tile), ns, T, tile)
+        kname = prog.kernel_symbol(variant if variant is not None else prog.plan(ns, tile), ns, T, tile)
         wkey = f"cascade6_{ns}x{T}_{lay}"
         traffic = traffic_of(kname, wkey)
         share = issue_share_of(kname, wkey)

@@ -297,10 +297,16 @@ typedef struct fz_kernel_resources {
 } fz_kernel_resources;
 int fz_program_kernel_resources(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
                                 int as_launched, fz_kernel_resources* out);
-/* symbol of the variant's kernel as profilers show it, e.g. "fz_block_kernel_p2u16b256f2097152": exactly the kernel a launch of
- * the shape (n_streams, n_samples, tile_streams) runs -- one resolution shared with the launch path; returns length */
+/* name of the variant's kernel, e.g. "fz_block_kernel_p2u16b256f2097152" (streams per lane, rows per chunk, lanes per workgroup,
+ * flags): exactly the kernel a launch of the shape (n_streams, n_samples, tile_streams) runs -- one resolution shared with the
+ * launch path; returns length */
 long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
                             char* buf, size_t cap);
+/* ... and the SYMBOL of that kernel as profilers show it (rocprofv3 --kernel-trace --stats): the name + "_g<8 hex digits>", a tag of
+ * the graph's structure -- two graphs that run the same variant are different rows of a profile (graphs that differ only in
+ * coefficient values share the symbol and the code object) */
+long fz_program_kernel_symbol(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
+                              char* buf, size_t cap);
 /* generated HIP source of a variant (skeleton + graph body); returns length, writes <= cap    */
 long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap);
 

@@ -1526,7 +1526,7 @@ def test_stream_major_pair_body_is_the_default_for_deep_graphs_on_many_streams(t
     assert prog.kernel_name(sm, (1 << 20) + 1, 4096).startswith("fz_block_kernel_p1u128b256s6f")
     assert prog.kernel_name(sm, 1 << 20, 128).startswith("fz_block_kernel_p1u")
     assert F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u128b256f")
-    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u")   # per-stream coefficients
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b256f384"   # per-stream coefficients ride along as packed pairs (round 4)
     ns, T = (1 << 19) + 130, 644
     x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
     F.synth_fill(x, SEED + 7)

@@ -249,7 +249,7 @@ def test_stream_major_pair_long_run_body_rules_and_code(tmp_path, monkeypatch):
     assert p.kernel_name(sm, 1 << 20, 128).startswith("fz_block_kernel_p1u")                        # shorter than a long-run block
     assert p.kernel_name(F.make_variant(0, 0, 0, SMF | F.C.FZ_VF_SM_SHORT), 1 << 20, 4096).startswith("fz_block_kernel_p1u32")   # anything asked for: as before
     assert F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u128b256f")     # shallow graphs
-    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u")               # per-stream coefficients
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b256f384"              # per-stream coefficients ride along as packed pairs (round 4)
     for bad in (F.make_variant(2, 128, 0, SMF | LONG), F.make_variant(2, 32, 0, SMF | LONG)):
         with pytest.raises(F.FlowzError):
             p.kernel_name(bad, 1024, 512)
@@ -260,7 +260,7 @@ def test_stream_major_pair_long_run_body_rules_and_code(tmp_path, monkeypatch):
     r = p.kernel_resources(F.make_variant(2, 64, 0, SMF | LONG), 1 << 20, 4096)
     assert r["scratch_bytes"] == 0 and r["lds_bytes"] == 4 * 64 * (2 * 64 + 4) * 4 and r["vgprs"] <= 512 and r["unroll"] == 64
     obj = [o for o in tmp_path.glob("*.hsaco")
-           if "p2u64b256f384" in subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(o)], text=True)][0]
+           if p.kernel_symbol(F.make_variant(2, 64, 0, SMF | LONG), 1 << 20, 4096) in subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(o)], text=True)][0]
     dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", str(obj)], text=True)
     assert not re.search(r"v_(pk_)?(fma|fmac|mad|mac)(_mix|_mixlo|_mixhi|_legacy)?_(f16|f32|f64|bf16)", dis)
     assert "scratch_" not in dis and "flat_load" not in dis and "v_cmp_eq_u64" not in dis and dis.count("v_readfirstlane_b32") < 8
@@ -564,7 +564,7 @@ def test_time_major_geometry_follows_the_cu_count():
     assert name(3 << 18) == "fz_block_kernel_p4u1b768f%d" % (L | GS | P3)              # 786 432 = 256 x 768 x 4
     assert name(1_000_000) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)           # 245 workgroups of 1024 lanes
     assert name(1 << 20) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)
-    assert name((1 << 20) + 1) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)       # one lap + a remainder launch of one stream: not ragged
+    assert name((1 << 20) + 1) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | RAGGED)   # one lap + a remainder launch of one stream; rows off the 16-byte grid: dword accesses
     assert name(1_000_001) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | RAGGED)  # fits the workgroups: the last lane is partial
     assert name(1 << 21) == "fz_block_kernel_p2u2b1024f%d" % (L | GS)                  # four laps of two streams per lane (0.75 against 0.70 for two laps of four)
     assert "b1024" not in name(1 << 17) and "f%d" % (L | GS) not in name((1 << 18) - 1024)   # below one wave per SIMD and CU: the few-stream kernels
@@ -702,3 +702,18 @@ def test_sample_rate_modulators_lower_like_the_oracle():
     with pytest.raises(F.FlowzError):                     # a graph without modulators takes no modulation array
         plain = F.compile(F.from_sexpr(G.df1()))
         _capi.check(_capi.lib.fz_program_set_modulation(plain._h, None, 16))
+
+
+def test_kernel_symbols_keep_graphs_apart_in_a_profile():
+    """The symbol in the code object is the variant's name + a tag of the graph's structure: two graphs that run the same variant are two
+    rows of `rocprofv3 --stats` (the bench line's roofline.kernel is such a symbol); graphs that differ in coefficient VALUES only share it
+    (and the code object: the values travel in the kernarg)."""
+    import re
+    a, b = F.compile(F.from_sexpr(G.df1_cascade(6))), F.compile(F.from_sexpr(G.df1()))
+    na, nb = a.kernel_name(None, 1 << 20, 4096, 0), b.kernel_name(None, 1 << 20, 4096, 0)
+    sa, sb = a.kernel_symbol(None, 1 << 20, 4096, 0), b.kernel_symbol(None, 1 << 20, 4096, 0)
+    assert na == nb and sa != sb
+    assert re.fullmatch(re.escape(na) + r"_g[0-9a-f]{8}", sa) and sb.startswith(nb + "_g")
+    c = F.compile(F.from_sexpr(G.df1_cascade(6, coeffs=[(0.3, 0.1, 0.05, 0.2, -0.1)] * 6)))
+    assert c.kernel_symbol(None, 1 << 20, 4096, 0) == sa
+    assert sa in a.source(F.make_variant(4, 1, 1024, F.C.FZ_VF_LOCKSTEP | F.C.FZ_VF_GRID_SYNC | F.C.FZ_VF_PREFETCH3))

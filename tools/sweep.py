@@ -38,8 +38,8 @@ def main():
               "cascade6g": lambda: G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1))),
               "cascade12": lambda: G.df1_cascade(12), "cascade24": lambda: G.df1_cascade(24),
               "mod6": lambda: G.df1_cascade_modulated(6), "ldsring": G.lds_ring_comb, "farring": lambda: G.far_comb(300), "ident": lambda: G.IN(1),
-              "params6": lambda: G.df1_cascade_params(6)}
-    prog = F.compile(F.from_sexpr(graphs[a.graph]()))
+              "params6": lambda: G.df1_cascade_params(6), "c32onepole": G.complex_one_pole, "f64biquad": G.df1_double}
+    prog = F.compile(F.from_sexpr(graphs[a.graph]()), typed=a.graph in ("c32onepole", "f64biquad"))
     ns, T = a.streams, a.samples
     if a.prebuild:
         for s in a.variants:

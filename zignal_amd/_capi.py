@@ -115,6 +115,7 @@ def _load():
         "fz_program_wave_part": (ctypes.c_int, [P, u32, u32, ctypes.POINTER(P)]),
         "fz_program_kernel_resources": (ctypes.c_int, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_int, ctypes.POINTER(KernelResources)]),
         "fz_program_kernel_name": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_char_p, ctypes.c_size_t]),
+        "fz_program_kernel_symbol": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_char_p, ctypes.c_size_t]),
         "fz_program_source": (ctypes.c_long, [P, ctypes.POINTER(Variant), ctypes.c_char_p, ctypes.c_size_t]),
         "fz_run_block": (ctypes.c_int, [P, P, P, P, P, u64, u32, ctypes.POINTER(Variant), P]),
         "fz_run_block_tiled": (ctypes.c_int, [P, P, P, P, P, u64, u32, u32, ctypes.POINTER(Variant), P]),

@@ -23,6 +23,7 @@ int fz_compile(const fz_expr* e, fz_program** out)
       try {
          p->g = lower(e);
          p->graph_hash = graph_structure_hash(p->g);
+         p->g.sym_tag = (uint32_t)p->graph_hash;
       } catch (...) {
          delete p;
          throw;
@@ -42,6 +43,7 @@ int fz_program_wave_part(const fz_program* p, uint32_t n_parts, uint32_t k, fz_p
       q->g = (*roles)[k];
       q->g.wave_splits.assign(5, {});
       q->graph_hash = graph_structure_hash(q->g);
+      q->g.sym_tag = (uint32_t)q->graph_hash;
       *out = q;
       return FZ_OK;)
 }
@@ -61,6 +63,7 @@ int fz_compile_typed(const fz_expr* e, const uint32_t* in_dtypes, uint32_t n_in_
       std::unique_ptr<fz_program> p(new fz_program());
       p->g = lower(e, opt);
       p->graph_hash = graph_structure_hash(p->g);
+      p->g.sym_tag = (uint32_t)p->graph_hash;
       *out = p.release();
       return FZ_OK;)
 }
@@ -229,6 +232,24 @@ long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_strea
    try {
       if (!p) fail(FZ_E_INVALID, "null program");
       const std::string s = kernel_name(p->g, finalize_variant(p, v, n_streams ? n_streams : (1ull << 20), n_samples ? n_samples : (1u << 20), tile_streams));
+      if (buf && cap) {
+         const size_t n = std::min(cap - 1, s.size());
+         std::memcpy(buf, s.data(), n);
+         buf[n] = 0;
+      }
+      return (long)s.size();
+   } catch (const fz::Error& er) {
+      set_error(er.msg);
+      return er.code;
+   }
+}
+
+long fz_program_kernel_symbol(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
+                            char* buf, size_t cap)
+{
+   try {
+      if (!p) fail(FZ_E_INVALID, "null program");
+      const std::string s = kernel_symbol(p->g, finalize_variant(p, v, n_streams ? n_streams : (1ull << 20), n_samples ? n_samples : (1u << 20), tile_streams));
       if (buf && cap) {
          const size_t n = std::min(cap - 1, s.size());
          std::memcpy(buf, s.data(), n);

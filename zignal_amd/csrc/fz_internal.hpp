@@ -111,6 +111,7 @@ struct Graph {
    uint32_t n_in = 0, n_out = 0, n_param = 0;   // n_in / n_out: frame SLOTS (floats per frame)
    uint32_t n_mod = 0;               // sample-rate modulators (fz_modulator)
    bool typed = false;               // fz_compile_typed: wire types carried through inputs, state and outputs
+   uint32_t sym_tag = 0;             // low 32 bits of graph_structure_hash: the "_g<tag>" of the kernel symbols (kernel_symbol)
    std::vector<uint8_t> in_dtype;    // per input wire: fz_dtype
    std::vector<Node> nodes;          // topological order
    std::vector<uint32_t> outputs;    // node ids, one per output frame slot
@@ -183,7 +184,8 @@ struct Variant {
    }
 };
 
-std::string kernel_name(const Graph& g, const Variant& v);
+std::string kernel_name(const Graph& g, const Variant& v);     // the variant: fz_block_kernel_p<P>u<U>b<block>...f<flags>
+std::string kernel_symbol(const Graph& g, const Variant& v);   // the symbol in the code object: kernel_name + "_g<graph tag>"
 std::string gen_config(const Graph& g, const Variant& v); // generated "fz_graph_config.h"
 std::string gen_body(const Graph& g, const Variant& v);   // generated "fz_graph_body.h"
 const char* skeleton_source();                            // hand-written kernel skeleton text

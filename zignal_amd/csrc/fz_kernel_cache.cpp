@@ -557,7 +557,7 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
    if (fn_out) {
       require_device();
       try {
-         *fn_out = k->function_on_current_device(kernel_name(p->g, v));
+         *fn_out = k->function_on_current_device(kernel_symbol(p->g, v));
       } catch (const Error& er) {
          // a cached code object the DRIVER refuses to load (built for another code-object version, damaged in a way the trailer
          // does not see): delete it, build afresh, store that, try once more.  Anything else -- out of memory, no device, a
@@ -571,7 +571,7 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
          k->res = read_resources(k->code);
          k->cache_path = cache_dir() + cache_file_of(p, v, rtc().identity);   // (under the name of the compiler that built it)
          cache_store(cache_dir(), k->cache_path, k->code);
-         *fn_out = k->function_on_current_device(kernel_name(p->g, v));
+         *fn_out = k->function_on_current_device(kernel_symbol(p->g, v));
       }
    }
    return k;

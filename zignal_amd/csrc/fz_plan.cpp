@@ -285,7 +285,9 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
          return (double)wg / (double)(rounds * cus);
       };
       const bool enough = n_streams >= (1u << 19) || (n_streams >= (1u << 17) && fill(n_streams, 512) >= fill(n_streams, 256) - 0.02);
-      if (!uv_has_shape(uv) && g.n_in == 1 && g.n_out == 1 && g.n_lds_slots == 0 && g.far_lines.empty() && g.n_param == 0 && g.n_mod == 0 &&
+      // (per-stream coefficients ride along as packed pairs -- the oscillator chain with its 31: 6.38-6.43 ms against 6.70-6.79 ms for
+      //  the stage-packed one-stream body on two boards of round 4; a graph whose registers do not fit falls back in settle_variant)
+      if (!uv_has_shape(uv) && g.n_in == 1 && g.n_out == 1 && g.n_lds_slots == 0 && g.far_lines.empty() && g.n_param <= 32 && g.n_mod == 0 &&
           !g.typed && g.n_ops > 27 && g.n_state <= 20 && enough && n_streams % 2 == 0 && n_samples >= 256) {
          v.P = 2;
          v.flags |= FZ_VF_SM_LONG;
@@ -408,8 +410,16 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
       // XCD-wide synchronisation needs every workgroup running: with more blocks than the chip holds workgroups the launch path
       // cuts the block into laps, one launch each (fz_launch.cpp).  FLOWZ_HIP_LAPS=kernel keeps round 3's alternative for
       // comparison: ONE persistent launch whose workgroups loop over the laps (FZ_VF_PERSIST, a kernel of its own)
+      // FZ_VF_RAGGED (internal): one descriptor per row and, with several streams per lane, the lane's streams 64 apart (dword accesses).
+      // For a count that is not a multiple of the streams per lane -- and for rows whose pitch is not a multiple of the lane's vector
+      // access (1 048 577 streams: whole laps of four streams per lane, but every row starts 4 bytes further off the 16-byte grid)
       v.flags &= ~FZ_VF_RAGGED;
-      if ((v.flags & FZ_VF_LOCKSTEP) && !tile_streams && !stream_major && lockstep_streams(p->g, uv, v, n_streams) % v.P) v.flags |= FZ_VF_RAGGED;
+      if ((v.flags & FZ_VF_LOCKSTEP) && !tile_streams && !stream_major && !g.typed && g.far_lines.empty() && g.n_lds_slots == 0) {
+         auto vw = [](uint64_t w) { return w % 4 == 0 ? 4u : w % 2 == 0 ? 2u : 1u; };
+         const uint64_t ow = (uint64_t)g.n_out * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 2 : 1);
+         const bool off_grid = v.P > 1 && ((g.n_in && (n_streams * g.n_in) % vw((uint64_t)v.P * g.n_in)) || (ow && (n_streams * ow) % vw((uint64_t)v.P * ow)));
+         if (lockstep_streams(p->g, uv, v, n_streams) % v.P || off_grid) v.flags |= FZ_VF_RAGGED;
+      }
       static const bool kernel_laps = [] { const char* e = std::getenv("FLOWZ_HIP_LAPS"); return e && std::strcmp(e, "kernel") == 0; }();
       v.flags &= ~FZ_VF_PERSIST;
       if (kernel_laps && (v.flags & FZ_VF_GRID_SYNC) && ((n_streams + v.P - 1) / v.P + v.block - 1) / v.block > chip_cus()) v.flags |= FZ_VF_PERSIST;

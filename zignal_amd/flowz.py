@@ -366,11 +366,18 @@ class Program:
         return int(C.lib.fz_recommended_tile_streams(self._h))
 
     def kernel_name(self, variant: Optional[Variant] = None, n_streams: int = 0, n_samples: int = 0, tile_streams: int = 0) -> str:
-        """Symbol of the kernel that a launch of this shape runs for this variant.  tile_streams: the frame layout (0 = plain
+        """Name of the kernel variant that a launch of this shape runs (kernel_symbol: the symbol profilers show).  tile_streams: the frame layout (0 = plain
         time-major rows, as for run_block on a 3-D tensor); stream-major frames: FZ_VF_STREAM_MAJOR in the variant's flags."""
         vp = ctypes.byref(variant) if variant is not None else None
         buf = ctypes.create_string_buffer(128)
         C.check(C.lib.fz_program_kernel_name(self._h, vp, int(n_streams), int(n_samples), int(tile_streams), buf, 128))
+        return buf.value.decode()
+
+    def kernel_symbol(self, variant: Optional[Variant] = None, n_streams: int = 0, n_samples: int = 0, tile_streams: int = 0) -> str:
+        """kernel_name + "_g<graph tag>": the symbol in the code object, what rocprofv3 --kernel-trace --stats lists."""
+        vp = ctypes.byref(variant) if variant is not None else None
+        buf = ctypes.create_string_buffer(160)
+        C.check(C.lib.fz_program_kernel_symbol(self._h, vp, int(n_streams), int(n_samples), int(tile_streams), buf, 160))
         return buf.value.decode()
 
     def source(self, variant: Optional[Variant] = None) -> str:
