@@ -1679,9 +1679,9 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     assert prog.kernel_name(None, 1 << 21, 4096, 0) == "fz_block_kernel_p2u2b1024f%d" % LG          # four laps, one launch each (no persistent kernel any more)
     assert prog.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % _capi.FZ_VF_MAX_WG(2)
     assert "b1024" not in prog.kernel_name(None, 1 << 17, 4096, 0)
-    # a register-heavy graph steps down: the oscillator chain (31 per-stream coefficients) runs two streams per lane with one row per
-    # chunk buffer (114 registers); a graph that ends at one stream per lane runs stage-packed there
-    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p2u1b1024f%d" % (LG | _capi.FZ_VF_PREFETCH3)
+    # a register-heavy graph steps down: with many per-stream coefficients (the oscillator chain: 31) straight to one stream per lane,
+    # stage-packed (packing by stages costs no registers per stream)
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s6f%d" % (LG | _capi.FZ_VF_STAGE_PACK)
     assert F.compile(F.from_sexpr(G.osc_chain(8))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s8f%d" % (LG | _capi.FZ_VF_STAGE_PACK)
     assert F.compile(F.from_sexpr(G.par4_sum())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u32b256f0"
     # more blocks than the chip holds workgroups (300 of 1024 lanes): two laps, a launch each with counters of its own

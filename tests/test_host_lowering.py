@@ -564,16 +564,16 @@ def test_time_major_geometry_follows_the_cu_count():
     assert name(3 << 18) == "fz_block_kernel_p4u1b768f%d" % (L | GS | P3)              # 786 432 = 256 x 768 x 4
     assert name(1_000_000) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)           # 245 workgroups of 1024 lanes
     assert name(1 << 20) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)
-    assert name((1 << 20) + 1) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | RAGGED)   # one lap + a remainder launch of one stream; rows off the 16-byte grid: dword accesses
+    assert name((1 << 20) + 1) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)       # one lap + a remainder launch of one stream: not ragged
     assert name(1_000_001) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | RAGGED)  # fits the workgroups: the last lane is partial
     assert name(1 << 21) == "fz_block_kernel_p2u2b1024f%d" % (L | GS)                  # four laps of two streams per lane (0.75 against 0.70 for two laps of four)
     assert "b1024" not in name(1 << 17) and "f%d" % (L | GS) not in name((1 << 18) - 1024)   # below one wave per SIMD and CU: the few-stream kernels
     # nothing of this on tiles, wide frames, LDS rings
     assert p.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % F.C.FZ_VF_MAX_WG(2)
     assert F.compile(F.from_sexpr(G.par4_sum())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u32b256f0"
-    # a register-heavy graph steps down: the oscillator chain (31 per-stream coefficients) runs two streams per lane with one row per
-    # chunk buffer (114 registers); a graph that ends at one stream per lane runs stage-packed there
-    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p2u1b1024f%d" % (L | GS | P3)
+    # a register-heavy graph steps down: with many per-stream coefficients (the oscillator chain: 31) straight to one stream per lane,
+    # stage-packed (packing by stages costs no registers per stream)
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s6f%d" % (L | GS | F.C.FZ_VF_STAGE_PACK)
     assert F.compile(F.from_sexpr(G.osc_chain(8))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s8f%d" % (L | GS | F.C.FZ_VF_STAGE_PACK)
 
 

@@ -109,7 +109,7 @@ struct ArgsHeader {
    unsigned int mod_stride;
    unsigned int n_blocks;
    unsigned int group0;
-   unsigned int stream_end;
+   unsigned int reserved0;
 };
 // the program's side stream on the current device and the two events that fork it from / join it to a caller's stream (created on
 // first use, destroyed with the program; the calls that use them are made under no lock: event record / wait take the state of the
@@ -345,12 +345,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
          if (w.flags & FZ_VF_PERSIST) laps = 1;                                     // (the kernel loops)
       }
       ArgsHeader h{in, out, state, params, mod_dev, nullptr, (unsigned long long)n_streams, n_samples, group0 + groups,
-                   (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (w.P * w.block)) : 0u, rows_total, row0, mod_stride, n_blocks, group0,
-                   (unsigned int)(first + count)};
-      // (FZ_VF_RAGGED with several streams per lane: the lane's streams are 64 apart and the rows' descriptors clip at the end of a ROW, so a
-      //  launch that ends before the last stream must end on a whole wave's streams -- laps and the part in front of a remainder do)
-      if ((w.flags & FZ_VF_RAGGED) && w.P > 1 && first + count != n_streams && count % (64u * w.P))
-         fail(FZ_E_INVALID, "internal: a partial launch of the strided row walk must cover whole waves");
+                   (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (w.P * w.block)) : 0u, rows_total, row0, mod_stride, n_blocks, group0, 0u};
       for (unsigned lap = 0; lap < laps; ++lap) {
          if (laps > 1) {
             h.group0 = group0 + lap * per_lap * w.block;

@@ -410,16 +410,12 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
       // XCD-wide synchronisation needs every workgroup running: with more blocks than the chip holds workgroups the launch path
       // cuts the block into laps, one launch each (fz_launch.cpp).  FLOWZ_HIP_LAPS=kernel keeps round 3's alternative for
       // comparison: ONE persistent launch whose workgroups loop over the laps (FZ_VF_PERSIST, a kernel of its own)
-      // FZ_VF_RAGGED (internal): one descriptor per row and, with several streams per lane, the lane's streams 64 apart (dword accesses).
-      // For a count that is not a multiple of the streams per lane -- and for rows whose pitch is not a multiple of the lane's vector
-      // access (1 048 577 streams: whole laps of four streams per lane, but every row starts 4 bytes further off the 16-byte grid)
+      // (Rows off the 16-byte grid -- 1 048 577 streams: whole laps of four streams per lane, but every row starts 4 bytes further off
+      //  the grid -- cost the b128 accesses 12-17 % of their rate.  Round 4 tried the lane's streams 64 apart instead (dword accesses,
+      //  256 contiguous bytes per wave and instruction): 9.6 ms against 6.5 ms -- four times the memory instructions cost more than the
+      //  straddled boundaries; profiles/r04/rows_off_the_grid.txt)
       v.flags &= ~FZ_VF_RAGGED;
-      if ((v.flags & FZ_VF_LOCKSTEP) && !tile_streams && !stream_major && !g.typed && g.far_lines.empty() && g.n_lds_slots == 0) {
-         auto vw = [](uint64_t w) { return w % 4 == 0 ? 4u : w % 2 == 0 ? 2u : 1u; };
-         const uint64_t ow = (uint64_t)g.n_out * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 2 : 1);
-         const bool off_grid = v.P > 1 && ((g.n_in && (n_streams * g.n_in) % vw((uint64_t)v.P * g.n_in)) || (ow && (n_streams * ow) % vw((uint64_t)v.P * ow)));
-         if (lockstep_streams(p->g, uv, v, n_streams) % v.P || off_grid) v.flags |= FZ_VF_RAGGED;
-      }
+      if ((v.flags & FZ_VF_LOCKSTEP) && !tile_streams && !stream_major && lockstep_streams(p->g, uv, v, n_streams) % v.P) v.flags |= FZ_VF_RAGGED;
       static const bool kernel_laps = [] { const char* e = std::getenv("FLOWZ_HIP_LAPS"); return e && std::strcmp(e, "kernel") == 0; }();
       v.flags &= ~FZ_VF_PERSIST;
       if (kernel_laps && (v.flags & FZ_VF_GRID_SYNC) && ((n_streams + v.P - 1) / v.P + v.block - 1) / v.block > chip_cus()) v.flags |= FZ_VF_PERSIST;
@@ -447,7 +443,11 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
                break;
             }
          }
-         level = level == 4 ? 2 : level - 1;
+         // (a graph with many per-stream coefficients that is a series of isomorphic segments goes straight to one stream per lane,
+         //  STAGE-PACKED: packing by stages costs no registers per stream, packing by lanes doubles the coefficient registers -- the
+         //  oscillator chain with its 31: 6.45 ms against 6.74-6.80 ms with two streams per lane, and 6.60 ms with four in 512-lane
+         //  workgroups, on the board that ran all three; ahead on two more boards; profiles/r04/sweep_time_major_geometry.txt)
+         level = level == 4 ? ((g.n_param >= 16 && g.split.ok) ? 1 : 2) : level - 1;
          w = resolve_variant(g, uv, n_streams, n_samples, tile_streams, level);
          v = fit(w);
          if (!(v.flags & FZ_VF_LOCKSTEP)) break;
