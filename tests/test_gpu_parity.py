@@ -1366,6 +1366,43 @@ def test_stream_major_kernel_vs_oracle(torch_cuda, F, name):
             assert torch.equal(out, y), (ns, T)
 
 
+def _wide_in_graphs():
+    bq = [G.df1(*c) for c in G.PAR4_SETS]
+    return {"par4_sum": G.par4_sum(),                                                                       # 4 wires in, 1 out: four chunks per out-run
+            "par4_two_sums": G.seq(G.par(*bq), G.chan(G.add(G.IN(1), G.IN(2)), G.sub(G.IN(3), G.IN(4)))),   # 4 in, 2 out: two chunks per out-run
+            "eight_wires": G.seq(G.par(*(bq + bq)), G.chan(G.add(G.add(G.IN(1), G.IN(2)), G.add(G.IN(3), G.IN(4))),
+                                                            G.add(G.add(G.IN(5), G.IN(6)), G.add(G.IN(7), G.IN(8)))))}   # 8 in, 2 out
+
+
+@pytest.mark.parametrize("name", ["par4_sum", "par4_two_sums", "eight_wires"])
+def test_stream_major_wide_frames_hold_their_outputs(torch_cuda, F, name):
+    """Stream-major buffers, wide frames in and narrow frames out (round 4): the outputs of n_in / n_out chunks wait in registers and
+    leave as out-runs as long as the in-runs (FZ_SM_HOLD in the short-chunk body).  Whole runs, a shorter last run, tails, windows,
+    ragged stream counts, every chunk depth -- against the oracle, and against the body that stores every chunk (two streams per lane)."""
+    torch = torch_cuda
+    g = _wide_in_graphs()[name]
+    prog = F.compile(F.from_sexpr(g))
+    for ns, T in ((64, 128), (130, 300), (777, 100), (1000, 260), (3, 516)):
+        x = O.synth_input(SEED + 171, np.arange(ns), T, n_wires=prog.n_in)
+        want = O.compile(g, ns).run(x)
+        xs = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))).cuda()
+        y, st = prog.run_block_stream_major(xs)
+        assert ndiff(y.permute(1, 0, 2).contiguous().cpu().numpy(), want) == 0, (ns, T)
+        for v in ((1, 4), (1, 8), (1, 16), (1, 32), (2, 8)):
+            if ns % v[0] == 0:
+                try:
+                    yv, stv = prog.run_block_stream_major(xs, variant=F.make_variant(*v))
+                except F.FlowzError:
+                    assert v[0] == 2 or name == "eight_wires"           # (patches that do not fit)
+                    continue
+                assert torch.equal(yv, y) and torch.equal(stv, st), (ns, T, v)
+        # windows: the first 40 rows, then the rest (an out-run that starts off the run grid), state carried
+        out = torch.zeros_like(y)
+        _, st2 = prog.run_block_stream_major(xs, out=out, n_samples=40)
+        prog.run_block_stream_major(xs, out=out, state=st2, row0=40)
+        assert torch.equal(out, y), (ns, T)
+
+
 @pytest.mark.parametrize("T", [4, 8, 12, 36, 68, 160, 200, 264])
 @pytest.mark.parametrize("name", ["cascade6", "cascade12_two_stages_per_segment", "cascade7_prefix_plus_6", "cascade4_smoothing_one_pole",
                                   "integrator_cascade4_gain", "df2_pair"])
@@ -1522,7 +1559,7 @@ def test_stream_major_pair_body_is_the_default_for_deep_graphs_on_many_streams(t
     assert prog.kernel_name(sm, 1 << 19, 256) == "fz_block_kernel_p2u64b256f384"
     assert prog.kernel_name(sm, 1 << 17, 4096) == "fz_block_kernel_p2u64b256f384"
     assert prog.kernel_name(sm, 3 << 16, 4096).startswith("fz_block_kernel_p1u128b256s6f")
-    assert prog.kernel_name(sm, 1 << 16, 4096).startswith("fz_block_kernel_p1u128b256s6f")
+    assert prog.kernel_name(sm, 1 << 16, 4096).startswith("fz_block_kernel_p1u128b64s6f")     # at most one wave per SIMD of work: one-wave workgroups
     assert prog.kernel_name(sm, (1 << 20) + 1, 4096).startswith("fz_block_kernel_p1u128b256s6f")
     assert prog.kernel_name(sm, 1 << 20, 128).startswith("fz_block_kernel_p1u")
     assert F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u128b256f")
@@ -1723,7 +1760,7 @@ def test_ragged_stream_counts_in_lockstep_workgroups(torch_cuda, F, ns):
         for v in ((4, 1, 256, L | GS | P3), (4, 2, 128, L), (2, 2, 256, L | GS), (2, 4, 64, L)):
             if ns % v[0] == 0:
                 continue
-            assert prog.kernel_name(F.make_variant(*v), ns, T).endswith("f%d" % (v[3] | (1 << 28)))        # (internal flag: FZ_VF_RAGGED)
+            assert prog.kernel_name(F.make_variant(*v), ns, T).endswith("f%d" % (v[3] | (1 << 28) | (1 << 29)))   # (internal flags: FZ_VF_RAGGED, and FZ_VF_ST_MERGE: rows off the 64-byte store grid)
             got, st = run_gpu(torch, F, prog, x, variant=F.make_variant(*v), params=params)
             assert ndiff(got, want) == 0 and torch.equal(st, st0), (ns, v)
             a, st1 = run_gpu(torch, F, prog, x[:17], variant=F.make_variant(*v), params=params)

@@ -244,7 +244,7 @@ def test_stream_major_pair_long_run_body_rules_and_code(tmp_path, monkeypatch):
     assert p.kernel_name(sm, 1 << 19, 256) == "fz_block_kernel_p2u64b256f384"
     assert p.kernel_name(sm, 1 << 17, 4096) == "fz_block_kernel_p2u64b256f384"                       # 256 workgroups of 512 streams: one per CU
     assert p.kernel_name(sm, 3 << 16, 4096).startswith("fz_block_kernel_p1u128b256s6f")           # 384 workgroups: the second round would be half empty
-    assert p.kernel_name(sm, 1 << 16, 4096).startswith("fz_block_kernel_p1u128b256s6f")           # 128 workgroups: half of the CUs idle
+    assert p.kernel_name(sm, 1 << 16, 4096).startswith("fz_block_kernel_p1u128b64s6f")            # the pair body would leave half of the CUs idle; one-wave workgroups at <= one wave per SIMD
     assert p.kernel_name(sm, (1 << 20) + 1, 4096).startswith("fz_block_kernel_p1u128b256s6f")      # an odd count has no pairs
     assert p.kernel_name(sm, 1 << 20, 128).startswith("fz_block_kernel_p1u")                        # shorter than a long-run block
     assert p.kernel_name(F.make_variant(0, 0, 0, SMF | F.C.FZ_VF_SM_SHORT), 1 << 20, 4096).startswith("fz_block_kernel_p1u32")   # anything asked for: as before
@@ -556,7 +556,7 @@ def test_time_major_geometry_follows_the_cu_count():
     derived from the CU count (256 on a box without a GPU) and the measured table; counts just above whole laps run whole laps + a
     remainder launch; counts that are not a multiple of the streams per lane set the internal FZ_VF_RAGGED."""
     p = F.compile(F.from_sexpr(G.df1_cascade(6)))
-    L, GS, P3, RAGGED = F.C.FZ_VF_LOCKSTEP, F.C.FZ_VF_GRID_SYNC, F.C.FZ_VF_PREFETCH3, 1 << 28
+    L, GS, P3, RAGGED, MERGE = F.C.FZ_VF_LOCKSTEP, F.C.FZ_VF_GRID_SYNC, F.C.FZ_VF_PREFETCH3, 1 << 28, 1 << 29
     name = lambda n: p.kernel_name(None, n, 4096, 0)                                   # noqa: E731
     assert name(1 << 18) == "fz_block_kernel_p2u4b512f%d" % (L | GS)
     assert name(3 << 17) == "fz_block_kernel_p2u2b768f%d" % (L | GS)                   # 393 216 = 256 x 768 x 2
@@ -564,8 +564,10 @@ def test_time_major_geometry_follows_the_cu_count():
     assert name(3 << 18) == "fz_block_kernel_p4u1b768f%d" % (L | GS | P3)              # 786 432 = 256 x 768 x 4
     assert name(1_000_000) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)           # 245 workgroups of 1024 lanes
     assert name(1 << 20) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)
-    assert name((1 << 20) + 1) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)       # one lap + a remainder launch of one stream: not ragged
-    assert name(1_000_001) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | RAGGED)  # fits the workgroups: the last lane is partial
+    # rows that start off the 64-byte store grid: FZ_VF_ST_MERGE (stores that let L2 merge the sectors neighbouring waves share)
+    assert name((1 << 20) + 1) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | MERGE)       # one lap + a remainder launch of one stream: not ragged
+    assert name(1_000_001) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | RAGGED | MERGE)  # fits the workgroups: the last lane is partial
+    assert name(1_000_008) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | MERGE) and name(1_000_016) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)
     assert name(1 << 21) == "fz_block_kernel_p2u2b1024f%d" % (L | GS)                  # four laps of two streams per lane (0.75 against 0.70 for two laps of four)
     assert "b1024" not in name(1 << 17) and "f%d" % (L | GS) not in name((1 << 18) - 1024)   # below one wave per SIMD and CU: the few-stream kernels
     # nothing of this on tiles, wide frames, LDS rings

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--tile", type=int, default=0, help="streams per frame tile (0 = time-major)")
+    ap.add_argument("--sm", action="store_true", help="stream-major buffers [stream][t][wire] (fz_run_block_stream_major; FZ_VF_STREAM_MAJOR is added to the flags)")
     ap.add_argument("--prebuild", action="store_true", help="no GPU: build the variants' kernels into the cache (run without torch: the installation's compiler)")
     ap.add_argument("variants", nargs="*", default=["1,8", "2,8", "4,4"])
     a = ap.parse_args()
@@ -47,20 +48,31 @@ def main():
                 vs = prog.tune_candidates(ns, T, a.tile)
             else:
                 t = [int(v) for v in s.split(",")]
-                vs = [F.make_variant(*(t + [0] * (4 - len(t))))]
+                t += [0] * (4 - len(t))
+                if a.sm:
+                    t[3] |= 128
+                vs = [F.make_variant(*t)]
             for v in vs:
                 try:
                     prog.build(v, ns, T, a.tile)
                 except F.FlowzError as e:
                     print(f"# {a.graph} {ns} {s}: refused: {str(e)[:100]}")
         return
-    if a.tile:
+    if a.sm:
+        x = torch.empty((ns, T, max(prog.n_in, 1)), dtype=torch.float32, device="cuda")
+        y = torch.empty((ns, T, prog.n_out), dtype=torch.float32, device="cuda")
+    elif a.tile:
         x = torch.empty((ns // a.tile, T, a.tile, max(prog.n_in, 1)), dtype=torch.float32, device="cuda")
         y = torch.empty((ns // a.tile, T, a.tile, prog.n_out), dtype=torch.float32, device="cuda")
     else:
         x = torch.empty((T, ns, max(prog.n_in, 1)), dtype=torch.float32, device="cuda")
         y = torch.empty((T, ns, prog.n_out), dtype=torch.float32, device="cuda")
-    F.synth_fill(x, 20160512)
+    if a.sm:
+        x.normal_(0.0, 0.1)
+    else:
+        F.synth_fill(x, 20160512)
+    run = (lambda v: prog.run_block_stream_major(x, state=state, params=params, out=y, variant=v)) if a.sm else \
+          (lambda v: prog.run_block(x, state=state, params=params, out=y, variant=v))
     params = None
     if prog.n_param:
         P = W.osc_chain_params(20160513, np.arange(ns))
@@ -77,13 +89,15 @@ def main():
             continue
         t = [int(v) for v in s.split(",")]
         t += [0] * (4 - len(t))
-        vs.append((s, F.make_variant(*t)))
+        if a.sm:
+            t[3] |= 128
+        vs.append((s, F.make_variant(*t) if any(t[:3]) or (t[3] & ~128) else None))
     times = {s: [] for s, _ in vs}
     ok = []
     for s, v in vs:                              # warm (JIT + first touch); a variant the graph / shape refuses is reported and skipped
         try:
-            prog.run_block(x, state=state, params=params, out=y, variant=v)
-            ok.append((s + " " + prog.kernel_name(v if v is not None else prog.plan(ns, a.tile), ns, T, a.tile).replace("fz_block_kernel_", ""), v))
+            run(v)
+            ok.append((s + " " + prog.kernel_name(v if v is not None else (F.make_variant(0, 0, 0, 128) if a.sm else prog.plan(ns, a.tile)), ns, T, a.tile).replace("fz_block_kernel_", ""), v))
         except F.FlowzError as e:
             print(f"# {s}: refused: {str(e)[:120]}")
     vs = ok
@@ -93,7 +107,7 @@ def main():
         for s, v in vs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            prog.run_block(x, state=state, params=params, out=y, variant=v)
+            run(v)
             e1.record()
             torch.cuda.synchronize()
             times[s].append(e0.elapsed_time(e1))
@@ -106,7 +120,7 @@ def main():
     F.copy_probe(xs, ys)
     e1.record()
     torch.cuda.synchronize()
-    print(f"# {a.graph} {ns} streams x {T} samples, tile {a.tile}; B_alg = {b_alg / 1e9:.3f} GB; copy probe "
+    print(f"# {a.graph} {ns} streams x {T} samples, {'stream-major' if a.sm else 'tile ' + str(a.tile)}; B_alg = {b_alg / 1e9:.3f} GB; copy probe "
           f"{2 * n * 4 / (e0.elapsed_time(e1) / 1e3) / 1e9:.0f} GB/s")
     for s, _ in vs:
         ts = sorted(times[s])

@@ -158,6 +158,10 @@ constexpr uint32_t FZ_VF_PERSIST = 1u << 27;
 // internal variant flag: the stream count is not a multiple of the streams per lane -- the last lane's accesses run past the rows' ends,
 // where the per-row buffer descriptors return zeros / drop the writes (frame kernel in lockstep, plain time-major rows)
 constexpr uint32_t FZ_VF_RAGGED = 1u << 28;
+// internal: output rows of plain time-major frames that do not start on the store grid (kStoreGridBytes): neighbouring waves share the
+// sectors / lines at the ends of their footprints, and the frame stores must let L2 merge them (nt instead of nt | sc1; set by
+// finalize_variant, profiles/r04/rows_off_the_grid_store_policy.txt)
+constexpr uint32_t FZ_VF_ST_MERGE = 1u << 29;
 constexpr uint32_t kChipCUs = 256;       // MI355X (gfx950): 8 XCDs x 32 CUs -- what chip_cus() answers on a box without a GPU
 unsigned chip_cus();                     // compute units of the current device (fz_launch.cpp)
 

@@ -15,6 +15,10 @@ namespace fz {
 
 // ---- variant selection ---------------------------------------------------------------------------------
 constexpr uint64_t kMaxLdsBytes = 160 * 1024;
+// Output rows that start off this grid are stored with the merging policy (FZ_VF_ST_MERGE).  Measured, 6-biquad cascade x 4096 samples, nt | sc1
+// against nt alone: rows on the 4-byte grid (1 000 001 streams) 6.94 / 5.90 ms, 16-byte (1 000 004) 6.21 / 5.50, 32-byte (1 000 008) 5.86 / 5.52,
+// 64-byte (1 000 016) 5.39 / 5.43, 128-byte 5.42 / 5.43, 1 048 576 streams 5.48 / 5.52 (profiles/r04/rows_off_the_grid_store_policy.txt)
+constexpr uint64_t kStoreGridBytes = 64;
 constexpr uint32_t kLockstepMinRows = 1024;
 
 // tile_streams: the frame layout the variant is for -- 0 (or >= n_streams) plain time-major rows, else stream tiles (stream-major
@@ -219,6 +223,10 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    // (few streams, one stream per lane, no stage packing: 16 against 32 rows is board-dependent -- the fan-out 4-biquad sum at
    //  65 536 streams measured 0.65 / 0.74 of peak on one board and 0.79 / 0.69 on the next; fz_program_tune tries both)
    if (!reqU && reg_state * v.P > 60) v.U = 8;
+   // LDS rings leave room for one or two waves per SIMD (96 slots x 8 bytes per lane: 98 KiB for a 128-lane workgroup), so the rows in
+   // flight per wave must cover the latency alone: 32 rows per chunk -- 1 M streams x 4096, two combs (40 and 23 samples): 6.45 ms
+   // against 7.27 ms with 16 (0.68 against 0.60 of peak; one stream per lane 6.51 against 6.76; profiles/r04/sweep_next_rows.txt)
+   else if (!reqU && g.n_lds_slots && !(v.flags & FZ_VF_STAGE_PACK)) v.U = 32;
    if (!g.far_lines.empty()) {
       // far (HBM ring) reads are prefetched one chunk ahead: a read must be two chunks old, so the chunk
       // is at most half the youngest ring read (16 steps from kFarMinDelay = 32 on, 4 for a 9-sample read)
@@ -331,6 +339,9 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
          if ((v.flags & FZ_VF_STAGE_PACK) && !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
          // (patch rows: the lag of the in-run -- the skew rounded up to whole float4, at most 12 -- + the run, stride 4 mod 8 floats)
          auto lds_long = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (w.U + 12) * 4; };
+         // at most one wave per SIMD of work: workgroups of ONE wave spread better than the four-wave workgroups whose patches fill a
+         // CU's LDS (65 536 streams x 4096: 0.395 ms against 0.421 ms, 0.68 against 0.64 of peak; profiles/r04/stream_major_few_streams.txt)
+         if (!reqB && n_streams <= (uint64_t)chip_cus() * 256u) v.block = 64;
          while (lds_long(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
          if (lds_long(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: the LDS patches do not fit this block size");
          return v;
@@ -416,6 +427,12 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
       //  straddled boundaries; profiles/r04/rows_off_the_grid.txt)
       v.flags &= ~FZ_VF_RAGGED;
       if ((v.flags & FZ_VF_LOCKSTEP) && !tile_streams && !stream_major && lockstep_streams(p->g, uv, v, n_streams) % v.P) v.flags |= FZ_VF_RAGGED;
+      // output rows off the store grid: stores that let L2 merge the sectors neighbouring waves share (see fz_block_kernel.hip.inc)
+      v.flags &= ~FZ_VF_ST_MERGE;
+      if (!tile_streams && !stream_major) {
+         const uint64_t out_row_bytes = n_streams * (uint64_t)std::max<uint32_t>(g.n_out, 1) * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 8u : 4u);
+         if (out_row_bytes % kStoreGridBytes) v.flags |= FZ_VF_ST_MERGE;
+      }
       static const bool kernel_laps = [] { const char* e = std::getenv("FLOWZ_HIP_LAPS"); return e && std::strcmp(e, "kernel") == 0; }();
       v.flags &= ~FZ_VF_PERSIST;
       if (kernel_laps && (v.flags & FZ_VF_GRID_SYNC) && ((n_streams + v.P - 1) / v.P + v.block - 1) / v.block > chip_cus()) v.flags |= FZ_VF_PERSIST;
