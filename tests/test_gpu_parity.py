@@ -1660,7 +1660,7 @@ def test_sample_rate_modulators_through_the_chunked_host_paths(torch_cuda, F):
         prog.bank(ns).process_host(xd.cpu().numpy())
 
 
-@pytest.mark.parametrize("name", ["cascade2", "cross_wire", "osc_chain"])
+@pytest.mark.parametrize("name", ["cascade2", "cross_wire", "osc_chain", "par4_sum"])
 def test_time_major_lockstep_workgroups_vs_oracle(torch_cuda, F, name):
     """FZ_VF_LOCKSTEP (round 3): CU-wide workgroups of 1024 lanes that meet at a barrier after every chunk -- the library's
     choice for plain time-major frames of many streams.  Ragged stream counts (a last workgroup with lanes AND whole waves
@@ -1669,7 +1669,7 @@ def test_time_major_lockstep_workgroups_vs_oracle(torch_cuda, F, name):
     torch = torch_cuda
     from zignal_amd import _capi
     L = _capi.FZ_VF_LOCKSTEP
-    g = {"cascade2": lambda: G.df1_cascade(2), "cross_wire": G.cross_wire, "osc_chain": lambda: G.osc_chain(6)}[name]()
+    g = {"cascade2": lambda: G.df1_cascade(2), "cross_wire": G.cross_wire, "osc_chain": lambda: G.osc_chain(6), "par4_sum": G.par4_sum}[name]()
     prog = F.compile(F.from_sexpr(g))
     for ns, T in ((1024 * 4 + 260, 37), (3000, 64), (5000, 1), (2048, 130)):
         x = O.synth_input(SEED + 31, np.arange(ns), T, n_wires=max(prog.n_in, 1))
@@ -1720,7 +1720,18 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     # stage-packed (packing by stages costs no registers per stream)
     assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s6f%d" % (LG | _capi.FZ_VF_STAGE_PACK)
     assert F.compile(F.from_sexpr(G.osc_chain(8))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s8f%d" % (LG | _capi.FZ_VF_STAGE_PACK)
-    assert F.compile(F.from_sexpr(G.par4_sum())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u32b256f0"
+    # wide frames (round 4): one stream per lane in 1024-lane workgroups; the default on 4-wire frames equals the four-wave workgroups, laps and remainder included
+    p4 = F.compile(F.from_sexpr(G.par4_sum()))
+    assert p4.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u2b1024f%d" % LG and p4.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p1u1b1024f%d" % (LG | _capi.FZ_VF_PREFETCH3)
+    ns, T = (1 << 18) + 1024 + 5, 1030
+    x4 = torch.empty((T, ns, 4), dtype=torch.float32, device="cuda")
+    F.synth_fill(x4, SEED + 35)
+    y4, s4 = p4.run_block(x4)
+    y40, s40 = p4.run_block(x4, variant=F.make_variant(1, 16, 256))
+    assert torch.equal(y4, y40) and torch.equal(s4, s40)
+    ids = np.array([0, 63, 1024, 262143, 262144, ns - 1])
+    assert ndiff(y4[:, torch.as_tensor(ids, device="cuda")].cpu().numpy(), O.compile(G.par4_sum(), len(ids)).run(O.synth_input(SEED + 35, ids, T, n_wires=4))) == 0
+    del x4, y4, y40
     # more blocks than the chip holds workgroups (300 of 1024 lanes): two laps, a launch each with counters of its own
     ns, T = 300 * 1024 + 64, 40
     x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")

@@ -570,9 +570,14 @@ def test_time_major_geometry_follows_the_cu_count():
     assert name(1_000_008) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | MERGE) and name(1_000_016) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)
     assert name(1 << 21) == "fz_block_kernel_p2u2b1024f%d" % (L | GS)                  # four laps of two streams per lane (0.75 against 0.70 for two laps of four)
     assert "b1024" not in name(1 << 17) and "f%d" % (L | GS) not in name((1 << 18) - 1024)   # below one wave per SIMD and CU: the few-stream kernels
-    # nothing of this on tiles, wide frames, LDS rings
+    # nothing of this on tiles and LDS rings
     assert p.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % F.C.FZ_VF_MAX_WG(2)
-    assert F.compile(F.from_sexpr(G.par4_sum())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u32b256f0"
+    assert F.compile(F.from_sexpr(G.lds_ring_comb())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p2u32b128f0"
+    # wide frames (the 4-wire sum): one stream per lane in 1024-lane workgroups; one lap: one row per buffer, more: chunks of two rows
+    p4 = F.compile(F.from_sexpr(G.par4_sum()))
+    assert p4.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p1u1b1024f%d" % (L | GS | P3)
+    assert p4.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u2b1024f%d" % (L | GS)
+    assert p4.kernel_name(None, 1 << 16, 4096, 0) == "fz_block_kernel_p1u16b256f0" and p4.kernel_name(None, 1 << 20, 4096, 4096) == "fz_block_kernel_p1u32b256f0"
     # a register-heavy graph steps down: with many per-stream coefficients (the oscillator chain: 31) straight to one stream per lane,
     # stage-packed (packing by stages costs no registers per stream)
     assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s6f%d" % (L | GS | F.C.FZ_VF_STAGE_PACK)

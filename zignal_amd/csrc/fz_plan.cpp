@@ -187,14 +187,20 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // (short blocks -- control-rate windows -- run free: the walk in step needs about a thousand rows to pay for its start.  1 M
       //  streams, lockstep against free-running four-wave workgroups: 64-sample windows 0.57 / 0.77 of peak, 256 rows 0.60 / 0.66,
       //  512 rows 0.64 / 0.66, 1024 rows level, 4096 rows 0.76 / 0.66 -- profiles/r04/sweep_block_lengths.txt)
-      if (allow_lockstep && nothing_asked && !tile_streams && n_samples >= kLockstepMinRows && n_streams >= (uint64_t)chip_cus() * 1024u && g.n_in <= 2 && g.n_out <= 2 &&
+      // WIDE frames (three to eight wires; round 4): one stream per lane, 1024-lane workgroups.  Round 3 left them to the free-running
+      // workgroups ("their rows are wide already"); measured with laps as launches, the 4-wire sum x 4096 samples: 262 144 streams 3.36 ms
+      // against 3.95 ms (0.80 against 0.68 of peak), 1 000 000 streams 13.57 against 14.86 ms (0.76 / 0.69), 1 048 576 streams level
+      // (14.61 / 14.68 ms: rows exactly 16 MiB apart) -- profiles/r04/wide_frames_in_lockstep.txt.  One row per buffer and three buffers
+      // in one lap, chunks of two rows from two laps on (1 M streams: 14.61 against 15.03 ms).
+      const bool wide = (g.n_in > 2 || g.n_out > 2) && g.n_in <= 8 && g.n_out <= 8 && !g.typed;
+      if (allow_lockstep && nothing_asked && !tile_streams && n_samples >= kLockstepMinRows && n_streams >= (uint64_t)chip_cus() * 1024u && ((g.n_in <= 2 && g.n_out <= 2) || wide) &&
           g.far_lines.empty() && g.n_lds_slots == 0 && !(g.typed && (n_streams % 4))) {
-         const uint32_t cap = allow_lockstep >= 3 ? 4u : allow_lockstep;
+         const uint32_t cap = wide ? 1u : allow_lockstep >= 3 ? 4u : allow_lockstep;
          const TmGeometry geo = time_major_geometry(n_streams, cap, g.n_ops > 30, !g.typed);
          v.P = geo.P;
-         v.U = geo.U;
+         v.U = wide ? (geo.laps > 1 ? 2u : 1u) : geo.U;
          v.block = geo.lanes;
-         v.flags |= FZ_VF_LOCKSTEP | (geo.U == 1 ? (uint32_t)FZ_VF_PREFETCH3 : 0u);
+         v.flags |= FZ_VF_LOCKSTEP | (v.U == 1 ? (uint32_t)FZ_VF_PREFETCH3 : 0u);
          v.flags |= FZ_VF_GRID_SYNC;
          if (v.P == 1 && g.split.ok && n_samples >= 16u * (g.split.atoms() - 1)) {
             v.flags |= FZ_VF_STAGE_PACK;
