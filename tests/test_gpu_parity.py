@@ -1518,9 +1518,9 @@ def test_stream_major_pair_long_run_kernel_vs_oracle(torch_cuda, F, name):
     # (a graph whose registers do not fit next to the 256 staging registers runs the one-stream long-run body instead: the 12-stage
     #  cascade does with the compiler bundled with the PyTorch wheel, not with the ROCm installation's)
     kn = prog.kernel_name(F.make_variant(2, 64, 0, SM_LONG | 128), 1024, 512)
-    assert kn.startswith(("fz_block_kernel_p2u64b256f", "fz_block_kernel_p1u128b256")), kn
+    assert kn.startswith(("fz_block_kernel_p2u64b64f", "fz_block_kernel_p1u128b64")), kn
     if name in ("cascade6", "df1"):
-        assert kn.startswith("fz_block_kernel_p2u64b256f"), kn
+        assert kn.startswith("fz_block_kernel_p2u64b64f"), kn
     for ns, T in ((334, 256), (2, 388), (778, 300), (130, 128), (64, 124), (1026, 640)):
         x = O.synth_input(SEED + 101, np.arange(ns), T)
         want = O.compile(g, ns).run(x)
@@ -1555,15 +1555,15 @@ def test_stream_major_pair_body_is_the_default_for_deep_graphs_on_many_streams(t
     torch = torch_cuda
     sm = F.make_variant(0, 0, 0, 128)
     prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
-    assert prog.kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b256f384"
-    assert prog.kernel_name(sm, 1 << 19, 256) == "fz_block_kernel_p2u64b256f384"
-    assert prog.kernel_name(sm, 1 << 17, 4096) == "fz_block_kernel_p2u64b256f384"
-    assert prog.kernel_name(sm, 3 << 16, 4096).startswith("fz_block_kernel_p1u128b256s6f")
+    assert prog.kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b64f384"
+    assert prog.kernel_name(sm, 1 << 19, 256) == "fz_block_kernel_p2u64b64f384"
+    assert prog.kernel_name(sm, 1 << 17, 4096) == "fz_block_kernel_p2u64b64f384"
+    assert prog.kernel_name(sm, 3 << 16, 4096).startswith("fz_block_kernel_p1u128b64s6f")
     assert prog.kernel_name(sm, 1 << 16, 4096).startswith("fz_block_kernel_p1u128b64s6f")     # at most one wave per SIMD of work: one-wave workgroups
-    assert prog.kernel_name(sm, (1 << 20) + 1, 4096).startswith("fz_block_kernel_p1u128b256s6f")
+    assert prog.kernel_name(sm, (1 << 20) + 1, 4096).startswith("fz_block_kernel_p1u128b64s6f")
     assert prog.kernel_name(sm, 1 << 20, 128).startswith("fz_block_kernel_p1u")
-    assert F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u128b256f")
-    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b256f384"   # per-stream coefficients ride along as packed pairs (round 4)
+    assert F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u128b64f")
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b64f384"   # per-stream coefficients ride along as packed pairs (round 4)
     ns, T = (1 << 19) + 130, 644
     x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
     F.synth_fill(x, SEED + 7)

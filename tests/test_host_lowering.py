@@ -240,16 +240,16 @@ def test_stream_major_pair_long_run_body_rules_and_code(tmp_path, monkeypatch):
     SMF, LONG = F.C.FZ_VF_STREAM_MAJOR, F.C.FZ_VF_SM_LONG
     sm = F.make_variant(0, 0, 0, SMF)
     p = F.compile(F.from_sexpr(G.df1_cascade(6)))
-    assert p.kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b256f384"
-    assert p.kernel_name(sm, 1 << 19, 256) == "fz_block_kernel_p2u64b256f384"
-    assert p.kernel_name(sm, 1 << 17, 4096) == "fz_block_kernel_p2u64b256f384"                       # 256 workgroups of 512 streams: one per CU
-    assert p.kernel_name(sm, 3 << 16, 4096).startswith("fz_block_kernel_p1u128b256s6f")           # 384 workgroups: the second round would be half empty
+    assert p.kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b64f384"
+    assert p.kernel_name(sm, 1 << 19, 256) == "fz_block_kernel_p2u64b64f384"
+    assert p.kernel_name(sm, 1 << 17, 4096) == "fz_block_kernel_p2u64b64f384"                       # 1024 one-wave workgroups of 128 streams: one wave per SIMD
+    assert p.kernel_name(sm, 3 << 16, 4096).startswith("fz_block_kernel_p1u128b64s6f")           # 384 workgroups: the second round would be half empty
     assert p.kernel_name(sm, 1 << 16, 4096).startswith("fz_block_kernel_p1u128b64s6f")            # the pair body would leave half of the CUs idle; one-wave workgroups at <= one wave per SIMD
-    assert p.kernel_name(sm, (1 << 20) + 1, 4096).startswith("fz_block_kernel_p1u128b256s6f")      # an odd count has no pairs
+    assert p.kernel_name(sm, (1 << 20) + 1, 4096).startswith("fz_block_kernel_p1u128b64s6f")      # an odd count has no pairs
     assert p.kernel_name(sm, 1 << 20, 128).startswith("fz_block_kernel_p1u")                        # shorter than a long-run block
     assert p.kernel_name(F.make_variant(0, 0, 0, SMF | F.C.FZ_VF_SM_SHORT), 1 << 20, 4096).startswith("fz_block_kernel_p1u32")   # anything asked for: as before
-    assert F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u128b256f")     # shallow graphs
-    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b256f384"              # per-stream coefficients ride along as packed pairs (round 4)
+    assert F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(sm, 1 << 20, 4096).startswith("fz_block_kernel_p1u128b64f")     # shallow graphs
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(sm, 1 << 20, 4096) == "fz_block_kernel_p2u64b64f384"              # per-stream coefficients ride along as packed pairs (round 4)
     for bad in (F.make_variant(2, 128, 0, SMF | LONG), F.make_variant(2, 32, 0, SMF | LONG)):
         with pytest.raises(F.FlowzError):
             p.kernel_name(bad, 1024, 512)
@@ -258,7 +258,7 @@ def test_stream_major_pair_long_run_body_rules_and_code(tmp_path, monkeypatch):
     with pytest.raises(F.FlowzError):
         F.compile(F.from_sexpr(G.par4_sum())).kernel_name(F.make_variant(2, 64, 0, SMF | LONG), 1024, 512)   # 4-wire frames
     r = p.kernel_resources(F.make_variant(2, 64, 0, SMF | LONG), 1 << 20, 4096)
-    assert r["scratch_bytes"] == 0 and r["lds_bytes"] == 4 * 64 * (2 * 64 + 4) * 4 and r["vgprs"] <= 512 and r["unroll"] == 64
+    assert r["scratch_bytes"] == 0 and r["lds_bytes"] == 64 * (2 * 64 + 4) * 4 and r["vgprs"] <= 512 and r["unroll"] == 64
     obj = [o for o in tmp_path.glob("*.hsaco")
            if p.kernel_symbol(F.make_variant(2, 64, 0, SMF | LONG), 1 << 20, 4096) in subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(o)], text=True)][0]
     dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", str(obj)], text=True)

@@ -4,7 +4,7 @@
 # simply misses and is built again).  Round 4: 784 GPU tests take 550-785 s on a box that JITs ~1800 kernels through the compiler worker, 80 s with them cached.
 #   usage (here):  gpurun -- 'bash tools/harvest_kcache.sh [dir]'  &&  cp -n gpurun_out/<dir>/kcache/*.hsaco zignal_amd/_kcache/
 set -u
-cd "$(dirname "$0")/../.."
+cd "$(dirname "$0")/.."
 O=gpurun_out/${1:-harvest}; mkdir -p $O/kcache
 touch /tmp/fz_marker; sleep 1
 timeout 1500 python -m pytest tests -m gpu -x -q --durations=60 > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt

@@ -325,6 +325,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
          if (!pair_ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG with two streams per lane: needs a 1-in/1-out float graph (not fz_compile_typed), no delay lines beyond 8 samples");
          if (reqU && reqU != 64) fail(FZ_E_INVALID, "FZ_VF_SM_LONG with two streams per lane: unroll must be 64");
          v.U = 64;
+         if (!reqB) v.block = 64;                          // one-wave workgroups (see the one-stream body below)
          auto lds_pair = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (2 * w.U + 4) * 4; };
          while (lds_pair(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
          if (lds_pair(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: the LDS patches do not fit this block size");
@@ -345,9 +346,13 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
          if ((v.flags & FZ_VF_STAGE_PACK) && !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
          // (patch rows: the lag of the in-run -- the skew rounded up to whole float4, at most 12 -- + the run, stride 4 mod 8 floats)
          auto lds_long = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (w.U + 12) * 4; };
-         // at most one wave per SIMD of work: workgroups of ONE wave spread better than the four-wave workgroups whose patches fill a
-         // CU's LDS (65 536 streams x 4096: 0.395 ms against 0.421 ms, 0.68 against 0.64 of peak; profiles/r04/stream_major_few_streams.txt)
-         if (!reqB && n_streams <= (uint64_t)chip_cus() * 256u) v.block = 64;
+         // Workgroups of ONE wave (round 4, both long-run bodies): the patches of four waves fill a CU's LDS, so a four-wave workgroup
+         // can only start when four waves have finished, a one-wave workgroup whenever one has -- the CU refills wave by wave.  Measured,
+         // 6-biquad cascade x 4096, 64 / 128 / 256 lanes: 1 M streams 6.11 / 6.16 / 6.19 ms, 786 432 4.55 / 4.59 / 4.66, 262 144 1.60-1.67 /
+         // 1.69-1.71 / 1.72, 65 536 0.395 / 0.409 / 0.421; 1 M x 1024 rows 1.67 / 1.70 / 1.72; two biquads 5.45 / 5.51 / 5.59 (262 144: 1.47 /
+         // 1.50 / 1.53); oscillator chain 6.63 / 6.68 / 6.75; one biquad level (profiles/r04/stream_major_few_streams.txt,
+         // stream_major_workgroup_sizes.txt)
+         if (!reqB) v.block = 64;
          while (lds_long(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
          if (lds_long(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: the LDS patches do not fit this block size");
          return v;
