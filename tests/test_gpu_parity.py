@@ -78,7 +78,25 @@ def test_tests_cpp_known_answers_per_sample_calls(F, case):
 
 
 # ---- golden vectors produced by the reference's own hand-written filters ------------------------
-FORMS = {"df1": G.df1, "df2": G.df2, "df1t": G.df1t, "df1x2": lambda: G.seq(G.df1(), G.df1())}
+FORMS = {"df1": G.df1, "df2": G.df2, "df1t": G.df1t, "df1x2": lambda: G.seq(G.df1(), G.df1()),
+         "df1x6": lambda: G.seq(*[G.df1() for _ in range(6)])}       # six reference DF1 closures in series: the headline workload's shape
+
+
+@pytest.mark.parametrize("drive", ["dirac", "noise"])
+def test_reference_golden_vectors_four_closures_side_by_side(torch_cuda, F, drive):
+    """Config 3's shape against a composition of the reference's own DF1 closures (four instances, outputs summed left to right),
+    every lane packing, and through stream-major buffers (the hold body: 201 / 1024 rows)."""
+    g = G.seq(G.par(G.df1(), G.df1(), G.df1(), G.df1()), G.add(G.add(G.add(G.IN(1), G.IN(2)), G.IN(3)), G.IN(4)))
+    x = np.ascontiguousarray(np.repeat(bits(REF["inputs4"][drive]).reshape(-1, 1, 4), 2, axis=1))      # the same four wires on two streams
+    want = bits(REF["outputs4"][drive]["par4"])
+    prog = F.compile(F.from_sexpr(g))
+    for v in (None, F.make_variant(1, 8), F.make_variant(2, 4)):
+        y, _ = run_gpu(torch_cuda, F, prog, x, variant=v)
+        assert ndiff(y[:, 0, 0], want) == 0 and ndiff(y[:, 1, 0], want) == 0
+    T4 = (x.shape[0] // 4) * 4
+    xs = torch_cuda.from_numpy(np.ascontiguousarray(np.transpose(x[:T4], (1, 0, 2)))).cuda()
+    ys, _ = prog.run_block_stream_major(xs)
+    assert ndiff(ys[0, :, 0].cpu().numpy(), want[:T4]) == 0
 
 
 @pytest.mark.parametrize("drive", ["dirac", "noise"])

@@ -30,6 +30,7 @@ def test_c_closures_vs_reference_lambdas(drive):
     out = REF["outputs"][drive]
     assert same(C.df1_cascade([REFC], x)[:, 0, 0], bits(out["df1"]))
     assert same(C.df1_cascade([REFC, REFC], x)[:, 0, 0], bits(out["df1x2"]))
+    assert same(C.df1_cascade([REFC] * 6, x)[:, 0, 0], bits(out["df1x6"]))       # six reference closures in series (a composition: oracle/ref_harness.inc)
     assert same(C.df2(REFC, x)[:, 0, 0], bits(out["df2"]))
     assert same(C.df1t(REFC, x)[:, 0, 0], bits(out["df1t"]))
     y = C.cross_wire(x)

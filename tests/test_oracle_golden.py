@@ -43,7 +43,21 @@ def test_reference_coefficients():
     assert [G.B0, G.B1, G.B2, G.A1, G.A2] == list(c)
 
 
-FORMS = {"df1": G.df1, "df2": G.df2, "df1t": G.df1t, "df1x2": lambda: G.seq(G.df1(), G.df1())}
+FORMS = {"df1": G.df1, "df2": G.df2, "df1t": G.df1t, "df1x2": lambda: G.seq(G.df1(), G.df1()),
+         "df1x6": lambda: G.seq(*[G.df1() for _ in range(6)])}       # six reference DF1 closures in series: the headline workload's shape
+
+
+def ref_par4():
+    """Four reference DF1 closures side by side on four input wires, summed left to right (config 3's shape)."""
+    return G.seq(G.par(G.df1(), G.df1(), G.df1(), G.df1()), G.add(G.add(G.add(G.IN(1), G.IN(2)), G.IN(3)), G.IN(4)))
+
+
+@pytest.mark.parametrize("drive", ["dirac", "noise"])
+def test_par4_bitwise_vs_four_reference_lambdas(drive):
+    """(bq|bq|bq|bq) |= (_1+_2+_3+_4) against a composition of the reference's own DF1 closures (oracle/ref_harness.inc: zref_par4)."""
+    x = bits(REF["inputs4"][drive]).reshape(-1, 1, 4)
+    got = O.compile(ref_par4()).run(x)[:, 0, 0]
+    assert np.array_equal(got.view(np.uint32), bits(REF["outputs4"][drive]["par4"]).view(np.uint32))
 
 
 @pytest.mark.parametrize("drive", ["dirac", "noise"])
