@@ -1,4 +1,5 @@
 #!/bin/bash
+# (NOTE: the kernel / generator knob this script drives was an experiment and has been taken out again -- profiles/NOTES.md, "What the lone waves wait for"; kept as the record of what was run)
 # GPU box, round 4: the pair body with the waves of a CU started a quarter of a phase apart (-DFZ_DBG_STAGGER): 262 144 streams are two rounds of waves that
 # all start together, so the in-runs and out-runs of the whole chip come in bursts.
 set -u

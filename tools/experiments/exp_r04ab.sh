@@ -1,4 +1,5 @@
 #!/bin/bash
+# (NOTE: the kernel / generator knob this script drives was an experiment and has been taken out again -- profiles/NOTES.md, "What the lone waves wait for"; kept as the record of what was run)
 # GPU box, round 4: LDS ring reads shorter than the chunk forwarded from registers (no step of a chunk waits for an LDS round trip): parity of every
 # test that touches rings / delays, then the lds_ring graph of the bench line.
 set -u

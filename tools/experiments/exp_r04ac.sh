@@ -1,4 +1,5 @@
 #!/bin/bash
+# (NOTE: the kernel / generator knob this script drives was an experiment and has been taken out again -- profiles/NOTES.md, "What the lone waves wait for"; kept as the record of what was run)
 # GPU box, round 4: forwarded short ring reads against reads in place (FLOWZ_HIP_NO_RING_FORWARD=1), the same box, alternating.
 set -u
 cd "$(dirname "$0")/../.."

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (NOTE: the kernel / generator knob this script drives was an experiment and has been taken out again -- profiles/NOTES.md, "What the lone waves wait for"; kept as the record of what was run)
 # GPU box, round 4: what the lone waves of the few-stream frame kernels wait for.  (1) -DFZ_DBG_PRIME_VMCNT: dummy stores in the preheader so that the waitcnt
 # pass's merged state at the loop header is exact; (2) -DFZ_DBG_KEEP_STORE_REGS: output registers of their own for every row of the chunk buffers
 # (a frame store's data registers are guarded by vmcnt: re-used registers wait for the store to COMPLETE); (3) store policies with fast acknowledgement.

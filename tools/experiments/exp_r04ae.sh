@@ -1,4 +1,5 @@
 #!/bin/bash
+# (NOTE: the kernel / generator knob this script drives was an experiment and has been taken out again -- profiles/NOTES.md, "What the lone waves wait for"; kept as the record of what was run)
 # GPU box, round 4: -DFZ_DBG_PRIME_VMCNT (dummy stores in the preheader of the chunk loop: the waitcnt pass's merged state at the loop header becomes exact)
 # against the plain kernels, alternating processes on one box: kernels of one or two waves per SIMD.
 set -u
