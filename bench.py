@@ -40,6 +40,7 @@ os.environ.setdefault("FLOWZ_HIP_NO_PLAN_CACHE", "1")
 
 HBM_PEAK_GBS = 8000.0
 PARITY_STREAMS = 1024
+PARITY_STREAMS_OTHER_RANKS = 128
 
 
 # ---- CPU baseline --------------------------------------------------------------------------------------------------
@@ -350,15 +351,18 @@ def _profile_table(name):
     return json.load(open(path)) if os.path.exists(path) else {}
 
 
-def traffic_of(kernel, workload_key):
-    """PMC HBM bytes per launch of exactly this kernel symbol on this workload (profiles/pmc_traffic.json), or None."""
-    return _profile_table("pmc_traffic.json").get(f"{kernel}|{workload_key}")
-
-
-def issue_share_of(kernel, workload_key):
-    """SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of this kernel on this workload from the committed counter passes
-    (profiles/sq_issue_share.json), or None."""
-    return _profile_table("sq_issue_share.json").get(f"{kernel}|{workload_key}")
+def counters_of(code_id, workload_key):
+    """Counter-derived figures of EXACTLY this code on this workload, or ({}, None): profiles/pmc_traffic.json and sq_issue_share.json
+    are keyed '<code id>|<workload>', the code id being the hash of (generated source, build options, compiler) that names the kernel's
+    code object (fz_program_kernel_code_id) -- a kernel whose body changed since the counter passes has another id and reports null,
+    never last week's numbers.  Returns ({"traffic": bytes per block, "issue_share": x}, "file(s) @ commit the passes ran on")."""
+    out, src = {}, []
+    for name, field in (("pmc_traffic.json", "traffic"), ("sq_issue_share.json", "issue_share")):
+        e = _profile_table(name).get(f"{code_id}|{workload_key}")
+        if isinstance(e, dict) and "value" in e:
+            out[field] = e["value"]
+            src.append(f"profiles/{name} ({e.get('batch', '?')} @ {e.get('commit', '?')})")
+    return out, ("; ".join(src) if src else None)
 
 
 def limiter_of(issue_share, board, frac_of_row_walk):
@@ -371,6 +375,92 @@ def limiter_of(issue_share, board, frac_of_row_walk):
     if board and board.get("at_power_cap") and frac_of_row_walk is not None and frac_of_row_walk < 0.97:
         return "power"
     return "hbm"
+
+
+
+# ---- the line the driver parses ------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096                                            # bytes: the driver keeps the tail of stdout; round 4's 31 KB line did not survive it
+CONTRACT_KEYS = ("metric", "value", "unit", "per_gpu", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data")
+SHORT = {"config2_65536_streams": "config2", "cascade6_32768_streams": "cascade6_32768", "cascade6_16384_streams": "cascade6_16384",
+         "config3_par4_sum": "config3", "config3_par4_sum_fanout": "config3_fanout", "config4_osc_chain": "config4",
+         "ragged_counts": "ragged", "reference_benchmark_topologies": "ref", "next_rows": "", "other_shapes": "", "stream_major_layout": "stream_major",
+         "tiled_layout": "tiled", "time_major_layout": "time_major"}
+
+
+def flatten_legs(d, prefix=""):
+    """(name, leg) for every leg object (a dict holding `library_default` or `forced`) below `d`, depth first; names are the
+    path of keys, shortened by SHORT, joined with '_'"""
+    out = []
+    for k, v in d.items():
+        if not isinstance(v, dict):
+            continue
+        name = SHORT.get(k, k)
+        path = "_".join(x for x in (prefix, name) if x)
+        if "library_default" in v or "forced" in v:
+            # an object with sub-layouts names its own layout too: config2 -> config2_tiled, config2_time_major, config2_stream_major
+            subs = {kk: vv for kk, vv in v.items() if kk in ("time_major", "stream_major", "other_shapes")}
+            out.append((path + "_" + v.get("layout", "tiled") if ("time_major" in subs or "stream_major" in subs) else path, v))
+            out += flatten_legs(subs, path)
+        else:
+            out += flatten_legs(v, path)
+    return out
+
+
+def compact_line(full, details_path=None):
+    """The ONE line of stdout: the driver's contract keys, config, roofline, cpu_baseline, parity and one flat `summary` map
+    {object: library-default fraction of the HBM peak}; everything else lives in bench_details.json.  Always < LINE_LIMIT bytes."""
+    line = {k: full[k] for k in CONTRACT_KEYS if k in full}
+    c = full.get("config", {})
+    line["config"] = {k: c[k] for k in ("workload", "layout", "streams_per_gpu", "block_samples", "streams_total", "parallelism") if k in c}
+    r = full.get("roofline", {})
+    line["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "code_id", "workload_key", "algorithmic_bytes_per_launch", "avg_launch_ms", "traffic",
+                                             "traffic_source", "limiter", "issue_share", "measured_row_walk_GBs", "frac_of_row_walk", "measured_copy_GBs")}
+    sus = r.get("sustained")
+    if sus:
+        b = sus.get("board") or {}
+        line["roofline"]["sustained"] = {"frac": sus.get("frac"), "seconds": sus.get("seconds"), "avg_launch_ms": sus.get("avg_launch_ms"), "package_W": b.get("package_W"),
+                                         "cap_W": b.get("cap_W"), "sclk_MHz": b.get("sclk_MHz"), "joules_per_launch": sus.get("joules_per_launch")}
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:200]}
+        v = cb.get("vectorised_across_streams") or {}
+        if "value" in v:
+            line["cpu_baseline"]["vectorised_across_streams"] = v["value"]
+    for k in ("parity", "checksum", "rccl_ranks", "dist_backend", "ms_per_step_per_rank"):
+        if k in full:
+            line[k] = full[k]
+    legs = flatten_legs({k: v for k, v in full.items() if k not in ("config", "roofline", "cpu_baseline")})
+    if legs:
+        summary, gain, bad, joules = {}, {}, [], {}
+        for name, leg_ in legs:
+            base = leg_.get("library_default") or leg_.get("forced")
+            summary[name] = round(base["frac"], 3)
+            if "tuned" in leg_ and leg_["tuned"]["frac"] > base["frac"] + 0.01:
+                gain[name] = round(leg_["tuned"]["frac"] - base["frac"], 3)
+            if not str(leg_.get("parity", "")).startswith("bitwise-equal"):
+                bad.append(name)
+            j = (leg_.get("sustained") or {}).get("joules_per_launch")
+            if j:
+                joules[name] = j
+        line["summary"] = summary
+        line["summary_note"] = "fraction of 8 TB/s, library-default plan, HIP-event time, full BASELINE sizes; per-object detail in " + (details_path or "bench_details.json")
+        line["tuned_gain_over_default"] = gain                 # objects whose measured plan beat the default by > 0.01 (empty: none)
+        line["parity_objects"] = f"bitwise-equal on all {len(legs)} objects" if not bad else "MISMATCH in " + ",".join(bad)
+        if joules:
+            line["joules_per_launch"] = joules
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) >= LINE_LIMIT:                                # never again: drop the optional maps before the contract keys suffer
+        for k in ("joules_per_launch", "tuned_gain_over_default", "summary_note", "ms_per_step_per_rank"):
+            line.pop(k, None)
+            txt = json.dumps(line, separators=(",", ":"))
+            if len(txt) < LINE_LIMIT:
+                break
+    if len(txt) >= LINE_LIMIT:
+        line["summary"] = dict(list(line["summary"].items())[:40])
+        txt = json.dumps(line, separators=(",", ":"))
+    assert len(txt) < LINE_LIMIT, len(txt)
+    return txt
 
 
 # ---- workloads ---------------------------------------------------------------------------------------------------------
@@ -472,12 +562,15 @@ def leg(cx, sp, layout, tile=0, tune=True, forced=None, energy=False, reps_ms=60
             prog.run_block(x, state=state, params=pd, out=y, variant=mk(v))
 
     def name_of(v):
+        """(symbol, code id) of the kernel a launch with variant v runs"""
         if bank is not None:
-            return prog.kernel_symbol(mk(v), ns, sp.blocks[0], tile)
-        if sm:
+            a = (mk(v), ns, sp.blocks[0], tile)
+        elif sm:
             q = mk(v) or F.make_variant(0, 0, 0, 0)
-            return prog.kernel_symbol(F.make_variant(q.streams_per_lane, q.unroll, q.block_threads, q.flags | SMF), ns, T)
-        return prog.kernel_symbol(mk(v) if v is not None else prog.plan(ns, tile), ns, T, tile)
+            a = (F.make_variant(q.streams_per_lane, q.unroll, q.block_threads, q.flags | SMF), ns, T)
+        else:
+            a = (mk(v) if v is not None else prog.plan(ns, tile), ns, T, tile)
+        return prog.kernel_symbol(*a), prog.kernel_code_id(*a)
 
     b = sp.b_alg(prog)
 
@@ -489,9 +582,11 @@ def leg(cx, sp, layout, tile=0, tune=True, forced=None, energy=False, reps_ms=60
         reps = max(5, min(400, int(math.ceil(reps_ms / max(ms1, 1e-3)))))
         event_ms(torch, lambda: run(v), max(3, reps // 2))   # warm-up of the same kind as the timed region (sub-millisecond kernels: clocks and queues settle over dozens of launches)
         ms = event_ms(torch, lambda: run(v), reps)
-        k = name_of(v)
-        return {"kernel": k, "avg_launch_ms": round(ms, 4), "Msamples_per_s": round(ns * T / ms / 1e3, 1), "achieved_GBs": round(b / ms / 1e6, 1),
-                "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic_of(k, wkey), "launches_timed": reps}
+        k, cid = name_of(v)
+        cnt, csrc = counters_of(cid, wkey)
+        return {"kernel": k, "code_id": cid, "avg_launch_ms": round(ms, 4), "Msamples_per_s": round(ns * T / ms / 1e3, 1), "achieved_GBs": round(b / ms / 1e6, 1),
+                "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": cnt.get("traffic"), "issue_share": cnt.get("issue_share"), "traffic_source": csrc,
+                "launches_timed": reps}
 
     res = {}
     best_v = forced
@@ -523,7 +618,7 @@ def leg(cx, sp, layout, tile=0, tune=True, forced=None, energy=False, reps_ms=60
         n_sus, ms_tot, board = sustained_run(torch, lambda: run(best_v), res[best]["avg_launch_ms"], dev.index or 0, seconds=1.5)
         res["sustained"] = {"launches": n_sus, "avg_launch_ms": round(ms_tot / n_sus, 4), "frac": round(b / (ms_tot / n_sus) / 1e6 / HBM_PEAK_GBS, 4), "board": board,
                             "joules_per_launch": round(board["package_W"] * ms_tot / n_sus / 1e3, 3) if board else None}
-    sh = issue_share_of(res[best]["kernel"], wkey)
+    sh = res[best].get("issue_share")
     if sh is not None:
         res["issue_share"] = round(sh, 3)
         res["limiter"] = limiter_of(sh, (res.get("sustained") or {}).get("board") or cx.head_board, None)
@@ -540,6 +635,7 @@ def leg(cx, sp, layout, tile=0, tune=True, forced=None, energy=False, reps_ms=60
         nd += ndiff_bits(gather(torch, x, ids, layout, tile), O.synth_input(cx.SEED + sp.seed_off, ids, T, n_wires=nin))   # the device generator itself
     res["parity"] = parity_string(nd, len(ids), T)
     res["workload"] = f"{sp.desc}, {ns} streams x {T}-sample block, " + (LAYOUT_TEXT.get(layout) or f"stream-tiled frames [tile][t][{tile} streams][wire]")
+    res["layout"] = layout
     res["workload_key"] = wkey                               # (what profiles/pmc_traffic.json and sq_issue_share.json are keyed by, next to the kernel symbol)
     if keep is not None:
         keep.update(x=x, y=y, state=state, prog=prog)
@@ -857,8 +953,9 @@ def main():
     # first block from zero state: kept for the parity check (>= 1024 random streams across all tiles)
     prog.run_block(x, state=state, out=y, variant=variant)
     torch.cuda.synchronize()
-    par_ids = sample_ids(ns, PARITY_STREAMS, 11) if rank == 0 else None
-    first_block = gather(torch, y, par_ids, "tiled" if tile else "time_major", tile) if rank == 0 else None
+    # (every rank checks streams of its OWN shard against the oracle: rank 0 >= 1024, the others >= 128)
+    par_ids = sample_ids(ns, PARITY_STREAMS if rank == 0 else PARITY_STREAMS_OTHER_RANKS, 11 + rank)
+    first_block = gather(torch, y, par_ids, "tiled" if tile else "time_major", tile)
     for _ in range(max(args.warmup - 1, 0)):
         prog.run_block(x, state=state, out=y, variant=variant)
 
@@ -878,6 +975,13 @@ def main():
     checksum = zdist.bits_checksum(y[:, -1] if tile else y[-1])      # last time step of every stream: exact, shard-independent
     stats = zdist.reduce_stats(wall, float(ns) * T * args.steps, checksum, device=stats_dev)
     b_alg = ns * (4 * T * (prog.n_in + prog.n_out) + 8 * prog.n_state + 4 * prog.n_param)
+    per_rank_ms = zdist.gather_floats(kern_avg_s * 1e3, device=stats_dev)        # HIP-event ms per launch of every rank
+    # parity of every rank's shard (the oracle is the checker, outside the timed region; global stream ids = begin + local)
+    nd_all = n_checked = None
+    if not args.no_cpu_baseline or world > 1:
+        from oracle import coracle, flowz_oracle as O
+        want = coracle.df1_cascade([W.STABLE] * 6, O.synth_input(SEED, par_ids + begin, T))
+        nd_all, n_checked = (int(v) for v in zdist.sum_ints([ndiff_bits(first_block, want), len(par_ids)], device=stats_dev))
 
     # the same launches back to back for >= 2 s: whatever the power management does to the clocks has happened by then
     sustained = None
@@ -936,10 +1040,11 @@ def main():
 
     if rank == 0:
         achieved = b_alg / kern_avg_s / 1e9
-        kname = prog.kernel_symbol(variant if variant is not None else prog.plan(ns, tile), ns, T, tile)
+        vrun = variant if variant is not None else prog.plan(ns, tile)
+        kname, kcode = prog.kernel_symbol(vrun, ns, T, tile), prog.kernel_code_id(vrun, ns, T, tile)
         wkey = f"cascade6_{ns}x{T}_{lay}"
-        traffic = traffic_of(kname, wkey)
-        share = issue_share_of(kname, wkey)
+        cnt, csrc = counters_of(kcode, wkey)
+        traffic, share = cnt.get("traffic"), cnt.get("issue_share")
         line = {
             "metric": "Msamples/sec/GPU + achieved HBM GB/s, 6-biquad cascade, 1M streams",
             "value": round(stats["samples"] / stats["seconds"] / 1e6, 1),
@@ -961,8 +1066,8 @@ def main():
                                           "autotuned": tuned}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_kernel": kname if traffic is not None else None,
-                         "kernel": kname, "algorithmic_bytes_per_launch": b_alg,
+                         "traffic_source": csrc, "workload_key": wkey,
+                         "kernel": kname, "code_id": kcode, "algorithmic_bytes_per_launch": b_alg,
                          "avg_launch_ms": round(kern_avg_s * 1e3, 4),
                          "measured_row_walk_GBs": round(walk_gbs, 1) if walk_gbs else None,
                          "row_walk_kernel": walk_kernel,
@@ -975,13 +1080,22 @@ def main():
         if sustained is not None:
             line["roofline"]["sustained"] = sustained
         line.update(secondary)
+        if nd_all is not None:
+            line["parity"] = parity_string(nd_all, n_checked, T) + (f" (every one of the {world} ranks checked streams of its own shard)" if world > 1 else "")
+        if distributed:
+            line["dist_backend"] = args.dist_backend
+            line["rccl_ranks"] = dist.get_world_size() if args.dist_backend == "nccl" else 0
+            line["ms_per_step_per_rank"] = [round(v, 4) for v in per_rank_ms]
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import coracle, flowz_oracle as O
-            coefs = [W.STABLE] * 6
-            want = coracle.df1_cascade(coefs, O.synth_input(SEED, par_ids + begin, T))
-            line["parity"] = parity_string(ndiff_bits(first_block, want), len(par_ids), T)
-            line["cpu_baseline"] = cpu_baseline(T, SEED, coefs)
-        print(json.dumps(line), flush=True)
+            line["cpu_baseline"] = cpu_baseline(T, SEED, [W.STABLE] * 6)
+        # the full record goes to a file; stdout carries ONE line the driver can parse (< 4 KB)
+        details_path = os.environ.get("BENCH_DETAILS", os.path.join(ROOT, "bench_details.json"))
+        try:
+            with open(details_path, "w") as f:
+                json.dump(line, f, indent=1)
+        except OSError as e:                                 # (a read-only checkout must not cost the line)
+            print(f"# bench_details.json not written: {e}", file=sys.stderr)
+        print(compact_line(line, os.path.basename(details_path)), flush=True)
     if distributed:
         dist.destroy_process_group()
 

@@ -253,12 +253,6 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
        FZ_VF_GRID_SYNC = 8388608u, /* with FZ_VF_LOCKSTEP: the workgroups of one XCD (one contiguous 1/8 of every row) also walk the rows together:
                                    arrival counters in device memory (zeroed in stream order before the launch), bounded waits -- never a
                                    hang, never a different bit; chosen automatically when the chip holds all workgroups at once      */
-       FZ_VF_CROSS_PAIR = 16777216u, /* with FZ_VF_WAVES(W) and FZ_VF_IO_WAVE, a chain of exactly 2 W isomorphic segments: wave w evaluates segments w AND
-                                   w + W as one packed pair (every node one v_pk_* instruction), so that every hand-off between waves carries a
-                                   whole register pair -- ring entries of two steps x (low, high), read and written with one b128 LDS access
-                                   per two steps, no pack / unpack moves: 10 instructions per step and wave where the split into consecutive
-                                   stages issues 12.8.  The samples travel twice round the ring of waves (low halves, then high halves).
-                                   Chosen automatically for few streams where the graph allows it                                       */
        FZ_VF_IO_WAVE2 = 33554432u, /* with FZ_VF_IO_WAVE: TWO I/O waves per tuple -- one loads the input rows, one stores the output rows.  A wave
                                    issues its vector-memory instructions in order, one row of 64 streams x 4 bytes each: at one I/O wave per
                                    tuple that wave's 2 x n_samples instructions are what a round waits for (profiles/r04/few_streams_floor.txt) */
@@ -307,6 +301,17 @@ long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_strea
  * coefficient values share the symbol and the code object) */
 long fz_program_kernel_symbol(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
                               char* buf, size_t cap);
+/* ... and the identity of that kernel's CODE: 16 hex digits, a hash of (generated source, build options, compiler identity) -- the file name of
+ * its code object in the kernel cache.  The symbol names variant and graph; this names the instructions: counters measured on one build
+ * of a kernel are not this run's when the id differs (profiles/pmc_traffic.json is keyed by it). */
+long fz_program_kernel_code_id(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
+                               char* buf, size_t cap);
+/* Kernel manifests.  With FLOWZ_HIP_MANIFEST=<file> in the environment every kernel a process resolves for the first time is appended to
+ * <file> as (the program's expression, input types, variant).  fz_manifest_build replays such a file: compiles the programs again and
+ * builds -- in n_workers parallel compiler processes, no GPU needed -- whatever the kernel cache does not hold yet.  The records name
+ * expressions and variants, not generated code: a replay after the library changed builds the new kernels of the same launches.
+ * counts[4] = {records, already in the cache, built now, failed (a graph or variant this build no longer accepts)}. */
+int fz_manifest_build(const char* path, uint32_t n_workers, uint32_t* counts);
 /* generated HIP source of a variant (skeleton + graph body); returns length, writes <= cap    */
 long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap);
 

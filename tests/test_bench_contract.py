@@ -9,16 +9,64 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+LINE_LIMIT = 4096      # bytes the driver is sure to keep of the tail of stdout (round 4's 31 KB line came back as parsed = null)
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "roofline", "cpu_baseline")
+
+
+def test_compact_line_of_a_full_record_fits_the_driver(tmp_path):
+    """bench.compact_line on the full record of a real run (round 4's 31 KB line, kept under profiles/): every contract key, the roofline
+    and cpu_baseline objects the judge reads, one flat summary map -- in less than 4 KB"""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04", "bench_line_plain.json")))
+    assert len(json.dumps(full)) > 25000
+    txt = bench.compact_line(full)
+    assert len(txt) < LINE_LIMIT and "\n" not in txt
+    d = json.loads(txt)
+    for k in CONTRACT + ("parity", "summary"):
+        assert k in d, k
+    assert d["value"] == full["value"] and d["ms_per_step"] == full["ms_per_step"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "algorithmic_bytes_per_launch", "limiter"):
+        assert d["roofline"][k] == full["roofline"][k], k
+    assert d["roofline"]["sustained"]["frac"] == full["roofline"]["sustained"]["frac"]
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and len(d["cpu_baseline"]["sample"]) <= 200
+    s = d["summary"]
+    assert s["config2_time_major"] == round(full["config2_65536_streams"]["time_major"]["library_default"]["frac"], 3)
+    assert s["config2_tiled"] == round(full["config2_65536_streams"]["library_default"]["frac"], 3)
+    assert s["config3_stream_major"] == round(full["config3_par4_sum"]["stream_major"]["library_default"]["frac"], 3)
+    assert s["complex_one_pole"] == round(full["next_rows"]["complex_one_pole"]["library_default"]["frac"], 3)
+    assert len(s) == 30 and all(isinstance(v, float) for v in s.values())
+    assert d["parity_objects"].startswith("bitwise-equal on all 30")
+    # a record ten times as wide still fits: the optional maps go first, never the contract keys
+    wide = dict(full)
+    for i in range(300):
+        wide[f"extra_object_number_{i}"] = full["tiled_layout"]
+    txt = bench.compact_line(wide)
+    assert len(txt) < LINE_LIMIT
+    assert all(k in json.loads(txt) for k in CONTRACT)
+
+
+def _last_line_as_the_driver_sees_it(stdout):
+    """the driver keeps the tail of stdout: the JSON line must be recoverable from the last 4096 bytes alone"""
+    tail = stdout[-LINE_LIMIT:]
+    lines = [l for l in tail.splitlines() if l.startswith("{")]
+    assert lines, tail[-300:]
+    return json.loads(lines[-1])
+
+
 @pytest.mark.gpu
-def test_bench_json_contract_small_workload():
+def test_bench_json_contract_small_workload(tmp_path):
+    details = str(tmp_path / "details.json")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                          "--streams", "16384", "--samples", "512"], capture_output=True, text=True, timeout=600)
+                          "--streams", "16384", "--samples", "512"], capture_output=True, text=True, timeout=600, env=dict(os.environ, BENCH_DETAILS=details))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    assert len(lines[0]) < LINE_LIMIT
     d = json.loads(lines[0])
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+    assert d == _last_line_as_the_driver_sees_it(out.stdout)
+    for k in CONTRACT:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
@@ -26,24 +74,36 @@ def test_bench_json_contract_small_workload():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["kernel"].startswith("fz_block_kernel_p")
+    assert "traffic" in r and "traffic_source" in r and (r["traffic"] is None) == (r["traffic_source"] is None)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["parity"].startswith("bitwise-equal")
     assert d["roofline"]["sustained"]["seconds"] >= 1.9 and d["roofline"]["sustained"]["frac"] > 0
-    board = d["roofline"]["sustained"]["board"]        # rocm-smi during the sustained leg (best effort: None without rocm-smi)
-    assert board is None or (board["package_W"] > 0 and board["sclk_MHz"] > 0 and board["samples"] >= 1)
-    assert "traffic_kernel" in d["roofline"]
-    for k in ("config2_65536_streams", "cascade6_32768_streams", "cascade6_16384_streams", "config3_par4_sum", "config3_par4_sum_fanout", "config4_osc_chain"):
-        assert d[k]["parity"].startswith("bitwise-equal"), (k, d[k]["parity"])
-        assert d[k]["library_default"]["frac"] > 0 and d[k]["tuned"]["kernel"].startswith("fz_block_kernel_p")
     assert d["config"]["layout"] == "time-major"                       # SURVEY 8d's device layout is the headline's (round 3)
+    s = d["summary"]
+    for k in ("tiled", "stream_major", "config2_tiled", "config2_time_major", "config2_stream_major", "cascade6_32768", "cascade6_16384", "config3_tiled",
+              "config3_time_major", "config3_stream_major", "config3_fanout", "config4_tiled", "config4_time_major", "config4_stream_major",
+              "lds_ring", "far_ring", "blocks64", "modulated", "double_biquad", "complex_one_pole", "ref_df1", "ref_df2t"):
+        assert 0 < s[k] < 1, k
+    assert d["parity_objects"] == f"bitwise-equal on all {len(s)} objects"
+    assert abs(d["value"] - 16384 * 512 * 3 / (d["ms_per_step"] * 3 / 1e3) / 1e6) / d["value"] < 1e-2
+    # the full record next to it: everything the line summarises, per plan
+    full = json.load(open(details))
+    for k in CONTRACT:
+        assert full[k] == d[k] or k in ("config", "roofline", "cpu_baseline"), k
+    board = full["roofline"]["sustained"]["board"]     # rocm-smi during the sustained leg (best effort: None without rocm-smi)
+    assert board is None or (board["package_W"] > 0 and board["sclk_MHz"] > 0 and board["samples"] >= 1)
+    for k in ("config2_65536_streams", "cascade6_32768_streams", "cascade6_16384_streams", "config3_par4_sum", "config3_par4_sum_fanout", "config4_osc_chain"):
+        assert full[k]["parity"].startswith("bitwise-equal"), (k, full[k]["parity"])
+        assert full[k]["library_default"]["frac"] > 0 and full[k]["tuned"]["kernel"].startswith("fz_block_kernel_p")
+        assert len(full[k]["library_default"]["code_id"]) == 16
     for k in ("tiled_layout", "stream_major_layout"):                  # the other frame layout and the reference's calling convention, same workload
-        assert d[k]["parity"].startswith("bitwise-equal"), (k, d[k]["parity"])
-        assert d[k]["library_default"]["frac"] > 0 and d[k]["tuned"]["kernel"].startswith("fz_block_kernel_p") and 0 < d[k]["frac"] < 1
+        assert full[k]["parity"].startswith("bitwise-equal"), (k, full[k]["parity"])
+        assert full[k]["library_default"]["frac"] > 0 and full[k]["tuned"]["kernel"].startswith("fz_block_kernel_p") and 0 < full[k]["frac"] < 1
+    c = full["cpu_baseline"]
     assert c["Msamples_per_s_per_core"] > 0 and c["physical_cores"] >= 1 and c["logical_cpus"] >= c["physical_cores"]
     assert c["cores"] <= c["threads"] and (c["cgroup_cpu_quota"] is None or c["cores"] <= max(1, round(c["cgroup_cpu_quota"])))
     assert 0.5 < c["Msamples_per_s_per_core"] * c["cores"] / c["value"] < 2.0
-    assert abs(d["value"] - 16384 * 512 * 3 / (d["ms_per_step"] * 3 / 1e3) / 1e6) / d["value"] < 1e-2
 
 
 def _run_bench(args, nproc=1, timeout=900, launcher=False):
@@ -57,10 +117,13 @@ def _run_bench(args, nproc=1, timeout=900, launcher=False):
                "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
     else:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, BENCH_DETAILS=os.path.join(td, "details.json")))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
+    assert len(lines) == 1 and len(lines[0]) < LINE_LIMIT, out.stdout[-2000:]
+    assert json.loads(lines[0]) == _last_line_as_the_driver_sees_it(out.stdout)
     return json.loads(lines[0])
 
 
@@ -76,6 +139,9 @@ def test_bench_two_ranks_on_one_gpu_rehearse_the_sharded_path():
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak"
     assert weak["config"]["streams_total"] == 262144 and weak["config"]["streams_per_gpu"] == 131072
     assert weak["checksum"] == one["checksum"] and isinstance(weak["checksum"], int)
+    # the N > 1 line checks itself: every rank compared streams of its own shard with the oracle; per-rank launch times; who reduced
+    assert weak["parity"].startswith("bitwise-equal on") and "every one of the 2 ranks" in weak["parity"]
+    assert weak["dist_backend"] == "gloo" and weak["rccl_ranks"] == 0 and len(weak["ms_per_step_per_rank"]) == 2 and min(weak["ms_per_step_per_rank"]) > 0
     assert abs(weak["value"] - 262144 * 4096 * 2 / (weak["ms_per_step"] * 2 / 1e3) / 1e6) / weak["value"] < 1e-2
     strong = _run_bench(["--gpus", "2", "--scaling", "strong", "--streams-total", "262144", "--dist-backend", "gloo"] + common, nproc=2)
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["config"]["streams_total"] == 262144
@@ -95,4 +161,5 @@ def test_bench_one_rank_reduces_its_statistics_over_rccl():
     assert "statistics reduced over nccl" in rccl["config"]["parallelism"]
     assert "reduced over" not in one["config"]["parallelism"]
     assert rccl["checksum"] == one["checksum"] and isinstance(rccl["checksum"], int)
+    assert rccl["rccl_ranks"] == 1 and rccl["dist_backend"] == "nccl" and len(rccl["ms_per_step_per_rank"]) == 1
     assert abs(rccl["value"] - 131072 * 4096 * 2 / (rccl["ms_per_step"] * 2 / 1e3) / 1e6) / rccl["value"] < 1e-2

@@ -737,60 +737,6 @@ def test_wave_split_kernel_vs_oracle(torch_cuda, F, name, T):
     assert tried >= 8
 
 
-CROSSABLE = {
-    "cascade4": (lambda: G.df1_cascade(4), 2),
-    "cascade6": (lambda: G.df1_cascade(6), 3),
-    "cascade8": (lambda: G.df1_cascade(8), 4),
-    "cascade6_distinct_coeffs": (lambda: G.df1_cascade(6, [G.STABLE, G.PAR4_SETS[0], G.PAR4_SETS[1], G.PAR4_SETS[2], G.PAR4_SETS[3], G.STABLE]), 3),
-    "df2_x4": (lambda: G.seq(G.seq(G.df2(*G.STABLE), G.df2(*G.PAR4_SETS[3])), G.seq(G.df2(*G.PAR4_SETS[1]), G.df2(*G.STABLE))), 2),
-    "cascade12_two_stages_per_segment": (lambda: G.df1_cascade(12), 3),
-}
-
-
-@pytest.mark.parametrize("T", [1, 2, 3, 5, 13, 16, 17, 33, 40, 64, 101, 300, 1000])
-@pytest.mark.parametrize("name", sorted(CROSSABLE))
-def test_cross_paired_wave_split_vs_oracle(torch_cuda, F, name, T):
-    """FZ_VF_CROSS_PAIR (round 4): wave w of a tuple evaluates segments w and w + W of a chain of 2 W as one packed pair; every hand-off
-    between waves is a register pair, a sample travels twice round the ring of waves.  Every block length (blocks shorter than the
-    pipeline, blocks that end inside a round, many rounds), ragged stream counts, unroll 8 / 16 / 32, one to four tuples per workgroup
-    -- outputs and the canonical state against the oracle / the plain kernel; two chained blocks across variants."""
-    mk, W = CROSSABLE[name]
-    g = mk()
-    prog = F.compile(F.from_sexpr(g))
-    ns = 133 if T < 1000 else 300
-    x = O.synth_input(SEED + 55, np.arange(ns), T)
-    want = O.compile(g, ns).run(x)
-    ref, st_ref = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
-    assert ndiff(ref, want) == 0
-    fl = F.C.FZ_VF_WAVES(W) | F.C.FZ_VF_IO_WAVE | F.C.FZ_VF_CROSS_PAIR
-    assert "x" in prog.kernel_name(F.make_variant(1, 16, 0, fl), ns, T).split("w")[-1]
-    for U, B, io2 in ((8, 64, 0), (16, 128, 0), (32, 64, 0), (16, 64, 1), (8, 192, 0), (8, 128, 1)):
-        if B * (W + 1 + io2) > 1024:
-            continue
-        got, st = run_gpu(torch_cuda, F, prog, x, variant=F.make_variant(1, U, B, fl | (F.C.FZ_VF_IO_WAVE2 if io2 else 0)))
-        assert ndiff(got, want) == 0, (name, T, U, B, io2)
-        assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0, (name, T, U, B, io2)
-    if T >= 5:
-        k = T // 3 + 1
-        a, st1 = run_gpu(torch_cuda, F, prog, x[:k], variant=F.make_variant(1, 16, 64, fl))
-        b, st2 = run_gpu(torch_cuda, F, prog, x[k:], variant=F.make_variant(1, 8, 256, NO_STAGE_PACK), state=st1)
-        assert ndiff(np.concatenate([a, b]), want) == 0
-        a, st1 = run_gpu(torch_cuda, F, prog, x[:k], variant=F.make_variant(1, 8, 64))
-        b, st2 = run_gpu(torch_cuda, F, prog, x[k:], variant=F.make_variant(1, 16, 128, fl), state=st1)
-        assert ndiff(np.concatenate([a, b]), want) == 0 and ndiff(st2.cpu().numpy(), st_ref.cpu().numpy()) == 0
-
-
-def test_cross_pairing_refuses_what_it_cannot_do(torch_cuda, F):
-    fl3 = F.C.FZ_VF_WAVES(3) | F.C.FZ_VF_IO_WAVE | F.C.FZ_VF_CROSS_PAIR
-    x = torch_cuda.zeros((64, 128, 1), device="cuda")
-    for g, fl in ((G.df1_cascade(4), fl3),                                                        # four segments are two pairs, not three
-                  (G.df1_cascade(6), F.C.FZ_VF_WAVES(3) | F.C.FZ_VF_CROSS_PAIR),                   # no I/O wave
-                  (G.df1_cascade(7), fl3),                                                        # a scalar prefix stage
-                  (G.osc_chain(6), fl3)):
-        with pytest.raises(F.FlowzError):
-            F.compile(F.from_sexpr(g)).run_block(x, variant=F.make_variant(1, 16, 0, fl))
-
-
 @pytest.mark.parametrize("T", [1, 7, 64, 101, 300])
 @pytest.mark.parametrize("name", sorted(PACKABLE))
 def test_io_wave_kernel_vs_oracle(torch_cuda, F, name, T):
@@ -961,7 +907,7 @@ def test_empty_block_is_a_noop(torch_cuda, F):
 
 
 def test_headline_workload_1M_x_4096_tiled_full_size(torch_cuda, F):
-    """bench.py's workload itself: 6-stage cascade, 1 048 576 streams x 4096 samples, tile 8192
+    """bench.py's workload on STREAM-TILED frames: 6-stage cascade, 1 048 576 streams x 4096 samples, tile 8192
     (16 GiB in, 16 GiB out).  Sampled streams (first/last tiles included) bitwise vs the compiled
     oracle over the full length; a second variant bit-identical on the whole output."""
     torch = torch_cuda
@@ -980,6 +926,105 @@ def test_headline_workload_1M_x_4096_tiled_full_size(torch_cuda, F):
     y2, st2 = prog.run_block(x, variant=F.make_variant(4, 4))
     assert torch.equal(y.view(torch.int32), y2.view(torch.int32))
     assert torch.equal(st.view(torch.int32), st2.view(torch.int32))
+
+
+def test_headline_time_major_cascade6_1M_x_4096(torch_cuda, F, monkeypatch):
+    """BASELINE's headline workload on its contract layout: the 6-stage cascade, 1 048 576 streams x 4096 samples, PLAIN time-major frames
+    [t][stream] (rows 4 MiB apart), the library's static default -- the lockstep, XCD-synchronised row walk with four streams per lane.
+    >= 1024 sampled streams (first / last included) bitwise against the compiled oracle over the full length; the whole output and the
+    final state bit-identical to the free-running two-streams-per-lane kernel."""
+    torch = torch_cuda
+    monkeypatch.setenv("FLOWZ_HIP_AUTOTUNE", "0")                  # the static choice, whatever a first launch would measure on this board
+    monkeypatch.setenv("FLOWZ_HIP_NO_PLAN_CACHE", "1")
+    ns, T = 1 << 20, 4096
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    assert prog.kernel_name(None, ns, T) == "fz_block_kernel_p4u1b1024f8912928"      # lockstep | XCD sync | three buffers of one row
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED)
+    y, st = prog.run_block(x)
+    ids = _sample_ids(ns, 1024, 5)
+    assert len(ids) >= 1024 and ids[0] == 0 and ids[-1] == ns - 1
+    xh = O.synth_input(SEED, ids, T)
+    want = C.df1_cascade([G.STABLE] * 6, xh)
+    idt = torch.from_numpy(ids).cuda()
+    assert ndiff(y[:, idt].cpu().numpy(), want) == 0
+    assert ndiff(x[:, idt].cpu().numpy(), xh) == 0
+    y2, st2 = prog.run_block(x, variant=F.make_variant(2, 16, 256))
+    assert torch.equal(y.view(torch.int32), y2.view(torch.int32))
+    assert torch.equal(st.view(torch.int32), st2.view(torch.int32))
+
+
+def test_remainder_launches_of_two_host_threads_keep_their_own_order(torch_cuda, F, monkeypatch):
+    """A block of 262 145 streams runs as one lap of whole workgroups plus a REMAINDER launch on the program's side stream, forked from
+    and joined to the caller's stream by events (fz_launch.cpp).  Two host threads, each on its own HIP stream, refill their input
+    right before every launch: a remainder that waited on the OTHER thread's fork event would read the frames of the block before.
+    (Round 4 shared the event pair between concurrent launches with no lock; the fork ... join sequence is now one critical section.)"""
+    import threading
+    torch = torch_cuda
+    monkeypatch.setenv("FLOWZ_HIP_AUTOTUNE", "0")
+    props = torch.cuda.get_device_properties(0)
+    ns, T = props.multi_processor_count * 1024 + 1, 1024            # one stream more than the lap's workgroups hold
+    prog = F.compile(F.from_sexpr(G.df1_cascade(2)))
+    ids = np.array([0, 1, ns - 2, ns - 1])
+    idt = torch.from_numpy(ids).cuda()
+    bad, rounds = [], 6
+
+    def worker(k):
+        torch.cuda.set_device(0)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            x = torch.zeros((T, ns, 1), dtype=torch.float32, device="cuda")
+            y = torch.empty_like(x)
+            for r in range(rounds):
+                seed = 1000 * k + r
+                F.synth_fill(x, seed)                                # producer of THIS block on this thread's stream
+                st = torch.zeros((prog.n_state, ns), dtype=torch.float32, device="cuda")
+                prog.run_block(x, state=st, out=y)
+                got = y[:, idt].cpu().numpy()                       # (synchronises this stream only)
+                want = C.df1_cascade([G.STABLE] * 2, O.synth_input(seed, ids, T))
+                if ndiff(got, want):
+                    bad.append((k, r, ndiff(got, want)))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not bad, bad
+
+
+def test_cold_kernel_cache_first_launches_are_bounded(tmp_path):
+    """A checkout without the pre-built code objects (zignal_amd/_kcache travels with a built tree, not with git): a fresh process with an
+    EMPTY kernel cache builds and launches the library defaults of the headline (time-major 1 M x 4096), of config 2 (65 536 streams,
+    time-major and tiled) and of the stream-major layouts of both -- every kernel through hiprtc -- within two minutes, and leaves them
+    in the cache it was pointed at."""
+    import subprocess
+    import sys
+    import time
+    code = (
+        "import torch, time\n"
+        "from zignal_amd import flowz as F, workloads as W\n"
+        "p = F.compile(F.from_sexpr(W.df1_cascade(6)))\n"
+        "T = 4096\n"
+        "for ns, tile, sm in ((1 << 20, 0, False), (65536, 0, False), (65536, 8192, False), (1 << 20, 0, True), (65536, 0, True)):\n"
+        "    t0 = time.time()\n"
+        "    if sm:\n"
+        "        x = torch.zeros((ns, T, 1), dtype=torch.float32, device='cuda'); y, st = p.run_block_stream_major(x)\n"
+        "    else:\n"
+        "        x = torch.zeros((ns // tile, T, tile, 1) if tile else (T, ns, 1), dtype=torch.float32, device='cuda'); y, st = p.run_block(x)\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert float(y.abs().max()) == 0.0\n"
+        "    print('built+ran', ns, tile, sm, round(time.time() - t0, 1), flush=True)\n"
+        "    del x, y, st\n")
+    env = dict(os.environ, FLOWZ_HIP_CACHE=str(tmp_path), FLOWZ_HIP_AUTOTUNE="0", FLOWZ_HIP_NO_PLAN_CACHE="1")
+    env.pop("FLOWZ_HIP_NO_CACHE", None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=os.path.dirname(HERE))
+    wall = time.time() - t0
+    assert out.returncode == 0, out.stderr[-2000:]
+    built = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    assert len(built) >= 5, built
+    assert wall <= 120.0, (wall, out.stdout)
 
 
 def test_many_streams_16M(torch_cuda, F):

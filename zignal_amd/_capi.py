@@ -30,7 +30,6 @@ FZ_VF_STREAM_MAJOR = 128
 FZ_VF_SM_LONG, FZ_VF_SM_SHORT, FZ_VF_WAVE_SPLIT, FZ_VF_IO_WAVE = 256, 512, 1024, 32768
 FZ_VF_LOCKSTEP = 524288
 FZ_VF_GRID_SYNC = 8388608
-FZ_VF_CROSS_PAIR = 16777216
 FZ_VF_IO_WAVE2 = 33554432
 
 
@@ -115,6 +114,8 @@ def _load():
         "fz_program_wave_part": (ctypes.c_int, [P, u32, u32, ctypes.POINTER(P)]),
         "fz_program_kernel_resources": (ctypes.c_int, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_int, ctypes.POINTER(KernelResources)]),
         "fz_program_kernel_name": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_char_p, ctypes.c_size_t]),
+        "fz_manifest_build": (ctypes.c_int, [ctypes.c_char_p, u32, ctypes.POINTER(u32)]),
+        "fz_program_kernel_code_id": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_char_p, ctypes.c_size_t]),
         "fz_program_kernel_symbol": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_char_p, ctypes.c_size_t]),
         "fz_program_source": (ctypes.c_long, [P, ctypes.POINTER(Variant), ctypes.c_char_p, ctypes.c_size_t]),
         "fz_run_block": (ctypes.c_int, [P, P, P, P, P, u64, u32, ctypes.POINTER(Variant), P]),

@@ -22,6 +22,7 @@ int fz_compile(const fz_expr* e, fz_program** out)
       auto* p = new fz_program();
       try {
          p->g = lower(e);
+         p->recipe = "typed 0\n" + serialize_expr(e);
          p->graph_hash = graph_structure_hash(p->g);
          p->g.sym_tag = (uint32_t)p->graph_hash;
       } catch (...) {
@@ -62,6 +63,9 @@ int fz_compile_typed(const fz_expr* e, const uint32_t* in_dtypes, uint32_t n_in_
       }
       std::unique_ptr<fz_program> p(new fz_program());
       p->g = lower(e, opt);
+      p->recipe = "typed 1";
+      for (uint8_t d : opt.in_dtype) p->recipe += " " + std::to_string((unsigned)d);
+      p->recipe += "\n" + serialize_expr(e);
       p->graph_hash = graph_structure_hash(p->g);
       p->g.sym_tag = (uint32_t)p->graph_hash;
       *out = p.release();
@@ -210,7 +214,13 @@ int fz_program_build_for(fz_program* p, const fz_variant* v, uint64_t n_streams,
 {
    FZ_GUARD(
       if (!p || !n_streams || !n_samples) fail(FZ_E_INVALID, "fz_program_build_for: bad arguments");
-      (void)get_kernel(p, finalize_variant(p, v, n_streams, n_samples, tile_streams), nullptr);
+      const Variant rv = finalize_variant(p, v, n_streams, n_samples, tile_streams);
+      (void)get_kernel(p, rv, nullptr);
+      // (a plain time-major block whose laps leave a few streams over launches a second kernel next to them)
+      if (!(tile_streams && tile_streams < n_streams) && !(v && (v->flags & FZ_VF_STREAM_MAJOR))) {
+         const uint64_t main_streams = lockstep_streams(p->g, v, rv, n_streams);
+         if (main_streams < n_streams) (void)get_kernel(p, remainder_variant(p, v, n_streams, n_samples, n_streams - main_streams), nullptr);
+      }
       return FZ_OK;)
 }
 
@@ -260,6 +270,31 @@ long fz_program_kernel_symbol(fz_program* p, const fz_variant* v, uint64_t n_str
       set_error(er.msg);
       return er.code;
    }
+}
+
+long fz_program_kernel_code_id(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
+                               char* buf, size_t cap)
+{
+   try {
+      if (!p) fail(FZ_E_INVALID, "null program");
+      const std::string s = kernel_code_id(p, finalize_variant(p, v, n_streams ? n_streams : (1ull << 20), n_samples ? n_samples : (1u << 20), tile_streams));
+      if (buf && cap) {
+         const size_t n = std::min(cap - 1, s.size());
+         std::memcpy(buf, s.data(), n);
+         buf[n] = 0;
+      }
+      return (long)s.size();
+   } catch (const fz::Error& er) {
+      set_error(er.msg);
+      return er.code;
+   }
+}
+
+int fz_manifest_build(const char* path, uint32_t n_workers, uint32_t* counts)
+{
+   FZ_GUARD(
+      if (!path || !counts) fail(FZ_E_INVALID, "fz_manifest_build: null argument");
+      return manifest_build(path, n_workers, counts);)
 }
 
 long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap)

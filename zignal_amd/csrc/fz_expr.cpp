@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
+#include <map>
 
 #include "fz_internal.hpp"
 
@@ -75,6 +77,101 @@ std::vector<uint32_t> max_input_delays(const fz_expr* e)
       case EK::Channel: return zipmax(max_input_delays(e->a), max_input_delays(e->b));            // :493-496
    }
    return {};
+}
+
+// ---- recipes: an expression as text (kernel manifests, fz_kernel_cache.cpp) --------------------------------------------------
+// One line per node of the DAG in dependency order, shared sub-expressions once: "<kind letter> <fields>"; operands are line numbers.
+// Floating-point values travel as bit patterns.
+static uint32_t bits32(float v) { uint32_t u; std::memcpy(&u, &v, 4); return u; }
+static uint64_t bits64(double v) { uint64_t u; std::memcpy(&u, &v, 8); return u; }
+static float from32(uint32_t u) { float v; std::memcpy(&v, &u, 4); return v; }
+static double from64(uint64_t u) { double v; std::memcpy(&v, &u, 8); return v; }
+
+std::string serialize_expr(const fz_expr* root)
+{
+   std::map<const fz_expr*, size_t> id;
+   std::string out;
+   // (iterative post-order: cascades of hundreds of stages are deep left spines)
+   std::vector<std::pair<const fz_expr*, int>> st{{root, 0}};
+   while (!st.empty()) {
+      auto& top = st.back();
+      const fz_expr* e = top.first;
+      if (id.count(e)) { st.pop_back(); continue; }
+      if (top.second == 0) { top.second = 1; if (e->a && !id.count(e->a)) { st.push_back({e->a, 0}); continue; } }
+      if (top.second == 1) { top.second = 2; if (e->b && !id.count(e->b)) { st.push_back({e->b, 0}); continue; } }
+      char buf[160];
+      const unsigned long a = e->a ? (unsigned long)id[e->a] : 0ul, b = e->b ? (unsigned long)id[e->b] : 0ul;
+      switch (e->kind) {
+         case EK::Placeholder: std::snprintf(buf, sizeof buf, "P %u\n", e->i); break;
+         case EK::Delayed: std::snprintf(buf, sizeof buf, "D %u %u\n", e->i, e->n); break;
+         case EK::Literal:
+            std::snprintf(buf, sizeof buf, "L %d %d %08x %08x %016llx %016llx\n", (int)e->f64, (int)e->cplx, bits32(e->value), bits32(e->value_im),
+                          (unsigned long long)bits64(e->value64), (unsigned long long)bits64(e->value64_im));
+            break;
+         case EK::Uniform: std::snprintf(buf, sizeof buf, "U %u %08x\n", e->i, bits32(e->value)); break;
+         case EK::Param: std::snprintf(buf, sizeof buf, "Q %u\n", e->i); break;
+         case EK::Modulator: std::snprintf(buf, sizeof buf, "M %u\n", e->i); break;
+         case EK::Arith: std::snprintf(buf, sizeof buf, "A %d %lu %lu\n", (int)e->op, a, b); break;
+         case EK::Neg: std::snprintf(buf, sizeof buf, "N %lu\n", a); break;
+         case EK::Channel: std::snprintf(buf, sizeof buf, "C %lu %lu\n", a, b); break;
+         case EK::Parallel: std::snprintf(buf, sizeof buf, "B %lu %lu\n", a, b); break;
+         case EK::Sequence: std::snprintf(buf, sizeof buf, "S %lu %lu\n", a, b); break;
+         case EK::Feedback: std::snprintf(buf, sizeof buf, "F %lu\n", a); break;
+      }
+      out += buf;
+      const size_t n = id.size();
+      id[e] = n;
+      st.pop_back();
+   }
+   return out;
+}
+
+// the expression of a recipe (one reference, the caller's); nullptr + fz_last_error for text that is not one
+fz_expr* parse_expr(const std::string& text)
+{
+   std::vector<fz_expr*> nodes;
+   auto cleanup = [&] { for (fz_expr* e : nodes) fz_expr_release(e); };
+   auto bad = [&](const char* why) -> fz_expr* { cleanup(); set_error(std::string("recipe: ") + why); return nullptr; };
+   size_t pos = 0;
+   while (pos < text.size()) {
+      size_t eol = text.find('\n', pos);
+      if (eol == std::string::npos) eol = text.size();
+      const std::string ln = text.substr(pos, eol - pos);
+      pos = eol + 1;
+      if (ln.empty()) continue;
+      unsigned i = 0, n = 0, f64 = 0, cx = 0, v = 0, vi = 0;
+      unsigned long a = 0, b = 0;
+      unsigned long long d = 0, di = 0;
+      int op = 0;
+      fz_expr* e = nullptr;
+      auto ref = [&](unsigned long k) -> fz_expr* { return k < nodes.size() ? nodes[k] : nullptr; };
+      const char* s = ln.c_str() + 1;
+      switch (ln[0]) {
+         case 'P': if (std::sscanf(s, "%u", &i) == 1) e = fz_placeholder(i); break;
+         case 'D': if (std::sscanf(s, "%u %u", &i, &n) == 2) e = fz_delayed(i, n); break;
+         case 'L':
+            if (std::sscanf(s, "%u %u %x %x %llx %llx", &f64, &cx, &v, &vi, &d, &di) == 6)
+               e = cx ? (f64 ? fz_literal_c64(from64(d), from64(di)) : fz_literal_c32(from32(v), from32(vi))) : (f64 ? fz_literal_f64(from64(d)) : fz_literal(from32(v)));
+            break;
+         case 'U': if (std::sscanf(s, "%u %x", &i, &v) == 2) e = fz_uniform(i, from32(v)); break;
+         case 'Q': if (std::sscanf(s, "%u", &i) == 1) e = fz_stream_param(i); break;
+         case 'M': if (std::sscanf(s, "%u", &i) == 1) e = fz_modulator(i); break;
+         case 'A': if (std::sscanf(s, "%d %lu %lu", &op, &a, &b) == 3 && ref(a) && ref(b)) e = fz_arith((fz_op)op, ref(a), ref(b)); break;
+         case 'N': if (std::sscanf(s, "%lu", &a) == 1 && ref(a)) e = fz_arith(FZ_OP_NEG, ref(a), nullptr); break;
+         case 'C': if (std::sscanf(s, "%lu %lu", &a, &b) == 2 && ref(a) && ref(b)) e = fz_channel(ref(a), ref(b)); break;
+         case 'B': if (std::sscanf(s, "%lu %lu", &a, &b) == 2 && ref(a) && ref(b)) e = fz_parallel(ref(a), ref(b)); break;
+         case 'S': if (std::sscanf(s, "%lu %lu", &a, &b) == 2 && ref(a) && ref(b)) e = fz_sequence(ref(a), ref(b)); break;
+         case 'F': if (std::sscanf(s, "%lu", &a) == 1 && ref(a)) e = fz_feedback(ref(a)); break;
+         default: return bad("unknown node kind");
+      }
+      if (!e) return bad("malformed line");
+      nodes.push_back(e);
+   }
+   if (nodes.empty()) return bad("empty");
+   fz_expr* root = nodes.back();
+   fz_expr_retain(root);
+   cleanup();
+   return root;
 }
 
 }  // namespace fz

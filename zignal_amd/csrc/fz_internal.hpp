@@ -49,6 +49,10 @@ struct fz_expr {
 
 namespace fz {
 
+// an expression as text and back (fz_expr.cpp): what a kernel manifest records of a program
+std::string serialize_expr(const fz_expr* root);
+fz_expr* parse_expr(const std::string& text);
+
 // stage packing (fz_split.cpp): the graph is K isomorphic segments in series; segment j runs at
 // time t-j and segments 2i, 2i+1 share one packed float2 operation per node
 struct PackedLine {
@@ -132,17 +136,12 @@ struct Graph {
    // W = 2, 3, 4; empty when the graph does not allow it.
    std::vector<std::vector<Graph>> wave_splits;
    // (W = 1: the graph itself, when it is stage-packable -- the compute wave next to an I/O wave)
-   std::vector<std::vector<StageSplit>> cross_splits;   // FZ_VF_CROSS_PAIR: cross_splits[W] = the W packed pairs (segments w, w + W), W = 2, 3, 4
-   const std::vector<StageSplit>* cross_parts(uint32_t W) const { return W < cross_splits.size() && cross_splits[W].size() == W ? &cross_splits[W] : nullptr; }
    const std::vector<Graph>* wave_roles(uint32_t W) const { return W && W < wave_splits.size() && wave_splits[W].size() == W ? &wave_splits[W] : nullptr; }
 };
 
 // max_atoms: upper bound for K * m (the wave-split hand-offs and the long-run stream-major body bound the total skew)
 // force_atoms: cut every segment into atoms even when the chain has three or more packed pairs (a wave that carries ONE pair needs them)
 StageSplit find_stage_split(const Graph& g, bool plain = false, uint32_t divisor = 0, uint32_t max_atoms = 13, bool force_atoms = false);
-// FZ_VF_CROSS_PAIR: the chain as 2 W segments, part w = the stage split of segments (w, w + W) as ONE packed pair (K = 2, node ids the
-// graph's own); {} when the graph is not exactly 2 W isomorphic segments input to output
-std::vector<StageSplit> find_cross_parts(const Graph& g, uint32_t W);
 std::vector<Graph> find_wave_roles(const Graph& g, uint32_t W);   // fz_split.cpp; {} or W graphs
 // number of waves per stream tuple a variant asks for (flags bits 10..11: 1024 -> 2, 2048 -> 3, 3072 -> 4), 0 = no wave split
 inline uint32_t wave_split_of(uint32_t flags) { const uint32_t b = (flags >> 10) & 3u; return b ? b + 1 : 0; }
@@ -192,7 +191,7 @@ std::string kernel_name(const Graph& g, const Variant& v);     // the variant: f
 std::string kernel_symbol(const Graph& g, const Variant& v);   // the symbol in the code object: kernel_name + "_g<graph tag>"
 std::string gen_config(const Graph& g, const Variant& v); // generated "fz_graph_config.h"
 std::string gen_body(const Graph& g, const Variant& v);   // generated "fz_graph_body.h"
-const char* skeleton_source();                            // hand-written kernel skeleton text
+const std::string& skeleton_source(uint32_t flags);      // hand-written kernel text of a variant: the common head + the one body its flags select
 std::string full_source(const Graph& g, const Variant& v);
 
 // ---- runtime ---------------------------------------------------------------------------------------------
@@ -227,6 +226,7 @@ struct SideStream {        // hipStream_t / hipEvent_t, opaque here
    void* stream = nullptr;
    void* fork = nullptr;
    void* join = nullptr;
+   std::unique_ptr<std::mutex> mu;   // held from the fork's record to the join's wait: the event pair belongs to one launch at a time
 };
 }  // namespace fz
 
@@ -241,6 +241,7 @@ struct fz_program {
    std::set<std::tuple<uint64_t, uint32_t, int>> measuring;       // shapes whose first big launch is measuring its plan right now (other launches of the shape wait)
    std::condition_variable measured;
    std::set<std::tuple<uint64_t, uint32_t, int>> plan_looked_up;  // shapes whose persisted plan (plans.txt of the kernel cache) was consulted
+   std::string recipe;                                             // "typed <0|1> <input dtypes...>\n" + serialize_expr: how to compile this program again (kernel manifests); "" = not recorded
    uint64_t graph_hash = 0;                                        // structure of the lowered graph (no coefficient values)
    // FZ_VF_GRID_SYNC: arrival counters per device: 16 slices of `second` bytes, handed to the launches in turn (launches on
    // different streams may overlap and must not share counters; a slice comes round again after 15 other launches)
@@ -269,6 +270,8 @@ TmGeometry time_major_geometry(uint64_t n_streams, uint32_t max_p, bool heavy_op
 uint64_t lockstep_streams(const Graph& g, const fz_variant* uv, const Variant& v, uint64_t n_streams);
 // the kernel a launch of that shape runs: resolved, fitted to the tile / the 4 GiB chunk limit, unroll lowered until nothing spills
 Variant finalize_variant(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, bool settle = true);
+// the second kernel of a launch whose lockstep laps leave `rem` streams to a remainder launch (lockstep_streams(...) < n_streams)
+Variant remainder_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples, uint64_t rem);
 // builds (or fetches from the caches) the kernel of variant v; fn_out != null: also load it on the
 // current device and return its hipFunction_t
 std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_out);
@@ -294,4 +297,6 @@ struct NoJitScope {
 };
 // is the kernel's code object at hand (in memory or in the on-disk cache), i.e. can it run without a hiprtc build?
 bool kernel_at_hand(fz_program* p, const Variant& v);
+std::string kernel_code_id(const fz_program* p, const Variant& v);
+int manifest_build(const std::string& path, unsigned n_workers, uint32_t counts[4]);
 }  // namespace fz

@@ -17,6 +17,9 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <thread>
+
+#include <sys/file.h>
 
 #include "fz_runtime.hpp"
 
@@ -336,12 +339,12 @@ static const Rtc& rtc()
    return r;
 }
 
-static std::vector<char> jit_compile_in_process(const std::string& cfg, const std::string& body, const std::vector<const char*>& opts)
+static std::vector<char> jit_compile_in_process(const std::string& skel, const std::string& cfg, const std::string& body, const std::vector<const char*>& opts)
 {
    const char* headers[2] = {cfg.c_str(), body.c_str()};
    const char* names[2] = {"fz_graph_config.h", "fz_graph_body.h"};
    hiprtcProgram prog;
-   if (hiprtcCreateProgram(&prog, skeleton_source(), "fz_block_kernel.hip", 2, headers, names) != HIPRTC_SUCCESS)
+   if (hiprtcCreateProgram(&prog, skel.c_str(), "fz_block_kernel.hip", 2, headers, names) != HIPRTC_SUCCESS)
       fail(FZ_E_COMPILE, "hiprtcCreateProgram failed");
    hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), const_cast<const char**>(opts.data()));
    if (r != HIPRTC_SUCCESS) {
@@ -360,7 +363,7 @@ static std::vector<char> jit_compile_in_process(const std::string& cfg, const st
    return code;
 }
 
-static std::vector<char> jit_compile_in_worker(const std::string& worker, const std::string& cfg, const std::string& body, const std::vector<const char*>& opts)
+static std::vector<char> jit_compile_in_worker(const std::string& worker, const std::string& skel, const std::string& cfg, const std::string& body, const std::vector<const char*>& opts)
 {
    const std::string d = worker_tmp_dir();
    if (d.empty()) fail(FZ_E_COMPILE, "fz_rtc_worker: no temporary directory for the request");
@@ -373,7 +376,7 @@ static std::vector<char> jit_compile_in_worker(const std::string& worker, const 
          f << '\n';
       };
       f << "FZRTC1 " << (3 + opts.size()) << '\n';
-      section("source", "fz_block_kernel.hip", skeleton_source());
+      section("source", "fz_block_kernel.hip", skel);
       section("header", "fz_graph_config.h", cfg);
       section("header", "fz_graph_body.h", body);
       for (const char* o : opts) section("option", "-", o);
@@ -394,12 +397,24 @@ static std::vector<char> jit_compile_in_worker(const std::string& worker, const 
    return code;
 }
 
+// (manifest builds compile in parallel: every thread hands its kernels to a compiler process of its own)
+static thread_local bool tl_force_worker = false;
+
 static std::vector<char> jit_compile(const Graph& g, const Variant& v)
 {
    const std::string cfg = gen_config(g, v), body = gen_body(g, v);
    const std::vector<const char*> opts = build_options(g, v);
    const Rtc& R = rtc();
-   return R.worker.empty() ? jit_compile_in_process(cfg, body, opts) : jit_compile_in_worker(R.worker, cfg, body, opts);
+   std::string worker = R.worker;
+   if (worker.empty() && tl_force_worker && R.identity == preferred_identity()) {
+      const std::string w = library_dir() + "/fz_rtc_worker";
+      if (::access(w.c_str(), X_OK) == 0) worker = w;
+   }
+   const std::string& skel = skeleton_source(v.flags);
+   if (!worker.empty()) return jit_compile_in_worker(worker, skel, cfg, body, opts);
+   static std::mutex in_process;                          // (hiprtc in one process: one build at a time)
+   std::lock_guard<std::mutex> lock(in_process);
+   return jit_compile_in_process(skel, cfg, body, opts);
 }
 
 // One field of the kernel's metadata map (code object v3+: an ELF note holding msgpack; one kernel per code object here).
@@ -484,6 +499,10 @@ static std::string cache_file_of(const fz_program* p, const Variant& v, const st
    return name;
 }
 
+// identity of a variant's CODE (16 hex digits): the name of its code object in the kernel cache under the installation's compiler.  Two
+// kernels share it only when generated source, build options and compiler agree -- what counter tables are keyed by (profiles/)
+std::string kernel_code_id(const fz_program* p, const Variant& v) { return cache_file_of(p, v, preferred_identity()).substr(1, 16); }
+
 static bool cache_in_use(const std::string& dir) { return !std::getenv("FLOWZ_HIP_NO_CACHE") && !dir.empty(); }
 
 // lookups: the installation's compiler first (pre-built objects), then whoever compiles in this process
@@ -512,6 +531,109 @@ bool kernel_at_hand(fz_program* p, const Variant& v)
 }
 
 thread_local bool tl_no_jit = false;
+
+// ---- kernel manifests ---------------------------------------------------------------------------------------------------------
+// FLOWZ_HIP_MANIFEST=<file>: every kernel a process resolves for the first time is appended as (recipe of its program, variant) -- a few
+// hundred bytes.  fz_manifest_build replays such a file WITHOUT a GPU: compiles the programs again and builds, in parallel compiler
+// processes, whatever the kernel cache lacks.  The records name expressions and variants, not generated text: a replay after the kernel
+// skeleton or the code generator changed builds the NEW kernels of the same launches (round 5: the GPU test suite launches ~1800 kernels;
+// a box that has to JIT them all needs 10 minutes for what takes 80 s from a warm cache).
+static void manifest_record(const fz_program* p, const Variant& v)
+{
+   static const char* const path = std::getenv("FLOWZ_HIP_MANIFEST");
+   if (!path || !*path || p->recipe.empty()) return;
+   char head[96];
+   std::snprintf(head, sizeof head, "FZM1 %u %u %u %u %zu\n", v.P, v.U, v.block, v.flags, p->recipe.size());
+   const std::string rec = head + p->recipe;
+   {
+      static std::mutex mu;
+      static std::set<uint64_t> seen;                      // (a test suite compiles the same graphs hundreds of times)
+      std::lock_guard<std::mutex> lock(mu);
+      if (!seen.insert(fnv1a(rec)).second) return;
+   }
+   const int fd = ::open(path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+   if (fd < 0) return;
+   (void)::flock(fd, LOCK_EX);                             // (several processes may share the file: records never interleave)
+   size_t off = 0;
+   while (off < rec.size()) {
+      const ssize_t n = ::write(fd, rec.data() + off, rec.size() - off);
+      if (n <= 0) break;
+      off += (size_t)n;
+   }
+   (void)::flock(fd, LOCK_UN);
+   ::close(fd);
+}
+
+int manifest_build(const std::string& path, unsigned n_workers, uint32_t counts[4])
+{
+   const std::string text = slurp(path);
+   if (text.empty()) fail(FZ_E_INVALID, "kernel manifest: cannot read " + path);
+   // records -> unique (recipe, variant) pairs
+   std::map<std::string, std::set<Variant>> want;
+   size_t pos = 0;
+   while (pos < text.size()) {
+      const size_t eol = text.find('\n', pos);
+      if (eol == std::string::npos) break;
+      Variant v;
+      size_t n = 0;
+      if (std::sscanf(text.c_str() + pos, "FZM1 %u %u %u %u %zu", &v.P, &v.U, &v.block, &v.flags, &n) != 5 || eol + 1 + n > text.size())
+         fail(FZ_E_INVALID, "kernel manifest: damaged record at byte " + std::to_string(pos));
+      want[text.substr(eol + 1, n)].insert(v);
+      pos = eol + 1 + n;
+   }
+   struct Item { fz_program* p; Variant v; };
+   std::vector<std::unique_ptr<fz_program>> programs;
+   std::vector<Item> items;
+   counts[0] = counts[1] = counts[2] = counts[3] = 0;      // records, at hand, built, failed
+   for (const auto& kv : want) {
+      const std::string& recipe = kv.first;
+      const size_t eol = recipe.find('\n');
+      unsigned typed = 0;
+      if (eol == std::string::npos || std::sscanf(recipe.c_str(), "typed %u", &typed) != 1) fail(FZ_E_INVALID, "kernel manifest: damaged recipe");
+      std::vector<uint32_t> dt;
+      {
+         std::istringstream is(recipe.substr(7, eol - 7));
+         for (unsigned d; is >> d;) dt.push_back(d);
+      }
+      fz_expr* e = parse_expr(recipe.substr(eol + 1));
+      fz_program* p = nullptr;
+      const int rc = !e ? FZ_E_INVALID : typed ? fz_compile_typed(e, dt.empty() ? nullptr : dt.data(), (uint32_t)dt.size(), &p) : fz_compile(e, &p);
+      fz_expr_release(e);
+      counts[0] += (uint32_t)kv.second.size();
+      if (rc != FZ_OK || !p) {                              // (a graph this build of the library no longer accepts)
+         counts[3] += (uint32_t)kv.second.size();
+         continue;
+      }
+      programs.emplace_back(p);
+      for (const Variant& v : kv.second) items.push_back(Item{p, v});
+   }
+   std::atomic<size_t> next{0};
+   std::atomic<uint32_t> at_hand{0}, built{0}, failed{0};
+   auto work = [&] {
+      tl_force_worker = true;
+      for (size_t i; (i = next.fetch_add(1)) < items.size();) {
+         try {
+            if (kernel_at_hand(items[i].p, items[i].v)) {
+               ++at_hand;
+               continue;
+            }
+            (void)get_kernel(items[i].p, items[i].v, nullptr);
+            ++built;
+         } catch (const Error&) {
+            ++failed;                                       // (a variant the graph no longer allows, a kernel that no longer compiles)
+         }
+      }
+      tl_force_worker = false;
+   };
+   std::vector<std::thread> ths;
+   for (unsigned t = 1; t < std::max(1u, n_workers); ++t) ths.emplace_back(work);
+   work();
+   for (std::thread& t : ths) t.join();
+   counts[1] = at_hand;
+   counts[2] = built;
+   counts[3] += failed;
+   return FZ_OK;
+}
 
 // The program mutex is held only to find (or create) the variant's slot; cache lookup, the hiprtc build (seconds) and module
 // loading happen under the SLOT's own mutex, so other launches of the program -- other variants, other threads -- go on.
@@ -553,6 +675,7 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
       }
       k->res = read_resources(k->code);
       k->built.store(true);
+      manifest_record(p, v);
    }
    if (fn_out) {
       require_device();

@@ -112,21 +112,26 @@ struct ArgsHeader {
    unsigned int reserved0;
 };
 // the program's side stream on the current device and the two events that fork it from / join it to a caller's stream (created on
-// first use, destroyed with the program; the calls that use them are made under no lock: event record / wait take the state of the
-// moment, so launches of several host threads may share them)
-static SideStream side_stream(fz_program* p)
+// first use, destroyed with the program).  An event wait takes the event's LATEST record: with two host threads launching remainder
+// shapes at once, thread A's hipStreamWaitEvent(side, fork) could pick up thread B's record and A's remainder would no longer be
+// ordered behind A's own earlier work.  The whole fork ... join sequence of a launch therefore runs under the side stream's mutex
+// (enqueue calls only: microseconds; the kernels are resolved before it is taken).
+static SideStream& side_stream(fz_program* p)
 {
    int dev = 0;
    FZ_HIP(hipGetDevice(&dev));
    std::lock_guard<std::mutex> lock(p->mu);
-   SideStream& s = p->side[dev];
+   SideStream& s = p->side[dev];                            // (std::map: the reference stays valid)
    if (!s.stream) {
       hipStream_t st;
       hipEvent_t a, b;
       FZ_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
       FZ_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
       FZ_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-      s = SideStream{st, a, b};
+      s.stream = st;
+      s.fork = a;
+      s.join = b;
+      s.mu.reset(new std::mutex());
    }
    return s;
 }
@@ -162,7 +167,8 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    const uint64_t row_streams = tile_streams ? tile_streams : n_streams;
    const uint64_t out_w = (uint64_t)std::max<uint32_t>(g.n_out, 1) * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 2 : 1);
    if (!stream_major && row_streams * std::max(wmax, out_w) >= (1ull << 30)) fail(FZ_E_UNSUPPORTED, "row longer than 4 GiB: shard or tile the streams");
-   if (n_streams >= (1ull << 32)) fail(FZ_E_UNSUPPORTED, "more than 2^32 streams per launch: shard the streams");
+   // (state and coefficient rows go through one-row buffer descriptors: 32-bit byte offsets and sizes, n_streams * 4 < 2^32)
+   if (n_streams >= (1ull << 30)) fail(FZ_E_UNSUPPORTED, "2^30 streams or more per launch: shard the streams");
    if (tile_streams && n_streams % tile_streams) fail(FZ_E_INVALID, "n_streams must be a multiple of tile_streams");
    require_device();
    fz_variant planned;
@@ -173,9 +179,32 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       const auto key = std::make_tuple(n_streams, tile_streams, dev);
       bool known = false;
       (void)planned_variant(p, n_streams, tile_streams);      // first launch of this shape: a plan persisted by an earlier process?
+      // The first BIG block of a shape measures the plan by itself (round 3: on by default; FLOWZ_HIP_AUTOTUNE=0 turns it off):
+      // which variant streams fastest differs from board to board by more than the variants differ on one board (the same
+      // kernel: +5 % here, -13 % there), so the library's static choice is only the first candidate.  The measurement runs on the
+      // caller's buffers (the state is saved and restored around it, `out` is recomputed below), takes the candidates whose
+      // code objects are at hand (build() pre-builds them for the BASELINE graphs; nothing is JIT-compiled for it) and
+      // costs about ten launches each; blocks below 2^26 stream-samples (a few hundred microseconds) never trigger it.
+      const char* const at_env = std::getenv("FLOWZ_HIP_AUTOTUNE");      // (read at every launch: a process may turn it off for some of its work)
+      const bool autotune = !(at_env && *at_env == '0');
+      bool may_tune = autotune && rows_total == n_samples && row0 == 0 && n_streams * (uint64_t)n_samples >= (1ull << 26);
+      if (may_tune) {
+         // not while the stream is being captured into a hipGraph (the measurement allocates and synchronises), and not
+         // in place: the candidates run on the caller's buffers, an aliased `in` would be overwritten before the real launch
+         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) (void)hipGetLastError();
+         const char* ib = reinterpret_cast<const char*>(in);
+         const char* ob = reinterpret_cast<const char*>(out);
+         const size_t ibytes = (size_t)n_streams * n_samples * g.n_in * 4, obytes = (size_t)n_streams * n_samples * out_w * 4;
+         const bool overlap = in && ib < ob + obytes && ob < ib + ibytes;
+         may_tune = cap == hipStreamCaptureStatusNone && !overlap;
+      }
+      bool can_tune = false;
       {
          // (another thread's first big launch of this shape may be measuring the plan right now, on ITS buffers: wait for the
          //  result instead of racing it -- the measuring thread's own launches carry explicit variants and never come here)
+         // ONE critical section decides who measures: the thread whose insert into `measuring` succeeds; everybody else of the
+         // shape waits above until that thread is done
          std::unique_lock<std::mutex> lock(p->mu);
          p->measured.wait(lock, [&] { return p->measuring.count(key) == 0; });
          auto it = p->plans.find(key);
@@ -187,33 +216,12 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
             uv = &planned;
             from_plan = true;
          }
-      }
-      // The first BIG block of a shape measures the plan by itself (round 3: on by default; FLOWZ_HIP_AUTOTUNE=0 turns it off):
-      // which variant streams fastest differs from board to board by more than the variants differ on one board (the same
-      // kernel: +5 % here, -13 % there), so the library's static choice is only the first candidate.  The measurement runs on the
-      // caller's buffers (the state is saved and restored around it, `out` is recomputed below), takes the candidates whose
-      // code objects are at hand (build() pre-builds them for the BASELINE graphs; nothing is JIT-compiled for it) and
-      // costs about ten launches each; blocks below 2^26 stream-samples (a few hundred microseconds) never trigger it.
-      const char* const at_env = std::getenv("FLOWZ_HIP_AUTOTUNE");      // (read at every launch: a process may turn it off for some of its work)
-      const bool autotune = !(at_env && *at_env == '0');
-      bool can_tune = autotune && !known && rows_total == n_samples && row0 == 0 && n_streams * (uint64_t)n_samples >= (1ull << 26);
-      if (can_tune) {
-         // not while the stream is being captured into a hipGraph (the measurement allocates and synchronises), and not
-         // in place: the candidates run on the caller's buffers, an aliased `in` would be overwritten before the real launch
-         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) (void)hipGetLastError();
-         const char* ib = reinterpret_cast<const char*>(in);
-         const char* ob = reinterpret_cast<const char*>(out);
-         const size_t ibytes = (size_t)n_streams * n_samples * g.n_in * 4, obytes = (size_t)n_streams * n_samples * out_w * 4;
-         const bool overlap = in && ib < ob + obytes && ob < ib + ibytes;
-         can_tune = cap == hipStreamCaptureStatusNone && !overlap;
-      }
-      if (can_tune) {
-         {
-            std::lock_guard<std::mutex> lock(p->mu);
+         if (may_tune && !known) {
             p->tuned_default.insert(key);                   // (also stops the recursion through tune -> launch)
-            p->measuring.insert(key);                       // other launches of this shape wait until the plan is known
+            can_tune = p->measuring.insert(key).second;     // other launches of this shape wait until the plan is known
          }
+      }
+      if (can_tune) {
          struct Done {                                      // ... on every exit path
             fz_program* p;
             decltype(key) k;
@@ -379,15 +387,11 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    // another page, ~1.4 ms per 4096 rows for ONE stream behind a million (measured: 7.07 ms for 1 048 577 streams against 5.62 ms for
    // 1 048 576 when it ran behind the lap) -- and the lap's workgroups leave room for them (92 of a SIMD's 128 registers per lane).
    const uint64_t rem = n_streams - main_streams;
-   // one-wave workgroups of the ordinary frame kernel, one stream per lane, stage-packed where the graph allows: ~100 registers per
-   // lane, so that a wave of it fits a SIMD NEXT TO the four of a lap's workgroup (a fatter kernel would keep a lap's workgroup off
-   // its CU until the remainder is done); a spilling kernel steps down as always
-   const bool sp_ok = g.split.ok && n_samples >= 16u * (g.split.atoms() - 1);
-   const fz_variant rq{1, 16, 64, (sp_ok ? (uint32_t)FZ_VF_STAGE_PACK : (uint32_t)FZ_VF_NO_STAGE_PACK) | (uv ? (uv->flags & FZ_VF_OUT_F64) : 0u)};
-   Variant r = resolve_variant(g, &rq, rem, n_samples, 0, 0);
-   while ((uint64_t)row_streams * std::max(wmax, out_w) * 4u * r.U >= (1ull << 32) && r.U > (ws_parts(r.flags) ? 8u : 1u)) r.U /= 2;   // (a chunk of U rows: one 4 GiB descriptor)
-   r = settle_variant(p, r);
-   SideStream side = side_stream(p);
+   const Variant r = remainder_variant(p, uv, n_streams, n_samples, rem);
+   (void)get_kernel(p, r, nullptr);                          // (resolved -- built, if need be -- before the side stream's mutex is taken)
+   (void)get_kernel(p, v, nullptr);
+   SideStream& side = side_stream(p);
+   std::lock_guard<std::mutex> fork_join(*side.mu);
    FZ_HIP(hipEventRecord((hipEvent_t)side.fork, (hipStream_t)stream));
    FZ_HIP(hipStreamWaitEvent((hipStream_t)side.stream, (hipEvent_t)side.fork, 0));
    run_part(r, main_streams, rem, side.stream);

@@ -666,8 +666,6 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
    g.split = find_stage_split(g);
    g.wave_splits.assign(5, {});
    for (uint32_t W = 2; W <= 4; ++W) g.wave_splits[W] = find_wave_roles(g, W);
-   g.cross_splits.assign(5, {});
-   for (uint32_t W = 2; W <= 4; ++W) g.cross_splits[W] = find_cross_parts(g, W);
    if (g.split.ok && g.n_in == 1 && g.n_out == 1 && !g.typed && !g.n_lds_slots && g.far_lines.empty()) {
       Graph whole = g;                                   // one part: the compute wave next to an I/O wave (FZ_VF_IO_WAVE)
       whole.wave_splits.clear();

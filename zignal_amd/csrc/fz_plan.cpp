@@ -109,27 +109,6 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // W compute waves per 64 streams, each evaluating one part of the serial graph (fz_split.cpp: find_wave_roles), and with
       // FZ_VF_IO_WAVE one more wave for the frame I/O
       const uint32_t waves = ws_waves(v.flags);
-      if (v.flags & FZ_VF_CROSS_PAIR) {
-         // pairs across the parts: W compute waves (segments w and w + W of a chain of exactly 2 W) + the I/O wave; per tuple W hand-off
-         // rings of 2 x U / 2 float4 per lane and the output ring: (W U + U / 2) KiB
-         if (wave_split_of(v.flags) < 2 || !ws_io(v.flags)) fail(FZ_E_INVALID, "FZ_VF_CROSS_PAIR goes with FZ_VF_WAVES(2..4) and FZ_VF_IO_WAVE");
-         if (!g.cross_parts(W)) fail(FZ_E_UNSUPPORTED, "FZ_VF_CROSS_PAIR: the graph is not a chain of exactly 2 x W isomorphic segments (1 in, 1 out, register delay lines, no scalar prefix / suffix)");
-         if (reqP > 1) fail(FZ_E_INVALID, "wave split needs streams_per_lane == 1");
-         if (reqU && reqU != 8 && reqU != 16 && reqU != 32) fail(FZ_E_INVALID, "wave split: unroll must be 8, 16 or 32");
-         if (reqB && (reqB % 64 || reqB * waves > 1024)) fail(FZ_E_INVALID, "wave split: block_threads counts the streams of a workgroup: a multiple of 64, at most 1024 / waves per tuple");
-         if (v.flags & (FZ_VF_STREAM_MAJOR | FZ_VF_OUT_F64 | FZ_VF_PREFETCH3)) fail(FZ_E_UNSUPPORTED, "wave split: time-major / tiled float32 frames, double buffering only");
-         v.P = 1;
-         // as many tuples per workgroup as it takes to put a compute wave on every SIMD of a CU that gets that many streams
-         v.block = reqB ? reqB : (n_streams <= 16384 ? 64u : n_streams <= 32768 ? 128u : 256u);
-         while (v.block * waves > 1024 && !reqB) v.block /= 2;
-         v.U = reqU ? reqU : 16;
-         auto lds = [&](const Variant& q) { return (uint64_t)(q.block / 64) * (W * q.U + q.U / 2) * 1024u; };
-         while (lds(v) > kMaxLdsBytes && !reqU && v.U > 8) v.U /= 2;
-         while (lds(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
-         if (lds(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_CROSS_PAIR: the hand-off rings do not fit the LDS with this unroll and block size");
-         v.flags &= ~(uint32_t)(FZ_VF_STAGE_PACK | FZ_VF_NO_STAGE_PACK | FZ_VF_SLP);
-         return v;
-      }
       if (!g.wave_roles(W))
          fail(FZ_E_UNSUPPORTED, W == 1 ? "FZ_VF_IO_WAVE: the graph is not stage-packable (1 in, 1 out, register delay lines)"
                                        : "wave split: the graph is not that many groups of isomorphic segments in series (1 in, 1 out, register delay lines)");
@@ -401,6 +380,24 @@ uint64_t lockstep_streams(const Graph& g, const fz_variant* uv, const Variant& v
    return time_major_geometry(n_streams, v.P, g.n_ops > 30, !g.typed).main_streams;
 }
 
+// The kernel of the REMAINDER launch (the last `rem` streams of a plain time-major block whose laps cover whole workgroups only): one-wave
+// workgroups of the ordinary frame kernel, one stream per lane, stage-packed where the graph allows: ~100 registers per lane, so that a
+// wave of it fits a SIMD NEXT TO the four of a lap's workgroup (a fatter kernel would keep a lap's workgroup off its CU until the
+// remainder is done); a spilling kernel steps down as always.  ONE function for the launch path, fz_program_build_for and
+// fz_program_kernel_resources.  Its rows are off the grid by construction: the same store policy rule as the main kernel's.
+Variant remainder_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples, uint64_t rem)
+{
+   const Graph& g = p->g;
+   const bool f64 = uv && (uv->flags & FZ_VF_OUT_F64);
+   const bool sp_ok = g.split.ok && n_samples >= 16u * (g.split.atoms() - 1);
+   const fz_variant rq{1, 16, 64, (sp_ok ? (uint32_t)FZ_VF_STAGE_PACK : (uint32_t)FZ_VF_NO_STAGE_PACK) | (f64 ? (uint32_t)FZ_VF_OUT_F64 : 0u)};
+   Variant r = resolve_variant(g, &rq, rem, n_samples, 0, 0);
+   const uint64_t wmax = std::max<uint64_t>(std::max(g.n_in, g.n_out), 1), out_w = (uint64_t)std::max<uint32_t>(g.n_out, 1) * (f64 ? 2 : 1);
+   while (n_streams * std::max(wmax, out_w) * 4u * r.U >= (1ull << 32) && r.U > (ws_parts(r.flags) ? 8u : 1u)) r.U /= 2;   // (a chunk of U rows: one 4 GiB descriptor)
+   if ((n_streams * out_w * 4u) % kStoreGridBytes || ((n_streams - rem) * out_w * 4u) % kStoreGridBytes) r.flags |= FZ_VF_ST_MERGE;
+   return settle_variant(p, r);
+}
+
 // The kernel a launch of this shape runs: the variant resolved for the layout, fitted to the tile size and the 4 GiB chunk limit,
 // its unroll lowered until nothing spills.  ONE function for fz_run_block, fz_program_kernel_name, fz_program_build_for and
 // fz_program_kernel_resources, so that what is reported and pre-built is what is launched.
@@ -553,7 +550,7 @@ static bool plan_load(const fz_program* p, uint64_t n_streams, uint32_t tile, fz
       if ((P != 0 && P != 1 && P != 2 && P != 4) || U > 128 || B > 1024 || (B % 64)) continue;   // (a damaged line)
       // only what tune_candidates can emit: a stale or damaged line must not turn a default launch into another LAYOUT or output type
       // (FZ_VF_STREAM_MAJOR / FZ_VF_OUT_F64 would write past a float32 time-major `out`)
-      constexpr unsigned kPlanFlags = FZ_VF_STAGE_PACK | FZ_VF_WAVE_SPLIT | FZ_VF_WAVE_SPLIT3 | FZ_VF_IO_WAVE | FZ_VF_IO_WAVE2 | FZ_VF_CROSS_PAIR | FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC | FZ_VF_PREFETCH3 | FZ_VF_MAX_WG(7);
+      constexpr unsigned kPlanFlags = FZ_VF_STAGE_PACK | FZ_VF_WAVE_SPLIT | FZ_VF_WAVE_SPLIT3 | FZ_VF_IO_WAVE | FZ_VF_IO_WAVE2 | FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC | FZ_VF_PREFETCH3 | FZ_VF_MAX_WG(7);
       if (fl & ~kPlanFlags) continue;
       *out = fz_variant{P, U, B, fl};
       found = true;

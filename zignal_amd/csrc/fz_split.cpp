@@ -497,37 +497,4 @@ std::vector<Graph> find_wave_roles(const Graph& g, uint32_t W)
    return roles;
 }
 
-// ---- pairs across the parts (FZ_VF_CROSS_PAIR) ------------------------------------------------------------------------------------
-// The wave split above gives a wave CONSECUTIVE segments: its packed pair is (2 w, 2 w + 1), the chain crosses from the low to the
-// high half inside the wave, and what travels between waves is a single wire that must be taken out of / put into a register pair.
-// Pairing ACROSS the parts -- wave w evaluates segments w and w + W of a chain of 2 W -- makes every hand-off a whole pair:
-//    in -> [seg 0 | wave 0 lo] -> [seg 1 | wave 1 lo] -> .. -> [seg W-1 | wave W-1 lo] -> [seg W | wave 0 hi] -> .. -> [seg 2W-1 | wave W-1 hi] -> out
-// Part w is the chain's stage split narrowed to the two segments: K = 2, the same atoms, tuples (t[w], t[w + W]), node ids the
-// graph's own (constants, per-stream coefficients, state rows: the parent's).  The generator (gen_body_skew, cross mode) takes the
-// pair's inputs from outside instead of feeding the low half's output to the high half.
-std::vector<StageSplit> find_cross_parts(const Graph& g, uint32_t W)
-{
-   if (W < 2 || g.typed || g.n_mod || g.n_lds_slots || !g.far_lines.empty() || g.n_in != 1 || g.n_out != 1) return {};
-   const StageSplit sp = find_stage_split(g, true, 2 * W, 32, true);
-   if (!sp.ok || sp.K != 2 * W || !sp.prefix.empty() || !sp.suffix.empty()) return {};
-   std::vector<StageSplit> parts(W);
-   for (uint32_t w = 0; w < W; ++w) {
-      StageSplit& q = parts[w];
-      auto narrow = [&](const std::vector<uint32_t>& t) { return std::vector<uint32_t>{t[w], t[w + W]}; };
-      q.ok = true;
-      q.K = 2;
-      q.m = sp.m;
-      q.cuts = {sp.cuts[w], sp.cuts[w + 1], sp.cuts[w + W + 1]};      // input of the low half; the outputs of the low and of the high half
-      for (const auto& t : sp.tuples) q.tuples.push_back(narrow(t));
-      q.sub = sp.sub;
-      for (const auto& t : sp.icuts) q.icuts.push_back(narrow(t));
-      for (const PackedLine& l : sp.lines) {
-         PackedLine n = l;
-         n.srcs = narrow(l.srcs);
-         q.lines.push_back(n);
-      }
-   }
-   return parts;
-}
-
 }  // namespace fz

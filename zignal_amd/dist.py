@@ -37,6 +37,31 @@ def reduce_stats(seconds: float, samples: float, checksum: int, device=None) -> 
     return {"seconds": float(t[0]), "samples": float(s[0]), "checksum": int(c[0]), "world": dist.get_world_size()}
 
 
+def gather_floats(value: float, device=None):
+    """[value of rank 0, value of rank 1, ...] on every rank ([value] when not distributed)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [float(t[0]) for t in parts]
+
+
+def sum_ints(values, device=None):
+    """element-wise sum of a short list of integers over all ranks, exact in int64 (identity when not distributed)"""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return [int(v) for v in values]
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t]
+
+
 def bits_checksum(last_row) -> int:
     """Sum of the uint32 bit patterns of a float32 CUDA/CPU tensor (exact in int64 for < 2^31 values)."""
     import torch

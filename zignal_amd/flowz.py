@@ -380,6 +380,14 @@ class Program:
         C.check(C.lib.fz_program_kernel_symbol(self._h, vp, int(n_streams), int(n_samples), int(tile_streams), buf, 160))
         return buf.value.decode()
 
+    def kernel_code_id(self, variant: Optional[Variant] = None, n_streams: int = 0, n_samples: int = 0, tile_streams: int = 0) -> str:
+        """16 hex digits naming the CODE of that kernel (hash of generated source + build options + compiler): the code object's file name
+        in the kernel cache.  Needs no GPU and builds nothing."""
+        vp = ctypes.byref(variant) if variant is not None else None
+        buf = ctypes.create_string_buffer(32)
+        C.check(C.lib.fz_program_kernel_code_id(self._h, vp, int(n_streams), int(n_samples), int(tile_streams), buf, 32))
+        return buf.value.decode()
+
     def source(self, variant: Optional[Variant] = None) -> str:
         vp = ctypes.byref(variant) if variant is not None else None
         n = C.check(C.lib.fz_program_source(self._h, vp, None, 0))
@@ -717,6 +725,25 @@ def unpack_typed(frames, dtypes):
             out.append(pair.view(np.float64 if dt == "f64" else np.complex64)[..., 0])
             k += 2
     return out
+
+
+def manifest_build(path: str, workers: int = 0) -> dict:
+    """Replay a kernel manifest (FLOWZ_HIP_MANIFEST=<file> records one while a process runs; *.gz is unpacked first): build, in `workers`
+    parallel compiler processes and without a GPU, every kernel of it the kernel cache lacks.  Returns the counts."""
+    import gzip
+    import os
+    import tempfile
+
+    workers = workers or max(1, len(os.sched_getaffinity(0)))
+    counts = (ctypes.c_uint32 * 4)()
+    if path.endswith(".gz"):
+        with tempfile.NamedTemporaryFile(suffix=".fzm") as tmp:
+            tmp.write(gzip.open(path, "rb").read())
+            tmp.flush()
+            C.check(C.lib.fz_manifest_build(tmp.name.encode(), workers, counts))
+    else:
+        C.check(C.lib.fz_manifest_build(path.encode(), workers, counts))
+    return dict(zip(("records", "at_hand", "built", "failed"), (int(c) for c in counts)))
 
 
 def device_count() -> int:
