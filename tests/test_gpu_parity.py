@@ -1023,7 +1023,7 @@ def test_cold_kernel_cache_first_launches_are_bounded(tmp_path):
     wall = time.time() - t0
     assert out.returncode == 0, out.stderr[-2000:]
     built = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
-    assert len(built) >= 5, built
+    assert len(built) >= 4, built                                   # (config 2 runs one kernel on rows and on tiles)
     assert wall <= 120.0, (wall, out.stdout)
 
 

@@ -194,6 +194,69 @@ def test_no_fma_contraction_in_generated_kernel(tmp_path, monkeypatch):
         assert ".vgpr_spill_count: 0" in notes and ".private_segment_fixed_size: 0" in notes
 
 
+def _main_loop_histogram(dis):
+    """opcode counts of the LARGEST loop of a disassembled kernel (its chunk loop): between a backward branch and its target"""
+    rows = []
+    for ln in dis.splitlines():
+        m = re.match(r"\s+(\S+).*//\s*([0-9A-Fa-f]+):", ln)
+        if m:
+            rows.append((int(m.group(2), 16), m.group(1), ln))
+    labels, pending = {}, None
+    for ln in dis.splitlines():
+        m = re.match(r"^([0-9a-f]+) <(.+)>:", ln)
+        if m:
+            pending = m.group(2)
+        elif pending and "//" in ln:
+            labels[pending] = int(ln.split("//")[1].split(":")[0].strip(), 16)
+            pending = None
+    best = {}
+    for addr, op, ln in rows:
+        m = re.search(r"s_cbranch\w+.*<(.+?)(?:\+0x([0-9a-f]+))?>", ln)
+        if not m or m.group(1) not in labels:
+            continue
+        tgt = labels[m.group(1)] + (int(m.group(2), 16) if m.group(2) else 0)
+        if tgt < addr:
+            body = [o for a, o, _ in rows if tgt <= a <= addr]
+            if len(body) > sum(best.values()):
+                best = {}
+                for o in body:
+                    best[o] = best.get(o, 0) + 1
+    return best
+
+
+def test_lds_rings_are_vectorised_in_time_in_the_isa(tmp_path, monkeypatch):
+    """Round 5: the LDS rings of the frame kernels are lane-major and accessed 16 bytes at a time -- 4 / P time steps per ds_read_b128 /
+    ds_write_b128, reads fetched and pushes flushed per sub-chunk of G steps.  The two combs of the bench line's lds_ring graph
+    (reads 40 and 23 samples back, two pushes per step: 4 LDS instructions per step in round 4) issue less than a quarter of that with
+    one stream per lane and less than half with two; no dword-sized LDS access is left in the chunk loop."""
+    import subprocess
+    monkeypatch.setenv("FLOWZ_HIP_CACHE", str(tmp_path))
+    from zignal_amd import workloads as ZW
+    g = ZW.lds_ring_comb()
+    for P, block, bound in ((1, 256, 1.0), (2, 128, 2.0)):
+        for f in tmp_path.glob("*.hsaco"):
+            f.unlink()
+        p = F.compile(F.from_sexpr(g))
+        v = F.make_variant(P, 32, block)
+        src = p.source(v)
+        assert "#define FZ_RING_G 16" in src                                # the largest power of two <= the youngest read (23)
+        p.build(v)
+        (obj,) = tmp_path.glob("*.hsaco")
+        dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", str(obj)], text=True)
+        h = _main_loop_histogram(dis)
+        steps = h.get("buffer_store_dword" if P == 1 else "buffer_store_dwordx2", 0)     # one frame store per step
+        assert steps >= 32 and steps % 32 == 0, h
+        lds = sum(n for o, n in h.items() if o.startswith("ds_"))
+        assert lds / steps < bound, (P, lds, steps, h)
+        assert not any(o in h for o in ("ds_read_b32", "ds_write_b32", "ds_read_b64", "ds_write_b64") if h.get(o, 0) > 2), h
+        assert not re.search(r"v_(pk_)?(fma|fmac|mad|mac)(_mix|_mixlo|_mixhi|_legacy)?_(f16|f32|f64|bf16)", dis)
+        notes = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(obj)], text=True)
+        assert ".vgpr_spill_count: 0" in notes and ".private_segment_fixed_size: 0" in notes
+    # a read younger than a 16-byte access of the lane (1 sample back on a ring: a deep line with a shallow tap) keeps the rings in place
+    shallow = ("seq", ("in", 1), ("add", ("del", 1, 40), ("del", 1, 1)))
+    assert "#define FZ_RING_G 0" in F.compile(F.from_sexpr(shallow)).source(F.make_variant(1, 16, 256))
+
+
 def test_wave_split_kernels_in_the_isa(tmp_path, monkeypatch):
     """the wave-split / I/O-wave code objects, disassembled: no contraction, no scratch, no waterfall loop around a buffer access
     (a descriptor built from a VGPR would cost one per load), the cut wire moves as 16-byte LDS accesses, one s_barrier per round

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1 << 20)
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=1, help="back-to-back launches per timing (sub-millisecond kernels: >= 20)")
     ap.add_argument("--tile", type=int, default=0, help="streams per frame tile (0 = time-major)")
     ap.add_argument("--sm", action="store_true", help="stream-major buffers [stream][t][wire] (fz_run_block_stream_major; FZ_VF_STREAM_MAJOR is added to the flags)")
     ap.add_argument("--prebuild", action="store_true", help="no GPU: build the variants' kernels into the cache (run without torch: the installation's compiler)")
@@ -39,8 +40,10 @@ def main():
               "cascade6g": lambda: G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1))),
               "cascade12": lambda: G.df1_cascade(12), "cascade24": lambda: G.df1_cascade(24),
               "mod6": lambda: G.df1_cascade_modulated(6), "ldsring": G.lds_ring_comb, "farring": lambda: G.far_comb(300), "ident": lambda: G.IN(1),
-              "params6": lambda: G.df1_cascade_params(6), "c32onepole": G.complex_one_pole, "f64biquad": G.df1_double}
-    prog = F.compile(F.from_sexpr(graphs[a.graph]()), typed=a.graph in ("c32onepole", "f64biquad"))
+              "params6": lambda: G.df1_cascade_params(6), "c32onepole": G.complex_one_pole, "f64biquad": G.df1_double,
+              # yardsticks of the typed frames: a float wire in, a double / complex<float> wire out, one operation (4 bytes read, 8 written per sample)
+              "widen64": lambda: G.mul(G.lit64(1.0), G.IN(1)), "widenc32": lambda: G.mul(G.litc(1.0, 0.0), G.IN(1))}
+    prog = F.compile(F.from_sexpr(graphs[a.graph]()), typed=a.graph in ("c32onepole", "f64biquad", "widen64", "widenc32"))
     ns, T = a.streams, a.samples
     if a.prebuild:
         for s in a.variants:
@@ -107,10 +110,11 @@ def main():
         for s, v in vs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            run(v)
+            for _r in range(a.reps):
+                run(v)
             e1.record()
             torch.cuda.synchronize()
-            times[s].append(e0.elapsed_time(e1))
+            times[s].append(e0.elapsed_time(e1) / a.reps)
     # copy yardstick
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = min(x.numel(), y.numel())

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <map>
+#include <set>
 #include <sstream>
 
 #include "fz_internal.hpp"
@@ -49,6 +50,59 @@ std::string kernel_symbol(const Graph& g, const Variant& v)
    return kernel_name(g, v) + tag;
 }
 
+// LDS rings of the frame kernels, VECTORISED IN TIME (round 5).  Round 4 kept a ring as `ring[slot][lane]`: one ds_read and one
+// ds_write of a lane's 4 P bytes per line and step, and a read younger than the chunk (the 23-sample comb under 32-row chunks) was
+// issued where it was needed -- one LDS round trip per step with one or two waves per SIMD to hide it behind.  Now a lane's slots
+// are CONTIGUOUS (`ring[line][lane][slot][stream of the lane]`, rows padded by 16 bytes: the lanes of every 16-byte access group fall on
+// distinct banks), the chunk runs in SUB-CHUNKS of G steps (G = the largest power of two <= the youngest ring read, <= the chunk): all
+// ring reads of a sub-chunk refer to slots written before it began and are fetched together as 16-byte vectors (4 / P time steps each),
+// and its pushes are kept in registers and written as 16-byte vectors when it ends.  A read `d` samples back starts (-d) mod (4 / P)
+// slots off the 16-byte grid -- a constant: the aligned vectors around it are read and the step's value is a register of them.
+RingPlan ring_plan(const Graph& g, const Variant& v)
+{
+   RingPlan rp;
+   rp.slots = g.n_lds_slots;
+   if (!g.n_lds_slots || (v.flags & (FZ_VF_STREAM_MAJOR | FZ_VF_STAGE_PACK)) || ws_parts(v.flags) || v.P > 4 || v.U < 2) return rp;
+   const uint32_t TW = 4 / v.P;
+   uint32_t min_read = ~0u;
+   std::set<std::pair<uint32_t, uint32_t>> reads;
+   for (const Node& nd : g.nodes) {
+      if (nd.kind != FZ_IR_DELAY) continue;
+      const Line& L = g.lines[(size_t)g.line_of_node[nd.a]];
+      if (!L.in_lds) continue;
+      if (L.f64) return rp;                                  // (double rings: two word planes, read in place)
+      min_read = std::min(min_read, nd.b);
+      reads.insert({(uint32_t)g.line_of_node[nd.a], nd.b});
+   }
+   uint32_t n_lines = 0;
+   for (const Line& L : g.lines)
+      if (L.in_lds) {
+         if (L.f64 || (L.lds_size & (L.lds_size - 1)) || L.lds_size % TW) return rp;
+         ++n_lines;
+      }
+   if (min_read == ~0u) min_read = v.U;                      // (lines nobody reads from LDS: pushes only)
+   uint32_t G = 1;
+   while (G * 2 <= min_read && G * 2 <= v.U) G *= 2;
+   while (G > 1 && v.U % G) G /= 2;
+   auto regs = [&](uint32_t gg) {
+      uint32_t r = n_lines * gg * v.P;
+      for (const auto& rd : reads) r += ((((TW - rd.second % TW) % TW) + gg + TW - 1) / TW) * 4;
+      return r;
+   };
+   while (G > TW && regs(G) > 200) G /= 2;
+   if (G < TW || G < 2 || regs(G) > 200) return rp;
+   rp.vec = true;
+   rp.G = G;
+   rp.TW = TW;
+   rp.pad = 4 / v.P;
+   uint32_t lane = 0;
+   for (const Line& L : g.lines)
+      if (L.in_lds) lane += (L.lds_size + rp.pad) * v.P;
+   rp.lane_floats = lane;
+   rp.slots = (lane + v.P - 1) / v.P;
+   return rp;
+}
+
 std::string gen_config(const Graph& g, const Variant& v)
 {
    std::ostringstream o;
@@ -64,7 +118,9 @@ std::string gen_config(const Graph& g, const Variant& v)
    o << "#define FZ_U " << v.U << "\n";
    o << "#define FZ_BLOCK " << v.block << "\n";
    o << "#define FZ_FLAGS " << v.flags << "u\n";
-   o << "#define FZ_LDS_SLOTS " << g.n_lds_slots << "\n";
+   const RingPlan rp = ring_plan(g, v);
+   o << "#define FZ_LDS_SLOTS " << rp.slots << "   // V slots per lane of the LDS rings\n";
+   o << "#define FZ_RING_G " << (rp.vec ? rp.G : 0u) << "   // LDS rings vectorised in time: reads fetched / pushes flushed every so many steps (0: in place)\n";
    // the long-run stream-major body with 64-sample phases: patches of 19 KB per wave, so two workgroups fit a CU -- if the
    // kernel stays within 256 registers (it needs 258 left alone): ask for two waves per SIMD
    o << "#define FZ_MINWAVES " << (((v.flags & FZ_VF_SM_LONG) && v.U == 64 && v.P == 1) ? 2 : 0) << "\n";
@@ -73,7 +129,7 @@ std::string gen_config(const Graph& g, const Variant& v)
       const uint32_t cap = (v.flags >> 20) & 7u;
       uint32_t pad = 0;
       if (cap) {
-         const uint32_t ring = g.n_lds_slots * v.block * 4u * v.P, want = 160u * 1024u / (cap + 1) + 1024u;
+         const uint32_t ring = rp.slots * v.block * 4u * v.P, want = 160u * 1024u / (cap + 1) + 1024u;
          pad = want > ring ? (std::min(want, 160u * 1024u) - ring) / 4u : 0u;
       }
       o << "#define FZ_OCC_PAD " << pad << "\n";
@@ -121,8 +177,29 @@ std::string gen_body(const Graph& g, const Variant& v)
       if ((l.lds_size & (l.lds_size - 1)) == 0) return "((" + pos + ") & " + std::to_string(l.lds_size - 1) + "u)";
       return "fz_ring_mod<" + std::to_string(l.lds_size) + "u>(" + pos + ")";
    };
+   const RingPlan rp = ring_plan(g, v);
+   // (vectorised rings: float offset of line l's row of this lane = (floats of the lines before it) * FZ_BLOCK + tid * (floats per row))
+   std::vector<uint32_t> ring_before(g.lines.size(), 0), ring_row(g.lines.size(), 0);
+   if (rp.vec) {
+      uint32_t acc = 0;
+      for (size_t l = 0; l < g.lines.size(); ++l)
+         if (g.lines[l].in_lds) {
+            ring_before[l] = acc;
+            ring_row[l] = (g.lines[l].lds_size + rp.pad) * v.P;
+            acc += ring_row[l];
+         }
+   }
+   auto line_index = [&](const Line& l) { return (size_t)(&l - g.lines.data()); };
+   auto ring_base = [&](const Line& l) {
+      const size_t li = line_index(l);
+      return "(" + std::to_string(ring_before[li]) + "u * FZ_BLOCK + tid * " + std::to_string(ring_row[li]) + "u)";
+   };
    auto ring_at = [&](const Line& l, const std::string& pos) {
+      if (rp.vec) return "(*reinterpret_cast<V*>(reinterpret_cast<float*>(ring) + " + ring_base(l) + " + " + ring_idx(l, pos) + " * " + std::to_string(v.P) + "u))";
       return "ring[(" + std::to_string(l.lds_slot0) + "u + " + ring_idx(l, pos) + ") * FZ_BLOCK + tid]";
+   };
+   auto ring_vec_at = [&](const Line& l, const std::string& pos) {      // 16 bytes = 4 / P consecutive slots of the lane, `pos` on that grid
+      return "(*reinterpret_cast<fz_f4*>(reinterpret_cast<float*>(ring) + " + ring_base(l) + " + " + ring_idx(l, pos) + " * " + std::to_string(v.P) + "u))";
    };
 
    // a double ring keeps low and high words in two float rings of lds_size slots each
@@ -166,24 +243,38 @@ std::string gen_body(const Graph& g, const Variant& v)
    // started, for every step of the chunk: all of a chunk's reads can be issued up front, into registers (`lr<k>[u]`), one round
    // trip per chunk.  Float lines, frame kernels (the stream-major bodies call step() without a chunk position and read in place);
    // at most 96 registers.
-   struct RingRead { uint32_t line, d; };
+   struct RingRead { uint32_t line, d, m, nv; };              // m: slots between the 16-byte grid and the read's first slot; nv: vectors per sub-chunk
    std::vector<RingRead> ring_reads;
    std::map<std::pair<uint32_t, uint32_t>, size_t> ring_read_of;
-   if (!(v.flags & FZ_VF_STREAM_MAJOR) && v.U >= 2) {
+   if (rp.vec) {
+      for (const Node& nd : g.nodes) {
+         if (nd.kind != FZ_IR_DELAY) continue;
+         const int l = g.line_of_node[nd.a];
+         if (!g.lines[(size_t)l].in_lds) continue;
+         const uint32_t m = (rp.TW - nd.b % rp.TW) % rp.TW;
+         if (ring_read_of.emplace(std::make_pair((uint32_t)l, nd.b), ring_reads.size()).second)
+            ring_reads.push_back(RingRead{(uint32_t)l, nd.b, m, (m + rp.G + rp.TW - 1) / rp.TW});
+      }
+      for (size_t k = 0; k < ring_reads.size(); ++k)
+         o << "   fz_f4 lr" << k << "[" << ring_reads[k].nv << "];   // line " << ring_reads[k].line << " read " << ring_reads[k].d
+           << " samples back: the sub-chunk's slots as 16-byte vectors, the first value " << ring_reads[k].m << " slots in\n";
+      for (size_t l = 0; l < g.lines.size(); ++l)
+         if (g.lines[l].in_lds) o << "   fz_f4 wb" << l << "[" << rp.G / rp.TW << "];   // the sub-chunk's pushes of line " << l << "\n";
+   } else if (!(v.flags & FZ_VF_STREAM_MAJOR) && v.U >= 2) {
       for (const Node& nd : g.nodes) {
          if (nd.kind != FZ_IR_DELAY) continue;
          const int l = g.line_of_node[nd.a];
          const Line& L = g.lines[(size_t)l];
          if (!L.in_lds || L.f64 || L.far || nd.b < v.U) continue;
-         if (ring_read_of.emplace(std::make_pair((uint32_t)l, nd.b), ring_reads.size()).second) ring_reads.push_back(RingRead{(uint32_t)l, nd.b});
+         if (ring_read_of.emplace(std::make_pair((uint32_t)l, nd.b), ring_reads.size()).second) ring_reads.push_back(RingRead{(uint32_t)l, nd.b, 0, 0});
       }
       if (ring_reads.size() * v.U * v.P > 96) {
          ring_reads.clear();
          ring_read_of.clear();
       }
+      for (size_t k = 0; k < ring_reads.size(); ++k)
+         o << "   V lr" << k << "[FZ_U];   // line " << ring_reads[k].line << " read " << ring_reads[k].d << " samples back, the steps of the chunk at hand\n";
    }
-   for (size_t k = 0; k < ring_reads.size(); ++k)
-      o << "   V lr" << k << "[FZ_U];   // line " << ring_reads[k].line << " read " << ring_reads[k].d << " samples back, the steps of the chunk at hand\n";
    o << "   const float* mod = nullptr;   // sample-rate modulators [n_mod][mod_stride], set by the kernel (row 0 of the block)\n";
    o << "   unsigned mod_stride = 0;\n";
    // far lines: ring geometry for the skeleton, shadow registers for their short reads
@@ -279,12 +370,26 @@ std::string gen_body(const Graph& g, const Variant& v)
    o << "   // the LDS ring reads of the chunk that starts at sample n0 (see lr<k> above)\n";
    o << "   __device__ __forceinline__ void ring_prefetch(V* ring, unsigned tid, unsigned n0)\n   {\n";
    o << "      (void)ring; (void)tid; (void)n0;\n";
-   if (!ring_reads.empty()) {
+   if (rp.vec) {
+      // n0: first sample of the sub-chunk (a multiple of FZ_RING_G); vector j of read k starts at sample n0 - d - m + j * (4 / P)
+      for (size_t k = 0; k < ring_reads.size(); ++k)
+         for (uint32_t j = 0; j < ring_reads[k].nv; ++j)
+            o << "      lr" << k << "[" << j << "] = " << ring_vec_at(g.lines[ring_reads[k].line], "n0 + " + std::to_string(j * rp.TW) + "u - " + std::to_string(ring_reads[k].d + ring_reads[k].m) + "u") << ";\n";
+   } else if (!ring_reads.empty()) {
       o << "      _Pragma(\"unroll\") for (int u = 0; u < FZ_U; ++u)\n      {\n";
       for (size_t k = 0; k < ring_reads.size(); ++k)
          o << "         lr" << k << "[u] = " << ring_at(g.lines[ring_reads[k].line], "n0 + (unsigned)u - " + std::to_string(ring_reads[k].d) + "u") << ";\n";
       o << "      }\n";
    }
+   o << "   }\n";
+   o << "   // the pushes of the sub-chunk that started at sample n0, kept in registers by its steps: 16 bytes per store\n";
+   o << "   __device__ __forceinline__ void ring_flush(V* ring, unsigned tid, unsigned n0)\n   {\n";
+   o << "      (void)ring; (void)tid; (void)n0;\n";
+   if (rp.vec)
+      for (size_t l = 0; l < g.lines.size(); ++l)
+         if (g.lines[l].in_lds)
+            for (uint32_t j = 0; j < rp.G / rp.TW; ++j)
+               o << "      " << ring_vec_at(g.lines[l], "n0 + " + std::to_string(j * rp.TW) + "u") << " = wb" << l << "[" << j << "];\n";
    o << "   }\n";
    o << "   // u: the step's position in the chunk whose ring reads were prefetched (ring_prefetch), or -1: read the rings in place\n";
    o << "   __device__ __forceinline__ void step(const V* x, VO* y, const float* c, const double* cd, V* ring, unsigned tid, unsigned n, const V* hr, V* hw, const float* mv, unsigned mvs, int u = -1)\n   {\n";
@@ -318,7 +423,9 @@ std::string gen_body(const Graph& g, const Variant& v)
             else if (L.f64) o << "fz_join_d(" << ring_at(L, "n - " + std::to_string(nd.b) + "u") << ", " << ring_hi(L, "n - " + std::to_string(nd.b) + "u") << ")";
             else {
                const auto it = ring_read_of.find(std::make_pair((uint32_t)l, nd.b));
-               if (it != ring_read_of.end()) o << "(u >= 0 ? lr" << it->second << "[u] : " << ring_at(L, "n - " + std::to_string(nd.b) + "u") << ")";
+               if (it != ring_read_of.end() && rp.vec)
+                  o << "(u >= 0 ? fz_ring_pick(lr" << it->second << ", " << ring_reads[it->second].m << " + (u % " << rp.G << ")) : " << ring_at(L, "n - " + std::to_string(nd.b) + "u") << ")";
+               else if (it != ring_read_of.end()) o << "(u >= 0 ? lr" << it->second << "[u] : " << ring_at(L, "n - " + std::to_string(nd.b) + "u") << ")";
                else o << ring_at(L, "n - " + std::to_string(nd.b) + "u");
             }
             break;
@@ -358,6 +465,9 @@ std::string gen_body(const Graph& g, const Variant& v)
       } else if (L.f64) {
          o << "      " << ring_at(L, "n") << " = fz_lo_d(" << val(L.src) << ");\n";
          o << "      " << ring_hi(L, "n") << " = fz_hi_d(" << val(L.src) << ");\n";
+      } else if (rp.vec) {
+         o << "      if (u >= 0) fz_ring_put(wb" << l << ", u % " << rp.G << ", " << as_f32(L.src) << ");\n";
+         o << "      else " << ring_at(L, "n") << " = " << as_f32(L.src) << ";\n";
       } else {
          o << "      " << ring_at(L, "n") << " = " << as_f32(L.src) << ";\n";
       }

@@ -189,6 +189,16 @@ struct Variant {
 
 std::string kernel_name(const Graph& g, const Variant& v);     // the variant: fz_block_kernel_p<P>u<U>b<block>...f<flags>
 std::string kernel_symbol(const Graph& g, const Variant& v);   // the symbol in the code object: kernel_name + "_g<graph tag>"
+// how a frame kernel keeps its LDS rings (fz_codegen.cpp: ring_plan): vectorised in time where the graph allows
+struct RingPlan {
+   bool vec = false;          // lane-major rows, 16-byte accesses of 4 / P time steps, reads fetched / pushes flushed per sub-chunk
+   uint32_t G = 0;            // steps per sub-chunk
+   uint32_t TW = 1;           // time steps per 16-byte access
+   uint32_t pad = 0;          // padding slots per lane and line
+   uint32_t lane_floats = 0;  // floats per lane of all rings
+   uint32_t slots = 0;        // V slots per lane the kernel declares (FZ_LDS_SLOTS)
+};
+RingPlan ring_plan(const Graph& g, const Variant& v);
 std::string gen_config(const Graph& g, const Variant& v); // generated "fz_graph_config.h"
 std::string gen_body(const Graph& g, const Variant& v);   // generated "fz_graph_body.h"
 const std::string& skeleton_source(uint32_t flags);      // hand-written kernel text of a variant: the common head + the one body its flags select

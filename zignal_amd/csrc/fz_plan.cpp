@@ -362,7 +362,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    if (plain_auto && tile_streams && v.P == 2 && n_streams >= (1u << 19) && !g.n_lds_slots) v.flags |= FZ_VF_MAX_WG(2);
    if (g.n_lds_slots) {
       // LDS rings: slots * block * 4P bytes must fit the CU's 160 KiB of LDS (one workgroup may take it all)
-      auto bytes = [&](const Variant& w) { return (uint64_t)g.n_lds_slots * w.block * 4u * w.P; };
+      auto bytes = [&](const Variant& w) { return (uint64_t)ring_plan(g, w).slots * w.block * 4u * w.P; };   // (the vectorised rings pad their rows)
       while (bytes(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
       while (bytes(v) > kMaxLdsBytes && !reqP && v.P > 1) v.P /= 2;
       if (bytes(v) > kMaxLdsBytes)
