@@ -354,7 +354,10 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       }
       ArgsHeader h{in, out, state, params, mod_dev, nullptr, (unsigned long long)n_streams, n_samples, group0 + groups,
                    (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (w.P * w.block)) : 0u, rows_total, row0, mod_stride, n_blocks, group0, 0u};
+      // (developer switch, timing experiments only: FLOWZ_HIP_ONLY_LAP=k launches lap k alone -- the other streams are left untouched)
+      static const int only_lap = [] { const char* e = std::getenv("FLOWZ_HIP_ONLY_LAP"); return e ? std::atoi(e) : -1; }();
       for (unsigned lap = 0; lap < laps; ++lap) {
+         if (only_lap >= 0 && laps > 1 && (int)lap != only_lap) continue;
          if (laps > 1) {
             h.group0 = group0 + lap * per_lap * w.block;
             grid = std::min(per_lap, n_blocks - lap * per_lap);

@@ -99,7 +99,9 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    if (reqP != 0 && reqP != 1 && reqP != 2 && reqP != 4) fail(FZ_E_INVALID, "streams_per_lane must be 0, 1, 2 or 4");
    if (g.typed && (v.flags & FZ_VF_OUT_F64))
       fail(FZ_E_INVALID, "FZ_VF_OUT_F64 does not apply to fz_compile_typed programs: their frames carry every wire in its own type");
-   if (reqU > 32 && !((v.flags & FZ_VF_SM_LONG) && (reqU == 64 || reqU == 128))) fail(FZ_E_INVALID, "unroll must be <= 32");
+   // (64 rows per chunk: frame kernels whose occupancy is capped by LDS rings -- one wave per SIMD must keep all the rows in flight itself)
+   if (reqU > 32 && !((v.flags & FZ_VF_SM_LONG) && (reqU == 64 || reqU == 128)) && !(reqU == 64 && g.n_lds_slots && !(v.flags & FZ_VF_STREAM_MAJOR) && !ws_parts(v.flags)))
+      fail(FZ_E_INVALID, "unroll must be <= 32");
    if (reqB != 0 && (reqB % 64 != 0 || reqB > 1024)) fail(FZ_E_INVALID, "block_threads must be a multiple of 64, <= 1024");
    if ((v.flags & FZ_VF_LOCKSTEP) && (ws_parts(v.flags) || (v.flags & FZ_VF_STREAM_MAJOR)))
       fail(FZ_E_INVALID, "FZ_VF_LOCKSTEP applies to the frame kernel (time-major / tiled frames, lane-packed or stage-packed; no wave split)");
@@ -146,6 +148,11 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // -- unless the frames are already wide (>= 3 wires: 12+ bytes per lane with one stream)
       // (measured crossover on the 6-biquad cascade: 2^18 streams, profiles/r01/sweep_stream_counts.txt)
       v.P = (n_streams >= (1u << 18) && n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) ? 2 : 1;
+      // LDS rings (round 5: vectorised in time, fz_codegen.cpp: ring_plan): one stream per lane -- a 16-byte LDS access then carries FOUR
+      // time steps, and a 256-lane workgroup puts a wave on every SIMD where two streams per lane leave room for 128 lanes only.
+      // Measured, the two combs of 40 and 23 samples at 1 M streams x 4096 (profiles/r05/sweeps_rings_typed_config2.txt): one stream per
+      // lane, 32-row chunks, 256 lanes 0.700-0.703 of peak; two streams, 128 lanes 0.60-0.66; 64 rows or three buffers in flight change nothing
+      if (g.n_lds_slots && !(v.flags & FZ_VF_STREAM_MAJOR)) v.P = 1;
    }
    // PLAIN TIME-MAJOR frames of many streams (round 3): consecutive rows are n_streams * wires * 4 bytes apart -- megabytes,
    // i.e. every row a wave has in flight is another 2 MiB page, and waves that drift apart in time multiply the pages a CU
