@@ -1834,7 +1834,7 @@ def test_ragged_stream_counts_in_lockstep_workgroups(torch_cuda, F, ns):
         for v in ((4, 1, 256, L | GS | P3), (4, 2, 128, L), (2, 2, 256, L | GS), (2, 4, 64, L)):
             if ns % v[0] == 0:
                 continue
-            assert prog.kernel_name(F.make_variant(*v), ns, T).endswith("f%d" % (v[3] | (1 << 28) | (1 << 29)))   # (internal flags: FZ_VF_RAGGED, and FZ_VF_ST_MERGE: rows off the 64-byte store grid)
+            assert prog.kernel_name(F.make_variant(*v), ns, T).endswith("f%dRM" % v[3])   # (internal bits as letters: R = rows clipped per descriptor, M = merging stores for rows off the 64-byte grid)
             got, st = run_gpu(torch, F, prog, x, variant=F.make_variant(*v), params=params)
             assert ndiff(got, want) == 0 and torch.equal(st, st0), (ns, v)
             a, st1 = run_gpu(torch, F, prog, x[:17], variant=F.make_variant(*v), params=params)

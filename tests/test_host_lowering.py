@@ -619,7 +619,7 @@ def test_time_major_geometry_follows_the_cu_count():
     derived from the CU count (256 on a box without a GPU) and the measured table; counts just above whole laps run whole laps + a
     remainder launch; counts that are not a multiple of the streams per lane set the internal FZ_VF_RAGGED."""
     p = F.compile(F.from_sexpr(G.df1_cascade(6)))
-    L, GS, P3, RAGGED, MERGE = F.C.FZ_VF_LOCKSTEP, F.C.FZ_VF_GRID_SYNC, F.C.FZ_VF_PREFETCH3, 1 << 28, 1 << 29
+    L, GS, P3 = F.C.FZ_VF_LOCKSTEP, F.C.FZ_VF_GRID_SYNC, F.C.FZ_VF_PREFETCH3      # (internal bits show as letters behind the flags: R ragged, M merging stores)
     name = lambda n: p.kernel_name(None, n, 4096, 0)                                   # noqa: E731
     assert name(1 << 18) == "fz_block_kernel_p2u4b512f%d" % (L | GS)
     assert name(3 << 17) == "fz_block_kernel_p2u2b768f%d" % (L | GS)                   # 393 216 = 256 x 768 x 2
@@ -628,14 +628,14 @@ def test_time_major_geometry_follows_the_cu_count():
     assert name(1_000_000) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)           # 245 workgroups of 1024 lanes
     assert name(1 << 20) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)
     # rows that start off the 64-byte store grid: FZ_VF_ST_MERGE (stores that let L2 merge the sectors neighbouring waves share)
-    assert name((1 << 20) + 1) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | MERGE)       # one lap + a remainder launch of one stream: not ragged
-    assert name(1_000_001) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | RAGGED | MERGE)  # fits the workgroups: the last lane is partial
-    assert name(1_000_008) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3 | MERGE) and name(1_000_016) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)
+    assert name((1 << 20) + 1) == "fz_block_kernel_p4u1b1024f%dM" % (L | GS | P3)       # one lap + a remainder launch of one stream: not ragged
+    assert name(1_000_001) == "fz_block_kernel_p4u1b1024f%dRM" % (L | GS | P3)  # fits the workgroups: the last lane is partial
+    assert name(1_000_008) == "fz_block_kernel_p4u1b1024f%dM" % (L | GS | P3) and name(1_000_016) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)
     assert name(1 << 21) == "fz_block_kernel_p2u2b1024f%d" % (L | GS)                  # four laps of two streams per lane (0.75 against 0.70 for two laps of four)
     assert "b1024" not in name(1 << 17) and "f%d" % (L | GS) not in name((1 << 18) - 1024)   # below one wave per SIMD and CU: the few-stream kernels
     # nothing of this on tiles and LDS rings
     assert p.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % F.C.FZ_VF_MAX_WG(2)
-    assert F.compile(F.from_sexpr(G.lds_ring_comb())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p2u32b128f0"
+    assert F.compile(F.from_sexpr(G.lds_ring_comb())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u32b256f0"   # (rings vectorised in time: one stream per lane, a wave on every SIMD)
     # wide frames (the 4-wire sum): one stream per lane in 1024-lane workgroups; one lap: one row per buffer, more: chunks of two rows
     p4 = F.compile(F.from_sexpr(G.par4_sum()))
     assert p4.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p1u1b1024f%d" % (L | GS | P3)

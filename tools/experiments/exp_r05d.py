@@ -17,21 +17,22 @@ from zignal_amd import flowz as F, workloads as W  # noqa: E402
 T = 4096
 prog = F.compile(F.from_sexpr(W.par4_sum()))
 os.environ["FLOWZ_HIP_AUTOTUNE"] = "0"
+V = F.make_variant(*[int(v) for v in os.environ["FZ_VARIANT"].split(",")]) if os.environ.get("FZ_VARIANT") else None   # (the same kernel on both shapes)
 for ns in [int(a) for a in sys.argv[1:]] or [262144, 1 << 20]:
     x = torch.empty((T, ns, 4), dtype=torch.float32, device="cuda")
     y = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
     F.synth_fill(x, 20160512)
     st = torch.zeros((prog.n_state, ns), dtype=torch.float32, device="cuda")
     for _ in range(2):
-        prog.run_block(x, state=st, out=y)
+        prog.run_block(x, state=st, out=y, variant=V)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        prog.run_block(x, state=st, out=y)
+        prog.run_block(x, state=st, out=y, variant=V)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    print(json.dumps({"streams": ns, "only_lap": os.environ.get("FLOWZ_HIP_ONLY_LAP"), "kernel": prog.kernel_name(None, ns, T), "ms": round(ms, 3),
+    print(json.dumps({"streams": ns, "only_lap": os.environ.get("FLOWZ_HIP_ONLY_LAP"), "kernel": prog.kernel_name(V, ns, T), "ms": round(ms, 3),
                       "frac_if_whole_block": round(ns * (4 * T * 5 + 8 * prog.n_state) / ms / 1e6 / 8000, 4)}), flush=True)
     del x, y, st
