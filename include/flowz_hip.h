@@ -306,6 +306,11 @@ long fz_program_kernel_symbol(fz_program* p, const fz_variant* v, uint64_t n_str
  * of a kernel are not this run's when the id differs (profiles/pmc_traffic.json is keyed by it). */
 long fz_program_kernel_code_id(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
                                char* buf, size_t cap);
+/* An expression as text (one line per node of the DAG, values as bit patterns) and back: what a kernel manifest records of a program.
+ * fz_expr_recipe returns the length and writes <= cap bytes; fz_expr_from_recipe returns a new reference, NULL (+ fz_last_error) for
+ * text that is not a recipe. */
+long fz_expr_recipe(const fz_expr* e, char* buf, size_t cap);
+fz_expr* fz_expr_from_recipe(const char* text);
 /* Kernel manifests.  With FLOWZ_HIP_MANIFEST=<file> in the environment every kernel a process resolves for the first time is appended to
  * <file> as (the program's expression, input types, variant).  fz_manifest_build replays such a file: compiles the programs again and
  * builds -- in n_workers parallel compiler processes, no GPU needed -- whatever the kernel cache does not hold yet.  The records name

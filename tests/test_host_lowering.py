@@ -787,3 +787,69 @@ def test_kernel_symbols_keep_graphs_apart_in_a_profile():
     c = F.compile(F.from_sexpr(G.df1_cascade(6, coeffs=[(0.3, 0.1, 0.05, 0.2, -0.1)] * 6)))
     assert c.kernel_symbol(None, 1 << 20, 4096, 0) == sa
     assert sa in a.source(F.make_variant(4, 1, 1024, F.C.FZ_VF_LOCKSTEP | F.C.FZ_VF_GRID_SYNC | F.C.FZ_VF_PREFETCH3))
+
+
+def test_launch_rejects_stream_counts_its_descriptors_cannot_address():
+    """State and coefficient rows go through one-row buffer descriptors (32-bit sizes and offsets): 2^30 streams and more are refused --
+    on tiles and stream-major buffers too, where the row check of plain time-major frames does not catch them (checked before any device
+    is touched: the pointers here are never dereferenced)."""
+    p = F.compile(F.from_sexpr(G.df1_cascade(2)))
+    fake = ctypes.c_void_p(1 << 20)                                   # 16-byte aligned, never read
+    for ns, tile, flags in ((1 << 30, 8192, 0), (1 << 31, 8192, 0), (1 << 30, 0, _capi.FZ_VF_STREAM_MAJOR), ((1 << 30) + 8192, 8192, 0)):
+        with pytest.raises(F.FlowzError) as e:
+            if flags:
+                _capi.check(_capi.lib.fz_run_block_stream_major(p._h, fake, fake, fake, None, ns, 4096, 0, 4096, ctypes.byref(F.make_variant(0, 0, 0, flags)), None))
+            else:
+                p.run_block_ptr(fake, fake, fake, None, ns, 64, tile_streams=tile)
+        assert e.value.code == _capi.FZ_E_UNSUPPORTED and "2^30" in str(e.value), str(e.value)
+
+
+def test_expression_recipes_round_trip():
+    """An expression serialised (what a kernel manifest records of a program) and parsed back lowers to the same DAG, coefficient values
+    included: named graphs, typed graphs, 120 random ones."""
+    import randgraphs as R
+    cases = [(G.df1_cascade(6), False), (G.par4_sum(), False), (G.osc_chain(6), False), (G.cross_wire(), False), (G.df2t(), False),
+             (G.mixed_precision_biquad(), True), (G.complex_mix(), True), (("seq", ("in", 1), ("add", ("del", 1, 40), ("del", 1, 5000))), False)]
+    cases += [(R.make(seed)[0], False) for seed in range(80)] + [(R.make_typed(seed)[0], True) for seed in range(40)]
+    lib = _capi.lib
+    lib.fz_expr_recipe.restype = ctypes.c_long
+    lib.fz_expr_recipe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    lib.fz_expr_from_recipe.restype = ctypes.c_void_p
+    lib.fz_expr_from_recipe.argtypes = [ctypes.c_char_p]
+    for g, typed in cases:
+        e = F.from_sexpr(g)
+        n = lib.fz_expr_recipe(e._h, None, 0)
+        buf = ctypes.create_string_buffer(n + 1)
+        lib.fz_expr_recipe(e._h, buf, n + 1)
+        h = lib.fz_expr_from_recipe(buf.value)
+        assert h, _capi.lib.fz_last_error()
+        e2 = F.Expr(h)
+        assert (e2.ins, e2.outs) == (e.ins, e.outs)
+        a, b = F.compile(e, typed=typed), F.compile(e2, typed=typed)
+        assert a.ir() == b.ir() and a.lines() == b.lines() and a.outputs() == b.outputs() and a.consts() == b.consts(), g
+    assert not lib.fz_expr_from_recipe(b"A 0 0 1\n") and not lib.fz_expr_from_recipe(b"Z 1\n") and not lib.fz_expr_from_recipe(b"")
+
+
+def test_kernel_manifest_records_and_replays_without_a_gpu(tmp_path):
+    """FLOWZ_HIP_MANIFEST records (expression, input types, variant) of every kernel a process resolves; fz_manifest_build rebuilds them
+    into an empty kernel cache in parallel compiler processes: the same code objects, byte for byte; a second replay finds them all."""
+    import subprocess
+    import sys
+    man, c1, c2 = tmp_path / "m.fzm", tmp_path / "c1", tmp_path / "c2"
+    code = ("from zignal_amd import flowz as F, workloads as W\n"
+            "p = F.compile(F.from_sexpr(W.df1_cascade(6))); p.build(None, 1 << 20, 4096); p.build(None, 65536, 4096); p.build(None, (1 << 20) + 1, 4096)\n"
+            "q = F.compile(F.from_sexpr(W.complex_one_pole()), typed=True); q.build(None, 1 << 20, 4096)\n"
+            "r = F.compile(F.from_sexpr(W.lds_ring_comb())); r.build(F.make_variant(1, 32, 256))\n")
+    env = dict(os.environ, FLOWZ_HIP_CACHE=str(c1), FLOWZ_HIP_MANIFEST=str(man))
+    subprocess.check_call([sys.executable, "-c", code], env=env, cwd=ROOT)
+    first = sorted(f.name for f in c1.glob("*.hsaco"))
+    assert len(first) >= 6                                           # (1 048 577 streams: the lap's kernel AND the remainder launch's, pre-built by build_for)
+    env = dict(os.environ, FLOWZ_HIP_CACHE=str(c2))
+    out = subprocess.check_output([sys.executable, "-c", f"from zignal_amd import flowz as F; print(F.manifest_build({str(man)!r}, 4)); print(F.manifest_build({str(man)!r}, 4))"],
+                                  env=env, cwd=ROOT, text=True).splitlines()
+    a, b = eval(out[0]), eval(out[1])
+    assert a["failed"] == 0 and a["built"] == a["records"] >= len(first) and a["at_hand"] == 0, a
+    assert b["at_hand"] == b["records"] and b["built"] == 0, b
+    assert sorted(f.name for f in c2.glob("*.hsaco")) == first
+    for f in first:
+        assert (c1 / f).read_bytes() == (c2 / f).read_bytes(), f

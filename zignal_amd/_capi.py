@@ -114,6 +114,8 @@ def _load():
         "fz_program_wave_part": (ctypes.c_int, [P, u32, u32, ctypes.POINTER(P)]),
         "fz_program_kernel_resources": (ctypes.c_int, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_int, ctypes.POINTER(KernelResources)]),
         "fz_program_kernel_name": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_char_p, ctypes.c_size_t]),
+        "fz_expr_recipe": (ctypes.c_long, [P, ctypes.c_char_p, ctypes.c_size_t]),
+        "fz_expr_from_recipe": (P, [ctypes.c_char_p]),
         "fz_manifest_build": (ctypes.c_int, [ctypes.c_char_p, u32, ctypes.POINTER(u32)]),
         "fz_program_kernel_code_id": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_char_p, ctypes.c_size_t]),
         "fz_program_kernel_symbol": (ctypes.c_long, [P, ctypes.POINTER(Variant), u64, u32, u32, ctypes.c_char_p, ctypes.c_size_t]),

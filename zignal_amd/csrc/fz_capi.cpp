@@ -290,6 +290,25 @@ long fz_program_kernel_code_id(fz_program* p, const fz_variant* v, uint64_t n_st
    }
 }
 
+long fz_expr_recipe(const fz_expr* e, char* buf, size_t cap)
+{
+   try {
+      if (!e) fail(FZ_E_INVALID, "null expression");
+      const std::string s = serialize_expr(e);
+      if (buf && cap) {
+         const size_t n = std::min(cap - 1, s.size());
+         std::memcpy(buf, s.data(), n);
+         buf[n] = 0;
+      }
+      return (long)s.size();
+   } catch (const fz::Error& er) {
+      set_error(er.msg);
+      return er.code;
+   }
+}
+
+fz_expr* fz_expr_from_recipe(const char* text) { return text ? parse_expr(text) : nullptr; }
+
 int fz_manifest_build(const char* path, uint32_t n_workers, uint32_t* counts)
 {
    FZ_GUARD(
