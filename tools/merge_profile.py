@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Summarise a tools/profile_r05.sh batch: HBM traffic and SQ issue share per (kernel CODE id, workload) into profiles/pmc_traffic.json,
+"""Summarise a tools/profile_bench.sh batch: HBM traffic and SQ issue share per (kernel CODE id, workload) into profiles/pmc_traffic.json,
 profiles/sq_issue_share.json and <profiles/rNN>/rocprofv3_summary.json; the kernel-trace stats of the default bench command next to them.
 Entries are {"value", "kernel", "commit", "batch"}: bench.py reports a counter only for the code it was measured on, with where it came from.
-usage: tools/merge_r05.py <gpurun_out/dir> <profiles/rNN>"""
+usage: tools/merge_profile.py <gpurun_out/dir> <profiles/rNN>"""
 import collections
 import csv
 import glob
@@ -47,13 +47,13 @@ if head and "fz_copy_kernel" in cf and "fz_copy_kernel" in cw:
     f = sum(cf["fz_copy_kernel"]["FETCH_SIZE"]) / len(cf["fz_copy_kernel"]["FETCH_SIZE"]) * 1024
     w = sum(cw["fz_copy_kernel"]["WRITE_SIZE"]) / len(cw["fz_copy_kernel"]["WRITE_SIZE"]) * 1024
     read_factor, write_factor = copy_bytes / f, copy_bytes / w
-summ = {"_source": f"tools/profile_r05.sh -> {base}", "commit": commit, "calibration_on_copy_kernel": {"read_factor": read_factor, "write_factor": write_factor, "copy_bytes": copy_bytes},
+summ = {"_source": f"tools/profile_bench.sh -> {base}", "commit": commit, "calibration_on_copy_kernel": {"read_factor": read_factor, "write_factor": write_factor, "copy_bytes": copy_bytes},
         "hbm_traffic": [], "sq_counters": {}}
 tp, sp = os.path.join(prof, "pmc_traffic.json"), os.path.join(prof, "sq_issue_share.json")
 # (entries of earlier rounds were keyed by kernel symbol: a symbol does not name the code, they are not carried over)
 traffic = {k: v for k, v in (json.load(open(tp)) if os.path.exists(tp) else {}).items() if isinstance(v, dict)}
 shares = {k: v for k, v in (json.load(open(sp)) if os.path.exists(sp) else {}).items() if isinstance(v, dict)}
-shares["_source"] = "SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES per '<kernel code id>|<workload>' (tools/profile_r05.sh, tools/merge_r05.py)"
+shares["_source"] = "SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES per '<kernel code id>|<workload>' (tools/profile_bench.sh, tools/merge_profile.py)"
 for d in sorted(glob.glob(os.path.join(base, "pmc_*_FETCH_SIZE"))):
     tag = os.path.basename(d)[4:-len("_FETCH_SIZE")]
     log = last_json(d + ".log")
@@ -90,7 +90,7 @@ for d in sorted(glob.glob(os.path.join(base, "pmc_*_FETCH_SIZE"))):
         summ["sq_counters"][f"{tag}:{k}"] = c
         shares[f"{cid}|{wkey}"] = {"value": c["SQ_ACTIVE_INST_ANY_share_of_wave_cycles"], "kernel": k, "commit": commit, "batch": batch}
         print(f"{'':34s} {'':44s} issuing {c['SQ_ACTIVE_INST_ANY_share_of_wave_cycles']:.3f} waiting {c['SQ_WAIT_ANY_share_of_wave_cycles']:.3f} clock {c.get('effective_clock_GHz', 0):.2f} GHz")
-traffic["_source"] = "profiles/rNN/rocprofv3_summary.json (tools/profile_r05.sh, tools/merge_r05.py); key = '<kernel code id>|<workload>' (fz_program_kernel_code_id), value = HBM bytes per block from FETCH_SIZE x read_factor + WRITE_SIZE x write_factor (separate --pmc passes)"
+traffic["_source"] = "profiles/rNN/rocprofv3_summary.json (tools/profile_bench.sh, tools/merge_profile.py); key = '<kernel code id>|<workload>' (fz_program_kernel_code_id), value = HBM bytes per block from FETCH_SIZE x read_factor + WRITE_SIZE x write_factor (separate --pmc passes)"
 json.dump(traffic, open(tp, "w"), indent=1)
 json.dump(shares, open(sp, "w"), indent=1)
 json.dump(summ, open(os.path.join(outdir, "rocprofv3_summary.json"), "w"), indent=1)

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # GPU box: the rocprofv3 evidence of the bench line (round 5: the counter tables are keyed by the kernels' CODE ids).
-#   usage: gpurun -- "FZ_COMMIT=$(git rev-parse --short HEAD) tools/profile_r05.sh <name>"   -> gpurun_out/<name>/...
-#   then here: tools/merge_r05.py gpurun_out/<name> profiles/r05      (refreshes profiles/pmc_traffic.json, sq_issue_share.json)
+#   usage: gpurun -- "FZ_COMMIT=$(git rev-parse --short HEAD) tools/profile_bench.sh <name>"   -> gpurun_out/<name>/...
+#   then here: tools/merge_profile.py gpurun_out/<name> profiles/r05      (refreshes profiles/pmc_traffic.json, sq_issue_share.json)
 # 1. the DEFAULT bench command plain, then under --kernel-trace --stats (what the driver runs);
 # 2. per workload x layout of the line (bench.py --only <spec>:<layout>[:tile], the library's static choice): separate --pmc passes --
 #    never combined with tracing -- of FETCH_SIZE, WRITE_SIZE (HBM traffic) and of the SQ counters (issue share, real clock).
