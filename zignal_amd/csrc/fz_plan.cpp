@@ -90,291 +90,223 @@ TmGeometry time_major_geometry(uint64_t n_streams, uint32_t max_p, bool heavy_op
    return best;
 }
 
-Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, uint32_t allow_lockstep)
+// ---- the library's choice, rule by rule ----------------------------------------------------------------------------------------
+// resolve_variant = checks of what the caller asked for, then ONE of three resolvers by kernel body: wave split, stream-major, frames.
+// Every threshold below is a measurement; where it came from is in profiles/NOTES.md ("Planner rules"), not here.
+struct Request {
+   uint32_t P, U, B;                                       // streams per lane, unroll, block as asked for (0 = the library's choice)
+   const fz_variant* uv;
+};
+
+static void check_request(const Graph& g, const Request& rq, const Variant& v)
 {
-   if (tile_streams >= n_streams) tile_streams = 0;
-   Variant v;
-   const uint32_t reqP = uv ? uv->streams_per_lane : 0, reqU = uv ? uv->unroll : 0, reqB = uv ? uv->block_threads : 0;
-   v.flags = uv ? uv->flags : 0;
-   if (reqP != 0 && reqP != 1 && reqP != 2 && reqP != 4) fail(FZ_E_INVALID, "streams_per_lane must be 0, 1, 2 or 4");
+   if (rq.P != 0 && rq.P != 1 && rq.P != 2 && rq.P != 4) fail(FZ_E_INVALID, "streams_per_lane must be 0, 1, 2 or 4");
    if (g.typed && (v.flags & FZ_VF_OUT_F64))
       fail(FZ_E_INVALID, "FZ_VF_OUT_F64 does not apply to fz_compile_typed programs: their frames carry every wire in its own type");
-   // (64 rows per chunk: frame kernels whose occupancy is capped by LDS rings -- one wave per SIMD must keep all the rows in flight itself)
-   if (reqU > 32 && !((v.flags & FZ_VF_SM_LONG) && (reqU == 64 || reqU == 128)) && !(reqU == 64 && g.n_lds_slots && !(v.flags & FZ_VF_STREAM_MAJOR) && !ws_parts(v.flags)))
-      fail(FZ_E_INVALID, "unroll must be <= 32");
-   if (reqB != 0 && (reqB % 64 != 0 || reqB > 1024)) fail(FZ_E_INVALID, "block_threads must be a multiple of 64, <= 1024");
+   // (64 rows per chunk: frame kernels whose occupancy is capped by LDS rings -- one wave per SIMD keeps all the rows in flight itself)
+   const bool long_unroll_ok = ((v.flags & FZ_VF_SM_LONG) && (rq.U == 64 || rq.U == 128)) ||
+                               (rq.U == 64 && g.n_lds_slots && !(v.flags & FZ_VF_STREAM_MAJOR) && !ws_parts(v.flags));
+   if (rq.U > 32 && !long_unroll_ok) fail(FZ_E_INVALID, "unroll must be <= 32");
+   if (rq.B != 0 && (rq.B % 64 != 0 || rq.B > 1024)) fail(FZ_E_INVALID, "block_threads must be a multiple of 64, <= 1024");
    if ((v.flags & FZ_VF_LOCKSTEP) && (ws_parts(v.flags) || (v.flags & FZ_VF_STREAM_MAJOR)))
       fail(FZ_E_INVALID, "FZ_VF_LOCKSTEP applies to the frame kernel (time-major / tiled frames, lane-packed or stage-packed; no wave split)");
    if ((v.flags & FZ_VF_GRID_SYNC) && !(v.flags & FZ_VF_LOCKSTEP)) fail(FZ_E_INVALID, "FZ_VF_GRID_SYNC goes with FZ_VF_LOCKSTEP");
    if ((v.flags & FZ_VF_IO_WAVE2) && !(v.flags & FZ_VF_IO_WAVE)) fail(FZ_E_INVALID, "FZ_VF_IO_WAVE2 goes with FZ_VF_IO_WAVE");
-   if (const uint32_t W = ws_parts(v.flags)) {
-      // W compute waves per 64 streams, each evaluating one part of the serial graph (fz_split.cpp: find_wave_roles), and with
-      // FZ_VF_IO_WAVE one more wave for the frame I/O
-      const uint32_t waves = ws_waves(v.flags);
-      if (!g.wave_roles(W))
-         fail(FZ_E_UNSUPPORTED, W == 1 ? "FZ_VF_IO_WAVE: the graph is not stage-packable (1 in, 1 out, register delay lines)"
-                                       : "wave split: the graph is not that many groups of isomorphic segments in series (1 in, 1 out, register delay lines)");
-      if (reqP > 1) fail(FZ_E_INVALID, "wave split needs streams_per_lane == 1");
-      if (reqB && (reqB % 64 || reqB * waves > 1024)) fail(FZ_E_INVALID, "wave split: block_threads counts the streams of a workgroup: a multiple of 64, at most 1024 / waves per tuple");
-      if (reqU && reqU != 8 && reqU != 16 && reqU != 32) fail(FZ_E_INVALID, "wave split: unroll must be 8, 16 or 32");
-      if (v.flags & (FZ_VF_STREAM_MAJOR | FZ_VF_OUT_F64 | FZ_VF_PREFETCH3))
-         fail(FZ_E_UNSUPPORTED, "wave split: time-major / tiled float32 frames, double buffering only");
-      v.P = 1;
-      v.U = reqU ? reqU : (W == 1 ? 16 : 32);           // (one barrier per round: waves in lockstep do better with longer rounds -- two parts +1.5 %, three +8 %;
-                                                        //  the lone compute wave next to an I/O wave keeps 16: its rings fill the LDS at 32)
-      // the waves of a workgroup go to consecutive SIMDs of a CU: pairs come two to a workgroup (one wave on each of the
-      // four SIMDs), triples and quadruples one
-      // (with I/O waves: one compute wave on each SIMD and the I/O waves next to them -- 4 tuples for one part, 2 for two)
-      v.block = reqB ? reqB : (ws_io(v.flags) ? (W == 1 ? 256 : W == 2 ? 128 : 64) : (W == 2 ? 128 : 64));
-      {  // the rings of a workgroup must fit the CU's LDS: tuples x hand-offs x ring x 1 KiB (the kernel sizes every ring of a
-         // tuple for the widest hand-off: U groups behind a part that lags by more than 4 samples, else U / 2)
-         uint32_t kmax = 0;
-         for (const Graph& r : *g.wave_roles(W)) kmax = std::max(kmax, r.split.atoms());
-         const uint32_t ring = (kmax - 1 > 4 ? v.U : v.U / 2), nring = W - 1 + 2 * ws_io(v.flags);
-         while ((uint64_t)(v.block / 64) * nring * ring * 1024 > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
-         if ((uint64_t)(v.block / 64) * nring * ring * 1024 > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "wave split: the hand-off rings do not fit the LDS with this unroll and block size");
-      }
-      v.flags &= ~(uint32_t)(FZ_VF_STAGE_PACK | FZ_VF_NO_STAGE_PACK | FZ_VF_SLP);   // (each part is stage-packed by itself)
+}
+
+// W compute waves per 64 streams, each evaluating one part of the serial graph (fz_split.cpp: find_wave_roles), and with FZ_VF_IO_WAVE
+// one or two more waves for the frame I/O.  The waves of a workgroup go to consecutive SIMDs of a CU: as many tuples per workgroup as
+// put one compute wave on every SIMD.
+static Variant resolve_wave_split(const Graph& g, const Request& rq, Variant v)
+{
+   const uint32_t W = ws_parts(v.flags), waves = ws_waves(v.flags);
+   if (!g.wave_roles(W))
+      fail(FZ_E_UNSUPPORTED, W == 1 ? "FZ_VF_IO_WAVE: the graph is not stage-packable (1 in, 1 out, register delay lines)"
+                                    : "wave split: the graph is not that many groups of isomorphic segments in series (1 in, 1 out, register delay lines)");
+   if (rq.P > 1) fail(FZ_E_INVALID, "wave split needs streams_per_lane == 1");
+   if (rq.B && (rq.B % 64 || rq.B * waves > 1024)) fail(FZ_E_INVALID, "wave split: block_threads counts the streams of a workgroup: a multiple of 64, at most 1024 / waves per tuple");
+   if (rq.U && rq.U != 8 && rq.U != 16 && rq.U != 32) fail(FZ_E_INVALID, "wave split: unroll must be 8, 16 or 32");
+   if (v.flags & (FZ_VF_STREAM_MAJOR | FZ_VF_OUT_F64 | FZ_VF_PREFETCH3))
+      fail(FZ_E_UNSUPPORTED, "wave split: time-major / tiled float32 frames, double buffering only");
+   v.P = 1;
+   v.U = rq.U ? rq.U : (W == 1 ? 16 : 32);                  // rounds of 32 steps (one barrier each); the lone compute wave's rings fill the LDS at 32
+   v.block = rq.B ? rq.B : (ws_io(v.flags) ? (W == 1 ? 256 : W == 2 ? 128 : 64) : (W == 2 ? 128 : 64));
+   // the rings of a workgroup must fit the CU's LDS: tuples x hand-offs x ring x 1 KiB (every ring of a tuple is sized for the widest
+   // hand-off: U groups behind a part that lags by more than 4 samples, else U / 2)
+   uint32_t kmax = 0;
+   for (const Graph& r : *g.wave_roles(W)) kmax = std::max(kmax, r.split.atoms());
+   const uint32_t ring = (kmax - 1 > 4 ? v.U : v.U / 2), nring = W - 1 + 2 * ws_io(v.flags);
+   while ((uint64_t)(v.block / 64) * nring * ring * 1024 > kMaxLdsBytes && !rq.B && v.block > 64) v.block /= 2;
+   if ((uint64_t)(v.block / 64) * nring * ring * 1024 > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "wave split: the hand-off rings do not fit the LDS with this unroll and block size");
+   v.flags &= ~(uint32_t)(FZ_VF_STAGE_PACK | FZ_VF_NO_STAGE_PACK | FZ_VF_SLP);   // (each part is stage-packed by itself)
+   return v;
+}
+
+// Plain time-major frames of many streams: one workgroup per CU in lockstep, the CUs of an XCD in step.  From one wave per
+// SIMD and CU of work on, blocks of >= 1024 rows, narrow frames (four / two / one stream per lane as the registers allow) or 3-8 wire
+// frames (one stream per lane), register delay lines only, nothing asked for by the caller.
+static bool lockstep_default(const Graph& g, Variant& v, uint64_t n_streams, uint32_t n_samples, uint32_t allow_lockstep)
+{
+   const bool wide = (g.n_in > 2 || g.n_out > 2) && g.n_in <= 8 && g.n_out <= 8 && !g.typed;
+   if (!(n_samples >= kLockstepMinRows && n_streams >= (uint64_t)chip_cus() * 1024u && ((g.n_in <= 2 && g.n_out <= 2) || wide) &&
+         g.far_lines.empty() && g.n_lds_slots == 0 && !(g.typed && (n_streams % 4))))
+      return false;
+   const uint32_t cap = wide ? 1u : allow_lockstep >= 3 ? 4u : allow_lockstep;
+   const TmGeometry geo = time_major_geometry(n_streams, cap, g.n_ops > 30, !g.typed);
+   v.P = geo.P;
+   v.U = wide ? (geo.laps > 1 ? 2u : 1u) : geo.U;           // wide frames: one row per buffer in one lap, chunks of two rows from two laps on
+   v.block = geo.lanes;
+   v.flags |= FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC | (v.U == 1 ? (uint32_t)FZ_VF_PREFETCH3 : 0u);
+   if (v.P == 1 && g.split.ok && n_samples >= 16u * (g.split.atoms() - 1)) {   // one stream per lane and a series of isomorphic segments: stage-packed
+      v.flags |= FZ_VF_STAGE_PACK;
+      v.flags &= ~(uint32_t)FZ_VF_PREFETCH3;
+      v.U = std::max(v.U, 4u);
+   }
+   return true;
+}
+
+// Stream-major frames (fz_run_block_stream_major): the pair long-run body for deep 1-in/1-out graphs on many streams, the one-stream
+// long-run body for other 1-in/1-out graphs, else short chunks; one-wave workgroups for the long-run bodies (a CU refills wave by wave).
+static Variant resolve_stream_major(const Graph& g, const Request& rq, Variant v, uint64_t n_streams, uint32_t n_samples)
+{
+   const fz_variant* uv = rq.uv;
+   if (rq.P > 2) fail(FZ_E_INVALID, "stream-major frames take one or two streams per lane");
+   if (rq.U % 4) fail(FZ_E_INVALID, "stream-major frames need unroll % 4 == 0");
+   if (!g.far_lines.empty()) fail(FZ_E_UNSUPPORTED, "stream-major frames: delay lines beyond 256 samples are not supported");
+   if (v.flags & (FZ_VF_OUT_F64 | FZ_VF_PREFETCH3)) fail(FZ_E_UNSUPPORTED, "stream-major frames: float32 frames, double buffering only");
+   v.P = rq.P ? rq.P : 1u;
+   // the pair body when its 512-stream workgroups fill the chip's rounds as well as the one-stream body's 256-stream ones do
+   auto fill = [](uint64_t ns, uint64_t per_wg) {
+      const uint64_t cus = chip_cus(), wg = (ns + per_wg - 1) / per_wg, rounds = (wg + cus - 1) / cus;
+      return (double)wg / (double)(rounds * cus);
+   };
+   const bool enough = n_streams >= (1u << 19) || (n_streams >= (1u << 17) && fill(n_streams, 512) >= fill(n_streams, 256) - 0.02);
+   if (!uv_has_shape(uv) && g.n_in == 1 && g.n_out == 1 && g.n_lds_slots == 0 && g.far_lines.empty() && g.n_param <= 32 && g.n_mod == 0 &&
+       !g.typed && g.n_ops > 27 && g.n_state <= 20 && enough && n_streams % 2 == 0 && n_samples >= 256) {
+      v.P = 2;
+      v.flags |= FZ_VF_SM_LONG;
+   }
+   // stage packing (one stream per lane) carries over; automatic only for graphs deep enough to be VALU-bound with one stream per lane
+   if (v.P != 1 || !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
+   else if (!(uv && (uv->flags & FZ_VF_NO_STAGE_PACK)) && n_samples >= 16u * (g.split.atoms() - 1) && g.n_ops > 27) v.flags |= FZ_VF_STAGE_PACK;
+   const uint32_t nw = std::max<uint32_t>(std::max(g.n_in, g.n_out), 1);
+   const bool long_ok = g.n_in == 1 && g.n_out == 1 && v.P == 1 && g.n_lds_slots == 0 && (!g.split.ok || g.split.atoms() <= 13);
+   const bool pair_ok = g.n_in == 1 && g.n_out == 1 && v.P == 2 && g.n_lds_slots == 0 && !g.typed;
+   const bool want_short = uv && (uv->flags & FZ_VF_SM_SHORT);
+   v.flags &= ~(uint32_t)FZ_VF_SM_SHORT;
+   if ((v.flags & FZ_VF_SM_LONG) && v.P == 2) {               // pair long-run body: halves of 64 samples, 512-byte out-runs
+      if (!pair_ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG with two streams per lane: needs a 1-in/1-out float graph (not fz_compile_typed), no delay lines beyond 8 samples");
+      if (rq.U && rq.U != 64) fail(FZ_E_INVALID, "FZ_VF_SM_LONG with two streams per lane: unroll must be 64");
+      v.U = 64;
+      if (!rq.B) v.block = 64;
+      auto lds_pair = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (2 * w.U + 4) * 4; };
+      while (lds_pair(v) > kMaxLdsBytes && !rq.B && v.block > 64) v.block /= 2;
+      if (lds_pair(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: the LDS patches do not fit this block size");
       return v;
    }
-   if (reqP) {
+   if (v.flags & FZ_VF_SM_LONG) {
+      if (!long_ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: needs a 1-in/1-out graph, one stream per lane, no delay lines beyond 8 samples");
+      if (rq.U && rq.U != 64 && rq.U != 128) fail(FZ_E_INVALID, "FZ_VF_SM_LONG: unroll must be 64 or 128");
+   } else if (long_ok && !want_short && !rq.U && n_samples >= 256) {
+      v.flags |= FZ_VF_SM_LONG;
+   }
+   if (v.flags & FZ_VF_SM_LONG) {                            // one-stream long-run body: 512-byte runs from 2048 samples on, else 256-byte
+      v.U = rq.U ? rq.U : (n_samples >= 2048 ? 128 : 64);
+      if ((v.flags & FZ_VF_STAGE_PACK) && !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
+      auto lds_long = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (w.U + 12) * 4; };
+      if (!rq.B) v.block = 64;
+      while (lds_long(v) > kMaxLdsBytes && !rq.B && v.block > 64) v.block /= 2;
+      if (lds_long(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: the LDS patches do not fit this block size");
+      return v;
+   }
+   // short chunks: the deepest chunk whose patches fit the CU's LDS
+   auto lds = [&](const Variant& w) { return (uint64_t)w.block * w.P * (w.U * nw + 4) * 4 + (uint64_t)g.n_lds_slots * w.block * 4 * w.P; };
+   if (!rq.U) {
+      v.U = 32;
+      while (v.U > 4 && lds(v) > kMaxLdsBytes) v.U /= 2;
+   }
+   if ((v.flags & FZ_VF_STAGE_PACK) && v.U <= g.split.atoms() - 1) {
+      if (uv && (uv->flags & FZ_VF_STAGE_PACK)) fail(FZ_E_INVALID, "stage-packed stream-major frames need unroll > number of segments - 1");
+      v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
+   }
+   while (lds(v) > kMaxLdsBytes && !rq.B && v.block > 64) v.block /= 2;
+   if (lds(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "stream-major frames: the LDS patches do not fit (too many wires per frame)");
+   // (two streams per lane with patches so large that a single wave fills the CU's LDS crawl: refuse)
+   if (v.P == 2 && (uint64_t)64 * v.P * (v.U * nw + 4) * 4 > kMaxLdsBytes / 4)
+      fail(FZ_E_UNSUPPORTED, "stream-major frames: two streams per lane leave one wave per CU with this many wires per frame and this "
+                             "unroll; use one stream per lane or a shorter unroll");
+   return v;
+}
+
+Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, uint32_t allow_lockstep)
+{
+   if (tile_streams >= n_streams) tile_streams = 0;
+   Variant v;
+   const Request rq{uv ? uv->streams_per_lane : 0u, uv ? uv->unroll : 0u, uv ? uv->block_threads : 0u, uv};
+   v.flags = uv ? uv->flags : 0;
+   check_request(g, rq, v);
+   if (ws_parts(v.flags)) return resolve_wave_split(g, rq, v);
+   if (rq.P) {
       // (the lockstep frame kernel on plain time-major rows takes any count: FZ_VF_RAGGED)
-      if (n_streams % reqP && !((v.flags & FZ_VF_LOCKSTEP) && !tile_streams && !g.typed && g.far_lines.empty() && g.n_lds_slots == 0))
+      if (n_streams % rq.P && !((v.flags & FZ_VF_LOCKSTEP) && !tile_streams && !g.typed && g.far_lines.empty() && g.n_lds_slots == 0))
          fail(FZ_E_INVALID, "n_streams must be a multiple of streams_per_lane");
-      v.P = reqP;
+      v.P = rq.P;
    } else {
-      // fill the chip first (256 CUs x 4 SIMDs, several waves each), then pack two streams per lane
-      // (v_pk_* issue at the scalar rate on gfx950: twice the lane-ops per cycle)
-      // -- unless the frames are already wide (>= 3 wires: 12+ bytes per lane with one stream)
-      // (measured crossover on the 6-biquad cascade: 2^18 streams, profiles/r01/sweep_stream_counts.txt)
+      // fill the chip first, then pack two streams per lane (narrow frames, from 2^18 even streams on); LDS rings: one stream per lane
+      // (vectorised in time a 16-byte LDS access carries four time steps, and 256 lanes put a wave on every SIMD)
       v.P = (n_streams >= (1u << 18) && n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) ? 2 : 1;
-      // LDS rings (round 5: vectorised in time, fz_codegen.cpp: ring_plan): one stream per lane -- a 16-byte LDS access then carries FOUR
-      // time steps, and a 256-lane workgroup puts a wave on every SIMD where two streams per lane leave room for 128 lanes only.
-      // Measured, the two combs of 40 and 23 samples at 1 M streams x 4096 (profiles/r05/sweeps_rings_typed_config2.txt): one stream per
-      // lane, 32-row chunks, 256 lanes 0.700-0.703 of peak; two streams, 128 lanes 0.60-0.66; 64 rows or three buffers in flight change nothing
       if (g.n_lds_slots && !(v.flags & FZ_VF_STREAM_MAJOR)) v.P = 1;
    }
-   // PLAIN TIME-MAJOR frames of many streams (round 3): consecutive rows are n_streams * wires * 4 bytes apart -- megabytes,
-   // i.e. every row a wave has in flight is another 2 MiB page, and waves that drift apart in time multiply the pages a CU
-   // touches (160 x the L1-TLB misses of tiled frames, profiles/r01/pmc_tlb_tiled_vs_timemajor.txt).  So the whole CU walks
-   // the rows together: ONE workgroup per CU that meets at a barrier after every chunk (FZ_VF_LOCKSTEP), few rows in flight per
-   // lane, and the workgroups of an XCD walk the rows together too (FZ_VF_GRID_SYNC): 0.76-0.79 of peak against 0.61-0.67 for
-   // four-wave workgroups that run free.  From one wave per SIMD and CU of work on (CUs x 1024 streams); narrow frames (4-wire
-   // frames gain nothing: their rows are wide already); register delay lines only.
-   // allow_lockstep caps the streams per lane: fz_finalize_variant steps it down (4 -> 2 -> 1) until the kernel fits the registers a
-   // lane of that workgroup gets; a graph that reaches one stream per lane and is a series of isomorphic segments runs STAGE-PACKED
-   // there -- packing by stages costs no registers per stream (the oscillator chain with its 31 per-stream coefficients: 0.70 of
-   // peak against 0.65 un-packed, where two streams per lane would need 155 registers).
-   // A stream count that is not a multiple of the streams per lane is no obstacle (FZ_VF_RAGGED, round 4): the last lane's
-   // accesses run past the end of the row, where the buffer descriptors of the rows return zeros and drop the writes (raw
-   // buffers are range-checked per dword, tools/oob_probe.hip), and rows that are only 4-byte aligned are fine for b64 / b128.
-   {
-      const bool nothing_asked = !reqP && !reqU && !reqB && !(v.flags & ~(uint32_t)FZ_VF_OUT_F64);
-      // (short blocks -- control-rate windows -- run free: the walk in step needs about a thousand rows to pay for its start.  1 M
-      //  streams, lockstep against free-running four-wave workgroups: 64-sample windows 0.57 / 0.77 of peak, 256 rows 0.60 / 0.66,
-      //  512 rows 0.64 / 0.66, 1024 rows level, 4096 rows 0.76 / 0.66 -- profiles/r04/sweep_block_lengths.txt)
-      // WIDE frames (three to eight wires; round 4): one stream per lane, 1024-lane workgroups.  Round 3 left them to the free-running
-      // workgroups ("their rows are wide already"); measured with laps as launches, the 4-wire sum x 4096 samples: 262 144 streams 3.36 ms
-      // against 3.95 ms (0.80 against 0.68 of peak), 1 000 000 streams 13.57 against 14.86 ms (0.76 / 0.69), 1 048 576 streams level
-      // (14.61 / 14.68 ms: rows exactly 16 MiB apart) -- profiles/r04/wide_frames_in_lockstep.txt.  One row per buffer and three buffers
-      // in one lap, chunks of two rows from two laps on (1 M streams: 14.61 against 15.03 ms).
-      const bool wide = (g.n_in > 2 || g.n_out > 2) && g.n_in <= 8 && g.n_out <= 8 && !g.typed;
-      if (allow_lockstep && nothing_asked && !tile_streams && n_samples >= kLockstepMinRows && n_streams >= (uint64_t)chip_cus() * 1024u && ((g.n_in <= 2 && g.n_out <= 2) || wide) &&
-          g.far_lines.empty() && g.n_lds_slots == 0 && !(g.typed && (n_streams % 4))) {
-         const uint32_t cap = wide ? 1u : allow_lockstep >= 3 ? 4u : allow_lockstep;
-         const TmGeometry geo = time_major_geometry(n_streams, cap, g.n_ops > 30, !g.typed);
-         v.P = geo.P;
-         v.U = wide ? (geo.laps > 1 ? 2u : 1u) : geo.U;
-         v.block = geo.lanes;
-         v.flags |= FZ_VF_LOCKSTEP | (v.U == 1 ? (uint32_t)FZ_VF_PREFETCH3 : 0u);
-         v.flags |= FZ_VF_GRID_SYNC;
-         if (v.P == 1 && g.split.ok && n_samples >= 16u * (g.split.atoms() - 1)) {
-            v.flags |= FZ_VF_STAGE_PACK;
-            v.flags &= ~(uint32_t)FZ_VF_PREFETCH3;
-            v.U = std::max(v.U, 4u);
-         }
-         return v;
-      }
-   }
-   // deep graphs: keep the register-resident delay lines + prefetch buffers inside the 512-entry
-   // VGPR/AGPR file (measured: a 24-stage cascade needs ~300 VGPRs at 2 streams per lane)
+   const bool nothing_asked = !rq.P && !rq.U && !rq.B && !(v.flags & ~(uint32_t)FZ_VF_OUT_F64);
+   if (allow_lockstep && nothing_asked && !tile_streams && lockstep_default(g, v, n_streams, n_samples, allow_lockstep)) return v;
+   // deep graphs: register delay lines + prefetch buffers must stay inside the 512-entry register file
    uint32_t reg_state = 0;
    for (const Line& l : g.lines)
       if (!l.in_lds) reg_state += l.depth;
-   if (!reqP && v.P == 2 && reg_state > 36) v.P = 1;
-   // prefetch depth in time steps: 16 rows in flight per lane; 32 once the chip is oversubscribed
-   // with packed lanes (fewer, fatter waves: 2 per SIMD)
-   // (per-stream coefficients sit in VGPRs too: with 31 of them the deep prefetch costs 10 %)
-   // (round 3: 16 rows for packed lanes too.  32 rows in flight measured level with 16 on the boards of rounds 1-2 and 13 % SLOWER
-   //  on two boards of round 3 -- 6.54 / 6.56 ms against 5.76 / 5.79 ms for the headline workload, gpurun_out/r03a-b -- so the
-   //  deeper prefetch is left to fz_program_tune)
-   v.U = reqU ? reqU : 16;
-   // wide frames, one stream per lane, chip oversubscribed: 32 rows in flight per lane (measured on three boards, 4-wire
-   // frames at 1 M streams: 13.4-14.1 ms against 14.4-14.6 ms with 16; profiles/r02/tune_logs.txt)
-   if (!reqU && v.P == 1 && g.n_in >= 3 && n_streams >= (1u << 19) && !(v.flags & FZ_VF_STAGE_PACK)) v.U = 32;
-   // (few streams, one stream per lane, no stage packing: 16 against 32 rows is board-dependent -- the fan-out 4-biquad sum at
-   //  65 536 streams measured 0.65 / 0.74 of peak on one board and 0.79 / 0.69 on the next; fz_program_tune tries both)
-   if (!reqU && reg_state * v.P > 60) v.U = 8;
-   // LDS rings leave room for one or two waves per SIMD (96 slots x 8 bytes per lane: 98 KiB for a 128-lane workgroup), so the rows in
-   // flight per wave must cover the latency alone: 32 rows per chunk -- 1 M streams x 4096, two combs (40 and 23 samples): 6.45 ms
-   // against 7.27 ms with 16 (0.68 against 0.60 of peak; one stream per lane 6.51 against 6.76; profiles/r04/sweep_next_rows.txt)
-   else if (!reqU && g.n_lds_slots && !(v.flags & FZ_VF_STAGE_PACK)) v.U = 32;
+   if (!rq.P && v.P == 2 && reg_state > 36) v.P = 1;
+   // rows per chunk: 16; 32 for wide frames of one stream per lane on an oversubscribed chip and for LDS rings; 8 for register-heavy lanes
+   v.U = rq.U ? rq.U : 16;
+   if (!rq.U && v.P == 1 && g.n_in >= 3 && n_streams >= (1u << 19) && !(v.flags & FZ_VF_STAGE_PACK)) v.U = 32;
+   if (!rq.U && reg_state * v.P > 60) v.U = 8;
+   else if (!rq.U && g.n_lds_slots && !(v.flags & FZ_VF_STAGE_PACK)) v.U = 32;
    if (!g.far_lines.empty()) {
-      // far (HBM ring) reads are prefetched one chunk ahead: a read must be two chunks old, so the chunk
-      // is at most half the youngest ring read (16 steps from kFarMinDelay = 32 on, 4 for a 9-sample read)
+      // far (HBM ring) reads are prefetched one chunk ahead: the chunk is at most half the youngest ring read
       const uint32_t cap = std::min(16u, std::max(1u, g.far_min_read ? g.far_min_read / 2 : 16u));
-      if (reqU > cap) fail(FZ_E_INVALID, "graphs with delays beyond LDS need unroll <= " + std::to_string(cap));
+      if (rq.U > cap) fail(FZ_E_INVALID, "graphs with delays beyond LDS need unroll <= " + std::to_string(cap));
       if (v.flags & FZ_VF_PREFETCH3) fail(FZ_E_INVALID, "FZ_VF_PREFETCH3 is not available with delays beyond LDS");
       v.U = std::min(v.U, cap);
    }
-   // wave split: fewer streams than 128 per CU -- W waves per 64 streams, each one part of the serial graph (measured,
-   // 6-biquad cascade, ms per 4096 samples: 32 768 streams 0.23 with two parts against 0.31-0.33 with the single wave;
-   // 16 384 streams 0.17 with three parts, 0.22 with two, 0.30 single; at 49 152 streams the 384 workgroups of pairs no
-   // longer spread evenly over 256 CUs and the single-wave kernel wins again; profiles/r02/sweep_wave_split.txt)
-   if (!reqP && !reqB && n_samples >= 256 && (reqU == 0 || reqU == 8 || reqU == 16 || reqU == 32) &&
+   // few streams: the most parts whose waves still find a SIMD each (<= 16 384 streams: four or three, <= 32 768: two), with an I/O wave
+   if (!rq.P && !rq.B && n_samples >= 256 && (rq.U == 0 || rq.U == 8 || rq.U == 16 || rq.U == 32) &&
        !(v.flags & (FZ_VF_STAGE_PACK | FZ_VF_NO_STAGE_PACK | FZ_VF_OUT_F64 | FZ_VF_PREFETCH3 | FZ_VF_STREAM_MAJOR | FZ_VF_SLP))) {
-      // the most parts whose waves still find a SIMD each: W waves per 64 streams on 1024 SIMDs, whole workgroups per CU
-      // (pairs: two to a workgroup, 128 streams per CU; triples / quadruples: one workgroup of 64 streams per CU)
       uint32_t W = 0;
       if (n_streams <= 16384) W = g.wave_roles(4) ? 4 : g.wave_roles(3) ? 3 : 0;
       if (!W && n_streams <= 32768 && g.wave_roles(2)) W = 2;
-      // The splits come with an I/O wave (FZ_VF_IO_WAVE): +2-4 % on every board measured (three parts at 16 384 streams:
-      // 0.397 / 0.406 / 0.397 / 0.428 of peak against 0.387 / 0.394 / 0.384 / 0.410; two parts at 32 768: 0.596 / 0.593 against
-      // 0.580 / 0.574).  The lone compute wave with an I/O wave at 65 536 streams is NOT a default: +3 % on one board -- 0.374 ms
-      // against 0.387 ms per 4096 samples, 97 % of what a plain copy gets there -- and -4 % on the next; fz_program_tune tries
-      // it (profiles/r02/sweep_io_wave.txt)
       if (W) {
-         fz_variant q{1, reqU, 0, v.flags | (W - 1) << 10 | (W < 4 ? (uint32_t)FZ_VF_IO_WAVE : 0u)};
+         fz_variant q{1, rq.U, 0, v.flags | (W - 1) << 10 | (W < 4 ? (uint32_t)FZ_VF_IO_WAVE : 0u)};
          return resolve_variant(g, &q, n_streams, n_samples, tile_streams, allow_lockstep);
       }
    }
-   // stage packing: one stream per lane, pairs of isomorphic graph segments in one v_pk_* (fz_split.cpp)
+   // stage packing: one stream per lane, pairs of isomorphic graph segments in one v_pk_* (fz_split.cpp); automatic unless the block is
+   // so short that the masked steps at either end would dominate
    if (v.flags & FZ_VF_STAGE_PACK) {
       if (!g.split.ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_STAGE_PACK: the graph is not a series of isomorphic segments");
       if (v.P != 1) fail(FZ_E_INVALID, "FZ_VF_STAGE_PACK needs streams_per_lane == 1");
-   } else if (!reqP && v.P == 1 && g.split.ok && !(v.flags & FZ_VF_NO_STAGE_PACK) &&
-              n_samples >= 16u * (g.split.atoms() - 1)) {
-      // automatic below 2^18 streams, unless the block is so short that the K-1 masked steps at
-      // either end would dominate
+   } else if (!rq.P && v.P == 1 && g.split.ok && !(v.flags & FZ_VF_NO_STAGE_PACK) && n_samples >= 16u * (g.split.atoms() - 1)) {
       v.flags |= FZ_VF_STAGE_PACK;
    }
    v.flags &= ~(uint32_t)FZ_VF_NO_STAGE_PACK;
-   v.block = reqB ? reqB : 256;
-   if (v.flags & FZ_VF_STREAM_MAJOR) {
-      // stream-major frames (fz_run_block_stream_major): one stream per lane, chunks of whole float4 pieces
-      if (reqP > 2) fail(FZ_E_INVALID, "stream-major frames take one or two streams per lane");
-      if (reqU % 4) fail(FZ_E_INVALID, "stream-major frames need unroll % 4 == 0");
-      if (!g.far_lines.empty()) fail(FZ_E_UNSUPPORTED, "stream-major frames: delay lines beyond 256 samples are not supported");
-      if (v.flags & (FZ_VF_OUT_F64 | FZ_VF_PREFETCH3)) fail(FZ_E_UNSUPPORTED, "stream-major frames: float32 frames, double buffering only");
-      // one stream per lane: two (packed FP32) are possible but measured slower everywhere -- twice the
-      // patch traffic per wave and 360 VGPRs (profiles/r01/stream_major_kernel.txt)
-      v.P = reqP ? reqP : 1u;
-      // ... except for DEEP 1-in/1-out graphs on many streams and blocks long enough for the long-run bodies: the PAIR long-run
-      // body (below) carries two streams per lane with every node ONE packed instruction -- 28.0 instructions per stream and step in the
-      // loop of the 6-biquad cascade where the stage-packed body issues 30.4 (two moves per step: the chain's crossing from the low to
-      // the high half, the output's way out of the high half) -- measured at
-      // 1 M streams: 6.12-6.13 ms against 6.38-6.42 ms per 4096 samples (0.70 of peak against 0.67), 1.66-1.68 against 1.81-1.88 ms
-      // per 1024; level at 262 144 streams, and SLOWER for shallow graphs (2 biquads 5.84 against 5.45 ms, one 7.29 against 5.77: a
-      // lone wave with one packed chain per step runs at the latency of the chain) -- profiles/r03/stream_major_pair_body.txt
-      // Below 2^19 streams the pair body's workgroups (512 streams, one per CU at a time) are few: it is chosen when they fill the
-      // chip's rounds as well as the one-stream body's 256-stream workgroups do -- measured x 4096 samples (tools/experiments/
-      // exp_r03pair_threshold.py): 131 072 streams 0.775 against 0.804-0.815 ms, 262 144 1.69 against 1.67 (level), 393 216 2.28
-      // against 2.41, 524 288 3.00 against 3.20; at 65 536 its 128 workgroups would leave half of the CUs idle
-      auto fill = [](uint64_t ns, uint64_t per_wg) {
-         const uint64_t cus = chip_cus(), wg = (ns + per_wg - 1) / per_wg, rounds = (wg + cus - 1) / cus;
-         return (double)wg / (double)(rounds * cus);
-      };
-      const bool enough = n_streams >= (1u << 19) || (n_streams >= (1u << 17) && fill(n_streams, 512) >= fill(n_streams, 256) - 0.02);
-      // (per-stream coefficients ride along as packed pairs -- the oscillator chain with its 31: 6.38-6.43 ms against 6.70-6.79 ms for
-      //  the stage-packed one-stream body on two boards of round 4; a graph whose registers do not fit falls back in settle_variant)
-      if (!uv_has_shape(uv) && g.n_in == 1 && g.n_out == 1 && g.n_lds_slots == 0 && g.far_lines.empty() && g.n_param <= 32 && g.n_mod == 0 &&
-          !g.typed && g.n_ops > 27 && g.n_state <= 20 && enough && n_streams % 2 == 0 && n_samples >= 256) {
-         v.P = 2;
-         v.flags |= FZ_VF_SM_LONG;
-      }
-      // stage packing (one stream per lane) carries over: the skew only shifts which output chunk a step completes.
-      // It is what lifts deep serial graphs off the VALU floor here, whatever the stream count.
-      if (v.P != 1 || !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
-      // (automatic only for graphs deep enough to be VALU-bound with one stream per lane: packing takes the in-runs of
-      //  the long-run body off the 512-byte grid, which costs ~10 % of the read rate -- measured: a 2-stage cascade runs
-      //  5.3-5.9 TB/s unpacked against 4.6-5.5 packed, a 6-stage one 4.6 against 5.3)
-      else if (!(uv && (uv->flags & FZ_VF_NO_STAGE_PACK)) && n_samples >= 16u * (g.split.atoms() - 1) && g.n_ops > 27) v.flags |= FZ_VF_STAGE_PACK;
-      const uint32_t nw = std::max<uint32_t>(std::max(g.n_in, g.n_out), 1);
-      // long-run body (512-byte runs per stream): 1-in/1-out graphs with register-resident state, blocks of at least two phases
-      const bool long_ok = g.n_in == 1 && g.n_out == 1 && v.P == 1 && g.n_lds_slots == 0 && (!g.split.ok || g.split.atoms() <= 13);
-      // the PAIR long-run body (two streams per lane, halves of 64 samples, 512-byte out-runs): on request
-      // (streams_per_lane = 2 with FZ_VF_SM_LONG); every node one packed instruction, no stage packing
-      const bool pair_ok = g.n_in == 1 && g.n_out == 1 && v.P == 2 && g.n_lds_slots == 0 && !g.typed;
-      const bool want_short = uv && (uv->flags & FZ_VF_SM_SHORT);
-      v.flags &= ~(uint32_t)FZ_VF_SM_SHORT;
-      if ((v.flags & FZ_VF_SM_LONG) && v.P == 2) {
-         if (!pair_ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG with two streams per lane: needs a 1-in/1-out float graph (not fz_compile_typed), no delay lines beyond 8 samples");
-         if (reqU && reqU != 64) fail(FZ_E_INVALID, "FZ_VF_SM_LONG with two streams per lane: unroll must be 64");
-         v.U = 64;
-         if (!reqB) v.block = 64;                          // one-wave workgroups (see the one-stream body below)
-         auto lds_pair = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (2 * w.U + 4) * 4; };
-         while (lds_pair(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
-         if (lds_pair(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: the LDS patches do not fit this block size");
-         return v;
-      }
-      if (v.flags & FZ_VF_SM_LONG) {
-         if (!long_ok) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: needs a 1-in/1-out graph, one stream per lane, no delay lines beyond 8 samples");
-         if (reqU && reqU != 64 && reqU != 128) fail(FZ_E_INVALID, "FZ_VF_SM_LONG: unroll must be 64 or 128");
-      } else if (long_ok && !want_short && !reqU && n_samples >= 256) {
-         v.flags |= FZ_VF_SM_LONG;
-      }
-      if (v.flags & FZ_VF_SM_LONG) {
-         // 512-byte runs per stream from 2048 samples on; shorter blocks do better with 256-byte runs (64-sample phases: patches of
-         // 19 KB per wave, two workgroups per CU, half the pipeline fill) -- 1 M streams x 1024: 1.78 ms against 1.92 ms; x 4096: 6.97
-         // against 6.65 ms (gpurun_out/r03j -> profiles/r03/stream_major_kernel.txt)
-         v.U = reqU ? reqU : (n_samples >= 2048 ? 128 : 64);
-         // stage packing rides along when the block is long enough for the masked ends not to matter
-         if ((v.flags & FZ_VF_STAGE_PACK) && !g.split.ok) v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
-         // (patch rows: the lag of the in-run -- the skew rounded up to whole float4, at most 12 -- + the run, stride 4 mod 8 floats)
-         auto lds_long = [&](const Variant& w) { return (uint64_t)(w.block / 64) * 64 * (w.U + 12) * 4; };
-         // Workgroups of ONE wave (round 4, both long-run bodies): the patches of four waves fill a CU's LDS, so a four-wave workgroup
-         // can only start when four waves have finished, a one-wave workgroup whenever one has -- the CU refills wave by wave.  Measured,
-         // 6-biquad cascade x 4096, 64 / 128 / 256 lanes: 1 M streams 6.11 / 6.16 / 6.19 ms, 786 432 4.55 / 4.59 / 4.66, 262 144 1.60-1.67 /
-         // 1.69-1.71 / 1.72, 65 536 0.395 / 0.409 / 0.421; 1 M x 1024 rows 1.67 / 1.70 / 1.72; two biquads 5.45 / 5.51 / 5.59 (262 144: 1.47 /
-         // 1.50 / 1.53); oscillator chain 6.63 / 6.68 / 6.75; one biquad level (profiles/r04/stream_major_few_streams.txt,
-         // stream_major_workgroup_sizes.txt)
-         if (!reqB) v.block = 64;
-         while (lds_long(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
-         if (lds_long(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "FZ_VF_SM_LONG: the LDS patches do not fit this block size");
-         return v;
-      }
-      auto lds = [&](const Variant& w) { return (uint64_t)w.block * w.P * (w.U * nw + 4) * 4 + (uint64_t)g.n_lds_slots * w.block * 4 * w.P; };
-      if (!reqU) {
-         // the longer the run of one stream inside a chunk the better it streams (measured: 128 B per
-         // stream and wire 2x faster than 64 B): the deepest chunk whose patches fit the CU's LDS
-         v.U = 32;
-         while (v.U > 4 && lds(v) > kMaxLdsBytes) v.U /= 2;
-      }
-      if ((v.flags & FZ_VF_STAGE_PACK) && v.U <= g.split.atoms() - 1) {
-         if (uv && (uv->flags & FZ_VF_STAGE_PACK)) fail(FZ_E_INVALID, "stage-packed stream-major frames need unroll > number of segments - 1");
-         v.flags &= ~(uint32_t)FZ_VF_STAGE_PACK;
-      }
-      while (lds(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
-      if (lds(v) > kMaxLdsBytes) fail(FZ_E_UNSUPPORTED, "stream-major frames: the LDS patches do not fit (too many wires per frame)");
-      // two streams per lane with patches so large that a single wave fills the CU's LDS: measured 20 x slower than one
-      // stream per lane (4-wire frames, 32-sample chunks: 10.3 ms against 0.95 ms) -- refuse instead of crawling
-      if (v.P == 2 && (uint64_t)64 * v.P * (v.U * nw + 4) * 4 > kMaxLdsBytes / 4)   // the PATCH of one wave: fewer than one wave per SIMD fit
-         fail(FZ_E_UNSUPPORTED, "stream-major frames: two streams per lane leave one wave per CU with this many wires per frame and this "
-                                "unroll; use one stream per lane or a shorter unroll");
-      return v;
-   }
-   const bool plain_auto = !reqP && !reqU && !reqB && !(v.flags & ~(uint32_t)FZ_VF_OUT_F64);   // nothing asked for: the library's choice
-   // stream-tiled frames, packed lanes, chip oversubscribed: two workgroups per CU (262 144 streams in flight keep fewer tiles
-   // open in DRAM: +2 % on the boards of round 3, level on those of round 2; profiles/r01/sweep_occupancy_cap.txt)
-   if (plain_auto && tile_streams && v.P == 2 && n_streams >= (1u << 19) && !g.n_lds_slots) v.flags |= FZ_VF_MAX_WG(2);
+   v.block = rq.B ? rq.B : 256;
+   if (v.flags & FZ_VF_STREAM_MAJOR) return resolve_stream_major(g, rq, v, n_streams, n_samples);
+   // stream-tiled frames, packed lanes, chip oversubscribed: two workgroups per CU
+   if (nothing_asked && tile_streams && v.P == 2 && n_streams >= (1u << 19) && !g.n_lds_slots) v.flags |= FZ_VF_MAX_WG(2);
    if (g.n_lds_slots) {
-      // LDS rings: slots * block * 4P bytes must fit the CU's 160 KiB of LDS (one workgroup may take it all)
-      auto bytes = [&](const Variant& w) { return (uint64_t)ring_plan(g, w).slots * w.block * 4u * w.P; };   // (the vectorised rings pad their rows)
-      while (bytes(v) > kMaxLdsBytes && !reqB && v.block > 64) v.block /= 2;
-      while (bytes(v) > kMaxLdsBytes && !reqP && v.P > 1) v.P /= 2;
+      // LDS rings: a workgroup's rings must fit the CU's 160 KiB (the vectorised rings pad their rows)
+      auto bytes = [&](const Variant& w) { return (uint64_t)ring_plan(g, w).slots * w.block * 4u * w.P; };
+      while (bytes(v) > kMaxLdsBytes && !rq.B && v.block > 64) v.block /= 2;
+      while (bytes(v) > kMaxLdsBytes && !rq.P && v.P > 1) v.P /= 2;
       if (bytes(v) > kMaxLdsBytes)
-         fail(FZ_E_UNSUPPORTED, "delay lines too long for the LDS ring buffers of this build (" +
-                                   std::to_string(g.n_lds_slots) + " slots)");
+         fail(FZ_E_UNSUPPORTED, "delay lines too long for the LDS ring buffers of this build (" + std::to_string(g.n_lds_slots) + " slots)");
    }
    return v;
 }
