@@ -161,6 +161,10 @@ constexpr uint32_t FZ_VF_RAGGED = 1u << 28;
 // sectors / lines at the ends of their footprints, and the frame stores must let L2 merge them (nt instead of nt | sc1; set by
 // finalize_variant, profiles/r04/rows_off_the_grid_store_policy.txt)
 constexpr uint32_t FZ_VF_ST_MERGE = 1u << 29;
+// internal: four streams per lane as TWO PAIRS 128 streams apart (the wave still covers 256 adjacent streams): frames whose lane slice
+// would leave in two 16-byte stores -- typed frames of 8 bytes per stream -- then store whole 32-byte sectors per instruction (lanes'
+// 16-byte pieces side by side) and can be written through like every other frame (fz_block_kernel.hip.inc: FZ_PAIRS; set by finalize_variant)
+constexpr uint32_t FZ_VF_LANE_PAIRS = 1u << 30;
 constexpr uint32_t kChipCUs = 256;       // MI355X (gfx950): 8 XCDs x 32 CUs -- what chip_cus() answers on a box without a GPU
 unsigned chip_cus();                     // compute units of the current device (fz_launch.cpp)
 

@@ -380,6 +380,16 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
          const uint64_t out_row_bytes = n_streams * (uint64_t)std::max<uint32_t>(g.n_out, 1) * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 8u : 4u);
          if (out_row_bytes % kStoreGridBytes) v.flags |= FZ_VF_ST_MERGE;
       }
+      // four streams per lane whose output slice is TWO 16-byte pieces (typed frames of 8 bytes per stream): the lane takes two pairs of
+      // streams 128 apart instead, so that every store instruction writes whole sectors (FZ_VF_LANE_PAIRS)
+      v.flags &= ~FZ_VF_LANE_PAIRS;
+      {
+         const uint32_t out_floats = g.n_out * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 2u : 1u);
+         static const bool off = std::getenv("FLOWZ_HIP_NO_LANE_PAIRS") != nullptr;       // (developer switch: the adjacent-streams kernel for comparison)
+         if (!off && v.P == 4 && out_floats == 2 && !stream_major && !ws_parts(v.flags) && !(v.flags & (FZ_VF_RAGGED | FZ_VF_STAGE_PACK)) && g.far_lines.empty() &&
+             n_streams % 256 == 0 && (!tile_streams || tile_streams % 256 == 0))
+            v.flags |= FZ_VF_LANE_PAIRS;
+      }
       static const bool kernel_laps = [] { const char* e = std::getenv("FLOWZ_HIP_LAPS"); return e && std::strcmp(e, "kernel") == 0; }();
       v.flags &= ~FZ_VF_PERSIST;
       if (kernel_laps && (v.flags & FZ_VF_GRID_SYNC) && ((n_streams + v.P - 1) / v.P + v.block - 1) / v.block > chip_cus()) v.flags |= FZ_VF_PERSIST;
