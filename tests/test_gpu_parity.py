@@ -452,6 +452,76 @@ def _typed_gpu(torch, F, prog, frames_host, variant=None, state=None, tile=0, st
     return y.cpu().numpy(), st
 
 
+@pytest.mark.parametrize("ns", [256, 768, 2048, 5120])
+def test_lane_groups_vs_oracle(torch_cuda, F, ns):
+    """Lane groups (round 5, internal flags FZ_VF_LANE_PAIRS / _SINGLES; letters L / S in the kernel name): whole waves of 64 P adjacent
+    streams whose lanes take their P streams in groups 64 x group size apart, so that no access of a lane is wider than 16 bytes.  Typed
+    frames of 8 bytes per stream with four streams per lane (pairs), 4-wire frames with two and four streams per lane (singles), a
+    2-in / 2-out float graph (pairs): free-running and in lockstep, chained blocks, state bit-identical to the adjacent-streams kernels."""
+    torch = torch_cuda
+    T = 101
+    L, GS, P3 = F.C.FZ_VF_LOCKSTEP, F.C.FZ_VF_GRID_SYNC, F.C.FZ_VF_PREFETCH3
+    x1 = O.synth_input(SEED + 71, np.arange(ns), T)
+    # typed graphs: (graph, oracle output as packed frames)
+    typed = [(G.complex_one_pole(), C.complex_one_pole(x1, std=True)), (G.complex_div_mix(), C.complex_div_mix(x1, std=True))]
+    gd = W.df1_double() if hasattr(W, "df1_double") else None
+    for g, want in typed:
+        prog = F.compile(F.from_sexpr(g), typed=True)
+        ref, st_ref = _typed_gpu(torch, F, prog, x1, F.make_variant(1, 8))
+        assert ndiff(ref, want) == 0
+        for v in ((4, 8, 256, 0), (4, 4, 64, 0), (4, 1, 256, L | P3), (4, 2, 128, L | GS), (4, 16, 0, 0)):
+            if ns % 256:
+                continue
+            vv = F.make_variant(*v)
+            assert prog.kernel_name(vv, ns, T).endswith("L"), prog.kernel_name(vv, ns, T)
+            got, st = _typed_gpu(torch, F, prog, x1, vv)
+            assert ndiff(got, want) == 0 and torch.equal(st.view(torch.int32), st_ref.view(torch.int32)), (ns, v)
+            a, st1 = _typed_gpu(torch, F, prog, x1[:40], vv)
+            b, st2 = _typed_gpu(torch, F, prog, x1[40:], F.make_variant(2, 8), state=st1)           # ... continued by an adjacent-streams kernel
+            assert ndiff(np.concatenate([a, b]), want) == 0 and torch.equal(st2.view(torch.int32), st_ref.view(torch.int32))
+    # a double biquad (double state rows: fz_ld_row64 / fz_st_row64 in groups)
+    from zignal_amd import workloads as ZW
+    g = ZW.df1_double()
+    prog = F.compile(F.from_sexpr(g), typed=True)
+    want = O.run_typed(O.compile(g, ns, typed=True), [x1[:, :, 0]])
+    ref, st_ref = _typed_gpu(torch, F, prog, x1, F.make_variant(2, 8))
+    for a_, b_ in zip(F.unpack_typed(ref, prog.output_dtypes()), want):
+        assert np.array_equal(a_, b_)
+    for v in ((4, 8, 256, 0), (4, 1, 256, L | P3)):
+        vv = F.make_variant(*v)
+        assert prog.kernel_name(vv, ns, T).endswith("L")
+        got, st = _typed_gpu(torch, F, prog, x1, vv)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and torch.equal(st.view(torch.int32), st_ref.view(torch.int32)), (ns, v)
+    # 4-wire frames (the 4-parallel sum): singles with two and four streams per lane
+    g = G.par4_sum()
+    prog = F.compile(F.from_sexpr(g))
+    x4 = O.synth_input(SEED + 72, np.arange(ns), T, n_wires=4)
+    want = O.compile(g, ns).run(x4)
+    ref, st_ref = run_gpu(torch, F, prog, x4, variant=F.make_variant(1, 8))
+    assert ndiff(ref, want) == 0
+    for v in ((2, 8, 128, 0), (2, 1, 128, L | P3), (2, 2, 128, L | GS), (4, 4, 64, 0), (2, 16, 0, 0)):
+        if ns % (64 * v[0]):
+            continue
+        vv = F.make_variant(*v)
+        assert prog.kernel_name(vv, ns, T).endswith("S"), prog.kernel_name(vv, ns, T)
+        got, st = run_gpu(torch, F, prog, x4, variant=vv)
+        assert ndiff(got, want) == 0 and torch.equal(st, st_ref), (ns, v)
+    # 2 wires in, 2 wires out (two biquads side by side): pairs with four streams per lane
+    g = G.par(G.df1(*G.STABLE), G.df1(*G.PAR4_SETS[1]))
+    prog = F.compile(F.from_sexpr(g))
+    x2 = O.synth_input(SEED + 73, np.arange(ns), T, n_wires=2)
+    want = O.compile(g, ns).run(x2)
+    for v in ((4, 8, 256, 0), (4, 2, 64, L)):
+        if ns % 256:
+            continue
+        vv = F.make_variant(*v)
+        assert prog.kernel_name(vv, ns, T).endswith("L")
+        got, _ = run_gpu(torch, F, prog, x2, variant=vv)
+        assert ndiff(got, want) == 0, (ns, v)
+    # the developer switch of the comparison kernels leaves the names bare
+    assert not F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(F.make_variant(4, 8, 256), ns, T).endswith(("L", "S"))
+
+
 @pytest.mark.parametrize("P", [0, 1, 2, 4])
 def test_typed_programs_complex_state_division_double_state(torch_cuda, F, P):
     """fz_compile_typed on the GPU vs std::complex<float> compiled by g++ / compiled C with double state: the complex

@@ -165,6 +165,9 @@ constexpr uint32_t FZ_VF_ST_MERGE = 1u << 29;
 // would leave in two 16-byte stores -- typed frames of 8 bytes per stream -- then store whole 32-byte sectors per instruction (lanes'
 // 16-byte pieces side by side) and can be written through like every other frame (fz_block_kernel.hip.inc: FZ_PAIRS; set by finalize_variant)
 constexpr uint32_t FZ_VF_LANE_PAIRS = 1u << 30;
+// internal: ... as SINGLE streams 64 apart (two or four streams per lane of frames with four floats per stream: every 16-byte access of a
+// lane is one stream's frame, contiguous across the lanes of the wave)
+constexpr uint32_t FZ_VF_LANE_SINGLES = 1u << 31;
 constexpr uint32_t kChipCUs = 256;       // MI355X (gfx950): 8 XCDs x 32 CUs -- what chip_cus() answers on a box without a GPU
 unsigned chip_cus();                     // compute units of the current device (fz_launch.cpp)
 

@@ -380,15 +380,19 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
          const uint64_t out_row_bytes = n_streams * (uint64_t)std::max<uint32_t>(g.n_out, 1) * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 8u : 4u);
          if (out_row_bytes % kStoreGridBytes) v.flags |= FZ_VF_ST_MERGE;
       }
-      // four streams per lane whose output slice is TWO 16-byte pieces (typed frames of 8 bytes per stream): the lane takes two pairs of
-      // streams 128 apart instead, so that every store instruction writes whole sectors (FZ_VF_LANE_PAIRS)
-      v.flags &= ~FZ_VF_LANE_PAIRS;
+      // LANE GROUPS: no access of a lane wider than 16 bytes, so that every memory instruction of a wave covers whole, contiguous sectors.  A
+      // lane of P streams whose frames hold w floats per stream (the wider of in and out) takes its streams in groups of 4 / w, the groups
+      // 64 x group size apart: typed frames of 8 bytes per stream with four streams per lane -> two PAIRS (the complex one-pole in lockstep:
+      // 0.76 against 0.68 of peak with the lane's 32-byte output slice in two half-sector stores); 4-wire frames with two streams per lane ->
+      // two SINGLES (profiles/r05/lane_groups.txt)
+      v.flags &= ~(FZ_VF_LANE_PAIRS | FZ_VF_LANE_SINGLES);
       {
-         const uint32_t out_floats = g.n_out * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 2u : 1u);
+         const uint32_t out_floats = g.n_out * ((uv && (uv->flags & FZ_VF_OUT_F64)) ? 2u : 1u), w = std::max<uint32_t>(g.n_in, out_floats);
+         const uint32_t group = w == 2 ? 2u : w == 4 ? 1u : 0u;
          static const bool off = std::getenv("FLOWZ_HIP_NO_LANE_PAIRS") != nullptr;       // (developer switch: the adjacent-streams kernel for comparison)
-         if (!off && v.P == 4 && out_floats == 2 && !stream_major && !ws_parts(v.flags) && !(v.flags & (FZ_VF_RAGGED | FZ_VF_STAGE_PACK)) && g.far_lines.empty() &&
-             n_streams % 256 == 0 && (!tile_streams || tile_streams % 256 == 0))
-            v.flags |= FZ_VF_LANE_PAIRS;
+         if (!off && group && v.P >= 2 * group && !stream_major && !ws_parts(v.flags) && !(v.flags & (FZ_VF_RAGGED | FZ_VF_STAGE_PACK)) && g.far_lines.empty() &&
+             n_streams % (64u * v.P) == 0 && (!tile_streams || tile_streams % (64u * v.P) == 0))
+            v.flags |= group == 2 ? FZ_VF_LANE_PAIRS : FZ_VF_LANE_SINGLES;
       }
       static const bool kernel_laps = [] { const char* e = std::getenv("FLOWZ_HIP_LAPS"); return e && std::strcmp(e, "kernel") == 0; }();
       v.flags &= ~FZ_VF_PERSIST;
