@@ -35,7 +35,7 @@ def trace(*what):
 first, count = int(sys.argv[1]), int(sys.argv[2])
 limit = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
 t_start, last = time.time(), first - 1
-ns, T = 200, 61
+ns, T = int(os.environ.get("FUZZ_NS", "200")), 61      # (FUZZ_NS=512: whole waves, so that the lane groups take part)
 ok = bad = skipped = refused = 0
 for seed in range(first, first + count):
     if time.time() - t_start > limit:
