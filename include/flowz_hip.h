@@ -340,6 +340,7 @@ long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap
  * it runs -- what fz_program_tune does, without the call (FLOWZ_HIP_AUTOTUNE=0 turns it off: the static choice).  What a caller
  * should know about that one launch:
  *   - it synchronises `hip_stream` and takes the time of a few dozen blocks (>= 100 ms of warm-up, every candidate timed twice);
+ *     a candidate replaces the library's static choice only when it wins by more than 3 % (fz_program_tune: 1.5 %);
  *   - it allocates a copy of `state` (n_state * n_streams floats), runs the candidates on the caller's in / out / state buffers and
  *     puts the state back; a state that cannot be put back is FZ_E_HIP (the message says so), never a silent advance; without room
  *     for the copy nothing is measured;
