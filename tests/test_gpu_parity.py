@@ -1204,6 +1204,40 @@ def test_far_delays_hbm_rings_chained_blocks(torch_cuda, F, P):
     assert np.abs(want[-500:]).max() > 1e-3                            # the combs are alive at the end
 
 
+def test_far_delays_walk_the_rows_in_lockstep(torch_cuda, F, monkeypatch):
+    """Round 5: graphs with delay lines in HBM rings take the lockstep / XCD-synchronised row walk on plain time-major rows too (chunks of
+    at least two rows, reads prefetched a chunk ahead; no third buffer).  One wave per SIMD of work x 1100 rows: the library's choice by
+    name, sampled streams against the oracle, the whole output and the final state (ring rows + phase) equal to the free-running kernel's;
+    a second block shorter than the lockstep minimum continues the rings."""
+    torch = torch_cuda
+    monkeypatch.setenv("FLOWZ_HIP_AUTOTUNE", "0")
+    ns = torch.cuda.get_device_properties(0).multi_processor_count * 1024
+    L, GS = F.C.FZ_VF_LOCKSTEP, F.C.FZ_VF_GRID_SYNC
+    for g in (W.far_comb(300) if hasattr(W, "far_comb") else None,
+              G.fb(G.add(G.add(G.mul(G.lit(0.4), G.DEL(1, 300)), G.mul(G.lit(-0.3), G.DEL(1, 32))), G.add(G.mul(G.lit(0.1), G.DEL(1, 2)), G.IN(2))))):
+        if g is None:
+            from zignal_amd import workloads as ZW
+            g = ZW.far_comb(300)
+        prog = F.compile(F.from_sexpr(g))
+        T = 1100
+        name = prog.kernel_name(None, ns, T)
+        assert name.endswith("f%d" % (L | GS)) and "b256" not in name, name
+        x = torch.empty((T + 300, ns, 1), dtype=torch.float32, device="cuda")
+        F.synth_fill(x, SEED + 9)
+        st = torch.zeros((prog.n_state, ns), dtype=torch.float32, device="cuda")
+        y1, st = prog.run_block(x[:T], state=st)
+        y2, st = prog.run_block(x[T:], state=st)                            # 300 rows: below the lockstep minimum, the free-running kernel goes on
+        st_ref = torch.zeros((prog.n_state, ns), dtype=torch.float32, device="cuda")
+        r1, st_ref = prog.run_block(x[:T], state=st_ref, variant=F.make_variant(1, 8, 256))
+        r2, st_ref = prog.run_block(x[T:], state=st_ref, variant=F.make_variant(2, 16, 256))
+        assert torch.equal(y1.view(torch.int32), r1.view(torch.int32)) and torch.equal(y2.view(torch.int32), r2.view(torch.int32))
+        assert torch.equal(st.view(torch.int32), st_ref.view(torch.int32))
+        ids = _sample_ids(ns, 96, 21)
+        want = O.compile(g, len(ids)).run(O.synth_input(SEED + 9, ids, T + 300))
+        idt = torch.from_numpy(ids).cuda()
+        assert ndiff(torch.cat([y1, y2])[:, idt].cpu().numpy(), want) == 0
+
+
 def test_far_delay_minimum_and_tiled_layout(torch_cuda, F):
     """smallest far-read distance (32 samples = two prefetch chunks) on a 300-deep line, tiled frames"""
     torch = torch_cuda

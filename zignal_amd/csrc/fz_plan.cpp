@@ -148,14 +148,19 @@ static Variant resolve_wave_split(const Graph& g, const Request& rq, Variant v)
 static bool lockstep_default(const Graph& g, Variant& v, uint64_t n_streams, uint32_t n_samples, uint32_t allow_lockstep)
 {
    const bool wide = (g.n_in > 2 || g.n_out > 2) && g.n_in <= 8 && g.n_out <= 8 && !g.typed;
+   // (delay lines in HBM rings walk along: their reads are prefetched a chunk ahead like frame rows -- chunks of at least two rows, no third
+   //  buffer, whole lanes only.  The 300-sample comb at 1 M streams: 10.85 ms against 11.2 ms free-running, and no longer a matter of where
+   //  the allocator put the buffers -- 0.65 ... 0.77 on the bench lines of one day)
+   const bool far = !g.far_lines.empty();
    if (!(n_samples >= kLockstepMinRows && n_streams >= (uint64_t)chip_cus() * 1024u && ((g.n_in <= 2 && g.n_out <= 2) || wide) &&
-         g.far_lines.empty() && g.n_lds_slots == 0 && !(g.typed && (n_streams % 4))))
+         g.n_lds_slots == 0 && !((g.typed || far) && (n_streams % 4)) && !(far && (wide || g.far_min_read < 4))))
       return false;
    const uint32_t cap = wide ? 1u : allow_lockstep >= 3 ? 4u : allow_lockstep;
-   const TmGeometry geo = time_major_geometry(n_streams, cap, g.n_ops > 30, !g.typed);
+   const TmGeometry geo = time_major_geometry(n_streams, cap, g.n_ops > 30, !g.typed && !far);
    v.P = geo.P;
    v.U = wide ? (geo.laps > 1 ? 2u : 1u) : geo.U;           // wide frames: one row per buffer in one lap, chunks of two rows from two laps on
    v.block = geo.lanes;
+   if (far) v.U = std::min(std::max(v.U, 2u), std::max(2u, g.far_min_read / 2));
    v.flags |= FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC | (v.U == 1 ? (uint32_t)FZ_VF_PREFETCH3 : 0u);
    if (v.P == 1 && g.split.ok && n_samples >= 16u * (g.split.atoms() - 1)) {   // one stream per lane and a series of isomorphic segments: stage-packed
       v.flags |= FZ_VF_STAGE_PACK;
@@ -316,7 +321,7 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
 uint64_t lockstep_streams(const Graph& g, const fz_variant* uv, const Variant& v, uint64_t n_streams)
 {
    if (uv_has_shape(uv) || !(v.flags & FZ_VF_LOCKSTEP)) return n_streams;
-   return time_major_geometry(n_streams, v.P, g.n_ops > 30, !g.typed).main_streams;
+   return time_major_geometry(n_streams, v.P, g.n_ops > 30, !g.typed && g.far_lines.empty()).main_streams;
 }
 
 // The kernel of the REMAINDER launch (the last `rem` streams of a plain time-major block whose laps cover whole workgroups only): one-wave
@@ -411,7 +416,7 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
          if (k->res.scratch_bytes == 0 && v.U >= w.U) break;
          // before giving up streams per lane: the same packing with ONE row per chunk buffer and three buffers needs fewer
          // registers than chunks of two or four rows (the oscillator chain, two streams per lane, 1024 lanes: 114 against 128 + spills)
-         if (w.U > 1 && !(w.flags & FZ_VF_STAGE_PACK)) {
+         if (w.U > 1 && !(w.flags & FZ_VF_STAGE_PACK) && g.far_lines.empty()) {   // (HBM rings: no third buffer)
             Variant one = w;
             one.U = 1;
             one.flags |= FZ_VF_PREFETCH3;
