@@ -1889,7 +1889,7 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     assert F.compile(F.from_sexpr(G.osc_chain(8))).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u4b1024s8f%d" % (LG | _capi.FZ_VF_STAGE_PACK)
     # wide frames (round 4): one stream per lane in 1024-lane workgroups; the default on 4-wire frames equals the four-wave workgroups, laps and remainder included
     p4 = F.compile(F.from_sexpr(G.par4_sum()))
-    assert p4.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u2b1024f%d" % LG and p4.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p1u1b1024f%d" % (LG | _capi.FZ_VF_PREFETCH3)
+    assert p4.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u3b1024f%d" % LG and p4.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p1u1b1024f%d" % (LG | _capi.FZ_VF_PREFETCH3)
     ns, T = (1 << 18) + 1024 + 5, 1030
     x4 = torch.empty((T, ns, 4), dtype=torch.float32, device="cuda")
     F.synth_fill(x4, SEED + 35)

@@ -636,10 +636,10 @@ def test_time_major_geometry_follows_the_cu_count():
     # nothing of this on tiles and LDS rings
     assert p.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % F.C.FZ_VF_MAX_WG(2)
     assert F.compile(F.from_sexpr(G.lds_ring_comb())).kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u32b256f0"   # (rings vectorised in time: one stream per lane, a wave on every SIMD)
-    # wide frames (the 4-wire sum): one stream per lane in 1024-lane workgroups; one lap: one row per buffer, more: chunks of two rows
+    # wide frames (the 4-wire sum): one stream per lane in 1024-lane workgroups; one lap: one row per buffer, more: chunks of three rows
     p4 = F.compile(F.from_sexpr(G.par4_sum()))
     assert p4.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p1u1b1024f%d" % (L | GS | P3)
-    assert p4.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u2b1024f%d" % (L | GS)
+    assert p4.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u3b1024f%d" % (L | GS)
     assert p4.kernel_name(None, 1 << 16, 4096, 0) == "fz_block_kernel_p1u16b256f0" and p4.kernel_name(None, 1 << 20, 4096, 4096) == "fz_block_kernel_p1u32b256f0"
     # a register-heavy graph steps down: with many per-stream coefficients (the oscillator chain: 31) straight to one stream per lane,
     # stage-packed (packing by stages costs no registers per stream)

@@ -158,7 +158,9 @@ static bool lockstep_default(const Graph& g, Variant& v, uint64_t n_streams, uin
    const uint32_t cap = wide ? 1u : allow_lockstep >= 3 ? 4u : allow_lockstep;
    const TmGeometry geo = time_major_geometry(n_streams, cap, g.n_ops > 30, !g.typed && !far);
    v.P = geo.P;
-   v.U = wide ? (geo.laps > 1 ? 2u : 1u) : geo.U;           // wide frames: one row per buffer in one lap, chunks of two rows from two laps on
+   // wide frames: one row per buffer in one lap; in several laps chunks of THREE rows (the 4-wire sum at 1 M streams, rows 16 MiB apart:
+   // 14.09-14.17 ms against 14.52-14.55 with two, 14.8 with four, 14.4-14.6 with five to seven; profiles/r05/lane_groups.txt)
+   v.U = wide ? (geo.laps > 1 ? 3u : 1u) : geo.U;
    v.block = geo.lanes;
    if (far) v.U = std::min(std::max(v.U, 2u), std::max(2u, g.far_min_read / 2));
    v.flags |= FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC | (v.U == 1 ? (uint32_t)FZ_VF_PREFETCH3 : 0u);
