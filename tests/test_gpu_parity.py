@@ -518,6 +518,25 @@ def test_lane_groups_vs_oracle(torch_cuda, F, ns):
         assert prog.kernel_name(vv, ns, T).endswith("L")
         got, _ = run_gpu(torch, F, prog, x2, variant=vv)
         assert ndiff(got, want) == 0, (ns, v)
+    # graphs WITHOUT input wires (generators): a typed complex rotor (pairs) and a 4-output float generator (singles) -- the lane's frame slice
+    # on the input side is empty (round 5: the first cut of the lane groups did not compile for these)
+    gens = [(G.fb(G.add(G.mul(G.litc(0.6, 0.7), G.DEL(1, 1)), G.litc(0.001, 0.0))), True, (4, 8, 256, 0), "L"),
+            (G.chan(G.fb(G.add(G.mul(G.lit(0.5), G.DEL(1, 1)), G.lit(0.1))), G.lit(1.0), G.lit(2.0), G.lit(3.0)), False, (2, 8, 128, 0), "S")]
+    for g, is_typed, v, letter in gens:
+        if ns % (64 * v[0]):
+            continue
+        prog = F.compile(F.from_sexpr(g), typed=is_typed)
+        assert prog.n_in == 0
+        x0 = torch.zeros((T, ns, 0), dtype=torch.float32, device="cuda")
+        ref, st_ref = prog.run_block(x0, variant=F.make_variant(1, 8))
+        vv = F.make_variant(*v)
+        assert prog.kernel_name(vv, ns, T).endswith(letter)
+        got, st = prog.run_block(x0, variant=vv)
+        assert torch.equal(got.view(torch.int32), ref.view(torch.int32)) and torch.equal(st.view(torch.int32), st_ref.view(torch.int32)), (ns, v)
+        assert float(got.abs().max()) > 0
+        if not is_typed:
+            want = O.compile(g, ns).run(np.zeros((T, ns, 0), np.float32))
+            assert ndiff(got.cpu().numpy(), want) == 0
     # the developer switch of the comparison kernels leaves the names bare
     assert not F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(F.make_variant(4, 8, 256), ns, T).endswith(("L", "S"))
 
