@@ -293,7 +293,8 @@ int fz_program_kernel_resources(fz_program* p, const fz_variant* v, uint64_t n_s
                                 int as_launched, fz_kernel_resources* out);
 /* name of the variant's kernel, e.g. "fz_block_kernel_p2u16b256f2097152" (streams per lane, rows per chunk, lanes per workgroup,
  * flags): exactly the kernel a launch of the shape (n_streams, n_samples, tile_streams) runs -- one resolution shared with the
- * launch path; returns length */
+ * launch path; returns length.  (A plain time-major block whose laps leave a few streams over runs a SECOND kernel next to them, on those
+ * streams: name, symbol, code id and resources describe the laps' kernel; fz_program_build_for builds both.) */
 long fz_program_kernel_name(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams,
                             char* buf, size_t cap);
 /* ... and the SYMBOL of that kernel as profilers show it (rocprofv3 --kernel-trace --stats): the name + "_g<8 hex digits>", a tag of
