@@ -476,9 +476,9 @@ def test_lane_groups_vs_oracle(torch_cuda, F, ns):
             assert prog.kernel_name(vv, ns, T).endswith("L"), prog.kernel_name(vv, ns, T)
             got, st = _typed_gpu(torch, F, prog, x1, vv)
             assert ndiff(got, want) == 0 and torch.equal(st.view(torch.int32), st_ref.view(torch.int32)), (ns, v)
-            if ns % 512 == 0 and v[2] in (0, 256):                                                  # stream tiles of 512: two whole waves of pairs per tile
-                assert prog.kernel_name(vv, ns, T, 512).endswith("L")
-                got_t, st_t = _typed_gpu(torch, F, prog, x1, vv, tile=512)
+            if ns % 1024 == 0 and v[2] in (0, 256):                                                 # stream tiles of 1024: one 256-lane workgroup of pairs per tile
+                assert prog.kernel_name(vv, ns, T, 1024).endswith("L")
+                got_t, st_t = _typed_gpu(torch, F, prog, x1, vv, tile=1024)
                 assert ndiff(got_t, want) == 0 and torch.equal(st_t.view(torch.int32), st_ref.view(torch.int32)), (ns, v, "tiled")
             a, st1 = _typed_gpu(torch, F, prog, x1[:40], vv)
             b, st2 = _typed_gpu(torch, F, prog, x1[40:], F.make_variant(2, 8), state=st1)           # ... continued by an adjacent-streams kernel
