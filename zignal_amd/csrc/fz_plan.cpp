@@ -149,8 +149,8 @@ static bool lockstep_default(const Graph& g, Variant& v, uint64_t n_streams, uin
 {
    const bool wide = (g.n_in > 2 || g.n_out > 2) && g.n_in <= 8 && g.n_out <= 8 && !g.typed;
    // (delay lines in HBM rings walk along: their reads are prefetched a chunk ahead like frame rows -- chunks of at least two rows, no third
-   //  buffer, whole lanes only.  The 300-sample comb at 1 M streams: 10.85 ms against 11.2 ms free-running, and no longer a matter of where
-   //  the allocator put the buffers -- 0.65 ... 0.77 on the bench lines of one day)
+   //  buffer, whole lanes only.  The 300-sample comb at 1 M streams: 10.85 ms against 11.2 ms free-running side by side; over the bench lines of
+   //  a day 0.73 ... 0.80 of peak against 0.65 ... 0.77 free-running)
    const bool far = !g.far_lines.empty();
    if (!(n_samples >= kLockstepMinRows && n_streams >= (uint64_t)chip_cus() * 1024u && ((g.n_in <= 2 && g.n_out <= 2) || wide) &&
          g.n_lds_slots == 0 && !((g.typed || far) && (n_streams % 4)) && !(far && (wide || g.far_min_read < 4))))
