@@ -541,6 +541,19 @@ def test_lane_groups_vs_oracle(torch_cuda, F, ns):
         if not is_typed:
             want = O.compile(g, ns).run(np.zeros((T, ns, 0), np.float32))
             assert ndiff(got.cpu().numpy(), want) == 0
+    # float64 output frames of a float graph with a double literal (FZ_VF_OUT_F64): 8 bytes per stream out -> pairs with four streams per lane
+    if ns % 256 == 0:
+        g = G.mixed_precision_biquad()
+        prog = F.compile(F.from_sexpr(g))
+        xd = torch.from_numpy(x1).cuda()
+        ref64, st_ref = prog.run_block(xd, variant=F.make_variant(1, 8), out_f64=True)
+        want64 = O.compile(g, ns, out_f64=True).run(x1)
+        assert np.array_equal(ref64.cpu().numpy().view(np.uint64), np.ascontiguousarray(want64, np.float64).view(np.uint64))
+        for v in ((4, 8, 256, 0), (4, 2, 64, L)):
+            vv = F.make_variant(v[0], v[1], v[2], v[3] | F.C.FZ_VF_OUT_F64)
+            assert prog.kernel_name(vv, ns, T).endswith("L"), prog.kernel_name(vv, ns, T)
+            got64, st = prog.run_block(xd, variant=F.make_variant(*v), out_f64=True)
+            assert torch.equal(got64.view(torch.int64), ref64.view(torch.int64)) and torch.equal(st, st_ref), (ns, v)
     # the developer switch of the comparison kernels leaves the names bare
     assert not F.compile(F.from_sexpr(G.df1_cascade(2))).kernel_name(F.make_variant(4, 8, 256), ns, T).endswith(("L", "S"))
 
