@@ -123,6 +123,12 @@ typedef struct fz_info {
    uint32_t n_in_wires;  /* input wires (input_arity); < n_in when a typed program has double / complex inputs */
    uint32_t typed;       /* 1 for fz_compile_typed programs                                           */
    uint32_t n_mod;       /* sample-rate modulators (highest fz_modulator index + 1)                            */
+   uint32_t differs_from_reference; /* != 0: the graph holds a feedback ~(a |= b) whose first part keeps that many EXTERNAL inputs for itself
+                            while the part behind it reads external inputs too (the graphs of test/tests.cpp:67-77).  The reference's
+                            shipped binary_feedback hands that second part the wrong wires (flowz.hpp:1045-1050: tuple_drop<std::min(0, ..)>,
+                            "TODO" there); this library routes per the reference's arity table (:162-246) -- e.g.
+                            ~(_1 + _2[_1] |= _1[_1] + _2) on (10,1),(20,2),(30,3) gives 1, 3, 16 here and 10, 30, 70 from the shipped header.
+                            fz_compile succeeds and leaves a note in fz_last_error()                                          */
 } fz_info;
 
 int  fz_compile(const fz_expr* e, fz_program** out);
@@ -336,10 +342,10 @@ long fz_program_source(fz_program* p, const fz_variant* v, char* buf, size_t cap
  * Asynchronous on `hip_stream` (hipStream_t, NULL = default stream); the caller synchronises.
  * `v` may be NULL (all defaults).  A program may run concurrently on different state buffers.
  *
- * FIRST BIG LAUNCH OF A SHAPE (v == NULL, the block is the whole buffer, n_streams * n_samples >= 2^26): which kernel variant
- * streams fastest differs from board to board, so such a launch MEASURES the plan once per (n_streams, tile_streams, device) before
- * it runs -- what fz_program_tune does, without the call (FLOWZ_HIP_AUTOTUNE=0 turns it off: the static choice).  What a caller
- * should know about that one launch:
+ * WHICH KERNEL RUNS (v == NULL): the plan fz_program_tune measured for this (n_streams, tile_streams, device) -- in this process or,
+ * persisted, in an earlier one --, else the library's static choice.  A launch never measures anything by itself.
+ * Opt-in, FLOWZ_HIP_AUTOTUNE=1 in the environment (rounds 3-5 did this by default): the first big launch of a shape (the block is the
+ * whole buffer, n_streams * n_samples >= 2^26) makes fz_program_tune's measurement on the caller's buffers before it runs:
  *   - it synchronises `hip_stream` and takes the time of a few dozen blocks (>= 100 ms of warm-up, every candidate timed twice);
  *     a candidate replaces the library's static choice only when it wins by more than 3 % (fz_program_tune: 1.5 %);
  *   - it allocates a copy of `state` (n_state * n_streams floats), runs the candidates on the caller's in / out / state buffers and

@@ -77,6 +77,24 @@ def test_tests_cpp_known_answers_per_sample_calls(F, case):
         _capi.lib.fz_bank_destroy(bank)
 
 
+def test_graph_the_shipped_reference_misroutes_runs_per_the_arity_table(torch_cuda, F):
+    """SURVEY App. C.1, the graph of test/tests.cpp:67-71: ~(_1 + _2[_1] |= _1[_1] + _2).  The reference asserts its arities and delays only;
+    its shipped binary_feedback (flowz.hpp:1045-1050) would return 10, 30, 70 on (10,1),(20,2),(30,3).  The library routes per the arity
+    table -- 1, 3, 16 -- says so in fz_info, and the kernels agree with the oracle on noise."""
+    g = tup([c for c in KA["arity"] if c["name"] == "fb_two_inputs"][0]["graph"])
+    prog = F.compile(F.from_sexpr(g))
+    assert prog.differs_from_reference == 1 and prog.note.startswith("note:")
+    x = np.array([[[10, 1]], [[20, 2]], [[30, 3]]], np.float32)
+    y, _ = run_gpu(torch_cuda, F, prog, x)
+    assert y.ravel().tolist() == [1.0, 3.0, 16.0]
+    ns, T = 300, 257
+    xn = O.synth_input(SEED + 21, np.arange(ns), T, n_wires=2)
+    want = O.compile(g, ns).run(xn)
+    for P in (1, 2, 4):
+        got, _ = run_gpu(torch_cuda, F, prog, xn, variant=F.make_variant(P, 8))
+        assert ndiff(got, want) == 0
+
+
 # ---- golden vectors produced by the reference's own hand-written filters ------------------------
 FORMS = {"df1": G.df1, "df2": G.df2, "df1t": G.df1t, "df1x2": lambda: G.seq(G.df1(), G.df1()),
          "df1x6": lambda: G.seq(*[G.df1() for _ in range(6)])}       # six reference DF1 closures in series: the headline workload's shape
@@ -2060,7 +2078,7 @@ def test_grid_sync_survives_a_busy_gpu_and_overlapping_streams(torch_cuda, F, mo
 
 
 def test_autotune_env_measures_the_plan_on_first_use(torch_cuda):
-    """FLOWZ_HIP_AUTOTUNE=1: the first big block of a shape selects its plan by itself; state and results are
+    """FLOWZ_HIP_AUTOTUNE=1 (opt-in since round 6): the first big block of a shape selects its plan by itself; state and results are
     what a plain launch gives (own process: the knob is read once per process).  The measurement is a one-off of bounded length:
     under two seconds for the first launch of the shape (kernels at hand only: nothing is JIT-compiled), an ordinary launch after it."""
     import subprocess
@@ -2091,6 +2109,11 @@ print("autotune ok")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and "autotune ok" in out.stdout, out.stdout + out.stderr[-2000:]
     assert out.stderr.count("[flowz_hip] tune ") >= 5                   # the candidates were measured
+    # round 6: WITHOUT the variable a launch never measures anything by itself -- the same script runs the static plan from the first block on
+    env.pop("FLOWZ_HIP_AUTOTUNE")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "autotune ok" in out.stdout, out.stdout + out.stderr[-2000:]
+    assert out.stderr.count("[flowz_hip] tune ") == 0 and "[flowz_hip] launched" in out.stderr
 
 
 def test_tuned_plan_is_persisted_per_graph_shape_and_board(torch_cuda, F, tmp_path, monkeypatch):

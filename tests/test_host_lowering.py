@@ -110,6 +110,48 @@ def test_feedback_expressions_of_the_canonical_shape_tests_lower_like_the_oracle
     assert same(got, O.compile(g, ns).run(x))
 
 
+def test_graphs_the_shipped_reference_misroutes_are_flagged_and_their_values_pinned():
+    """SURVEY App. C.1: binary_feedback hands its future part the external inputs from position std::min(0, ...) = 0 on
+    (flowz.hpp:1045-1050) -- wrong as soon as the promise part keeps external inputs for itself.  The reference only checks the ANALYSIS
+    of such graphs (test/tests.cpp:67-77); evaluated, its shipped header gives 10, 30, 70 on (10,1),(20,2),(30,3) (SURVEY App. D.5's
+    model).  This library routes per the arity table: y[n] = a[n-1] + v[n], a[n] = y[n] + u[n-1]  ->  1, 3, 16.  The choice is
+    pinned here, and the program says that it differs."""
+    ar = {c["name"]: c for c in KA["arity"]}
+    g2, g3 = tup(ar["fb_two_inputs"]["graph"]), tup(ar["fb_three_inputs"]["graph"])
+    p = F.compile(F.from_sexpr(g2))
+    assert p.differs_from_reference == 1 and "flowz.hpp:1045-1050" in p.note and p.note.startswith("note:")
+    x = np.array([[[10, 1]], [[20, 2]], [[30, 3]]], np.float32)
+    y, _ = run_ir(p, x)
+    assert y.ravel().tolist() == [1.0, 3.0, 16.0]
+    assert O.compile(g2, 1).run(x).ravel().tolist() == [1.0, 3.0, 16.0]
+    p3 = F.compile(F.from_sexpr(g3))
+    assert p3.differs_from_reference == 2 and p3.n_in == 3
+    assert F.compile(F.from_sexpr(g2), typed=True).differs_from_reference == 1
+    # nested: the flag is the graph's, wherever the feedback sits
+    assert F.compile(F.from_sexpr(G.seq(g2, G.df1()))).differs_from_reference == 1
+    # every graph the reference EVALUATES in its tests, the BASELINE workloads and the canonical-shape bodies: no divergence
+    clean = [tup(c["graph"]) for c in KA["evaluation"] + KA["readme"]] + [G.fb(b) for b in G.canonical_shape_bodies().values()]
+    clean += [G.df1_cascade(6), G.par4_sum(), G.par4_sum_fanout(), G.osc_chain(6), G.df2(), G.df1t(), G.df2t(), G.lds_ring_comb(), G.far_comb(300),
+              G.fb(G.seq(G.add(G.IN(1), G.IN(2)), G.DEL(1, 1)))]       # (a promise part with an input of its own and a future part with none: harmless)
+    for g in clean:
+        q = F.compile(F.from_sexpr(g))
+        assert q.differs_from_reference == 0 and q.note == "", g
+
+
+def test_remainder_kernel_of_a_far_line_with_a_shallow_tap_builds(tmp_path, monkeypatch):
+    """A plain time-major block whose laps leave a few streams over runs a remainder kernel next to them.  Its chunk must respect the
+    cap the HBM rings put on every kernel -- half the youngest ring read: with a tap 20 samples back, 10 rows -- or the shape is refused
+    although the same graph runs at 1 048 576 streams (round-5 advisor finding: the remainder asked for 16)."""
+    monkeypatch.setenv("FLOWZ_HIP_CACHE", str(tmp_path))
+    g = G.fb(G.add(G.add(G.mul(G.lit(0.5), G.DEL(1, 300)), G.mul(G.lit(0.25), G.DEL(1, 20))), G.IN(2)))
+    p = F.compile(F.from_sexpr(g))
+    assert p.max_delay == 300
+    for ns in (1048576, 1049600, 1052672):
+        p.build(None, ns, 4096)                              # main kernel + remainder kernel, both resolved as a launch would
+        name = p.kernel_name(None, ns, 4096)
+        assert name.startswith("fz_block_kernel_p"), name
+
+
 def test_lowering_osc_chain_with_stream_params():
     g = G.osc_chain(6)
     p = F.compile(F.from_sexpr(g))
@@ -853,6 +895,18 @@ def test_kernel_manifest_records_and_replays_without_a_gpu(tmp_path):
     assert sorted(f.name for f in c2.glob("*.hsaco")) == first
     for f in first:
         assert (c1 / f).read_bytes() == (c2 / f).read_bytes(), f
+    # a manifest is data from elsewhere (round-5 advisor finding): records with a variant no launch could have resolved (P = 0 would divide by
+    # zero, a block that is no multiple of 64) are counted as failed and skipped; a record whose length runs past the file is refused
+    text = man.read_bytes()
+    head, _, rest = text.partition(b"\n")
+    f = head.split()
+    bad = tmp_path / "bad.fzm"
+    bad.write_bytes(b" ".join([f[0], b"0"] + f[2:]) + b"\n" + rest[:int(f[5])] + b" ".join(f[:3] + [b"100"] + f[4:]) + b"\n" + rest[:int(f[5])] + text)
+    r = F.manifest_build(str(bad), 2)
+    assert r["failed"] == 2 and r["records"] == a["records"] + 2 and r["at_hand"] + r["built"] == a["records"], r
+    bad.write_bytes(b" ".join(f[:5] + [b"18446744073709551000"]) + b"\n" + rest)
+    with pytest.raises(F.FlowzError):
+        F.manifest_build(str(bad), 2)
 
 
 def test_typed_frames_take_lane_pairs(tmp_path, monkeypatch):

@@ -49,7 +49,7 @@ DTYPES = {"f32": 0, "f64": 1, "cf32": 2, "cf64": 3}
 class Info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in
                 ("n_in", "n_out", "n_nodes", "n_ops", "n_lines", "n_state", "n_const", "n_param", "max_delay", "n_lds_slots",
-                 "stage_packable", "n_const64", "n_out_wires", "n_in_wires", "typed", "n_mod")]
+                 "stage_packable", "n_const64", "n_out_wires", "n_in_wires", "typed", "n_mod", "differs_from_reference")]
 
 
 class IrNode(ctypes.Structure):

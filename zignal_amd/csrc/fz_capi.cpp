@@ -13,6 +13,16 @@ using namespace fz;
    catch (const fz::Error& er) { fz::set_error(er.msg); return er.code; }       \
    catch (const std::exception& ex) { fz::set_error(ex.what()); return FZ_E_INVALID; }
 
+// a program the SHIPPED reference would evaluate differently: the compile succeeds -- this library routes per the
+// reference's own arity table -- and says so: fz_info.differs_from_reference, and this note in fz_last_error()
+static void note_divergence(const Graph& g)
+{
+   if (g.ref_divergent)
+      set_error("note: a feedback in this graph keeps " + std::to_string(g.ref_divergent) + " external input(s) for its promise part next to a future part that "
+                "reads external inputs too: the reference's shipped binary_feedback hands the future part the wrong wires there (flowz.hpp:1045-1050, "
+                "std::min(0, ...)); this library routes per the arity table (flowz.hpp:162-246), so its results differ from the reference's closure");
+}
+
 extern "C" {
 
 int fz_compile(const fz_expr* e, fz_program** out)
@@ -30,6 +40,7 @@ int fz_compile(const fz_expr* e, fz_program** out)
          throw;
       }
       *out = p;
+      note_divergence(p->g);
       return FZ_OK;)
 }
 
@@ -68,6 +79,7 @@ int fz_compile_typed(const fz_expr* e, const uint32_t* in_dtypes, uint32_t n_in_
       p->recipe += "\n" + serialize_expr(e);
       p->graph_hash = graph_structure_hash(p->g);
       p->g.sym_tag = (uint32_t)p->graph_hash;
+      note_divergence(p->g);
       *out = p.release();
       return FZ_OK;)
 }
@@ -110,6 +122,7 @@ int fz_program_info(const fz_program* p, fz_info* info)
       info->n_in_wires = (uint32_t)g.in_dtype.size();
       info->typed = g.typed ? 1u : 0u;
       info->n_mod = g.n_mod;
+      info->differs_from_reference = g.ref_divergent;
       return FZ_OK;)
 }
 

@@ -79,6 +79,107 @@ std::vector<uint32_t> max_input_delays(const fz_expr* e)
    return {};
 }
 
+// per-wire YOUNGEST read, flowz.hpp:503 (min_input_delays: the same recursion with the combiner of :389-421): 0 = the wire is read
+// without a delay somewhere, n = only through _i[_n] and older, -1 = not read at all
+static std::vector<int> zipmin(const std::vector<int>& l, const std::vector<int>& r)
+{
+   std::vector<int> out(std::max(l.size(), r.size()), -1);
+   for (size_t k = 0; k < out.size(); ++k) {
+      const int x = k < l.size() ? l[k] : -1, y = k < r.size() ? r[k] : -1;
+      out[k] = x < 0 ? y : y < 0 ? x : std::min(x, y);
+   }
+   return out;
+}
+
+static std::vector<int> min_input_delays(const fz_expr* e)
+{
+   auto dropn = [](std::vector<int> v, size_t n) {
+      if (n >= v.size()) return std::vector<int>();
+      v.erase(v.begin(), v.begin() + (long)n);
+      return v;
+   };
+   auto catn = [](std::vector<int> a, const std::vector<int>& b) {
+      a.insert(a.end(), b.begin(), b.end());
+      return a;
+   };
+   switch (e->kind) {
+      case EK::Delayed:
+      case EK::Placeholder: {
+         std::vector<int> v(e->i, -1);
+         v[e->i - 1] = e->kind == EK::Delayed ? (int)e->n : 0;
+         return v;
+      }
+      case EK::Literal:
+      case EK::Uniform:
+      case EK::Modulator:
+      case EK::Param: return {};
+      case EK::Feedback: return dropn(min_input_delays(e->a), (size_t)e->a->out_arity);
+      case EK::Parallel: return catn(min_input_delays(e->a), min_input_delays(e->b));
+      case EK::Sequence: return catn(min_input_delays(e->a), dropn(min_input_delays(e->b), (size_t)e->a->out_arity));
+      case EK::Neg: return min_input_delays(e->a);
+      case EK::Arith:
+      case EK::Channel: return zipmin(min_input_delays(e->a), min_input_delays(e->b));
+   }
+   return {};
+}
+
+// Where the SHIPPED reference evaluates a feedback differently from its own arity table.  compile() rewrites `~x` into
+// binary_feedback(promise, future) (flowz.hpp:862-884: the chain  front |= s1 |= ... |= sn  is cut before the first box that needs none
+// of the wires in front of it undelayed: promise = front |= s1 .. sk, future = the rest) and binary_feedback hands the future part the
+// external inputs from position std::min(0, in(promise) - out(future)) = 0 on (:1045-1050, "TODO" there) instead of from behind the
+// promise's own.  Harmless unless the promise part consumes external inputs AND the future part reads some: then the reference's
+// closure reads the wrong wires, and this library -- which routes per the arity table, :162-246 -- computes other values.
+// Returns the number of external inputs the promise part takes in that case, else 0.
+uint32_t feedback_promise_inputs(const fz_expr* fb)
+{
+   if (fb->kind != EK::Feedback) return 0;
+   std::vector<const fz_expr*> chain;
+   std::vector<const fz_expr*> todo{fb->a};
+   while (!todo.empty()) {                                  // boxes of the body's `|=` chain, in evaluation order
+      const fz_expr* x = todo.back();
+      todo.pop_back();
+      if (x->kind == EK::Sequence) {
+         todo.push_back(x->b);
+         todo.push_back(x->a);
+      } else {
+         chain.push_back(x);
+      }
+   }
+   // arity and youngest reads of the remainders r_k = s(k+1) |= ... |= sn, built from the back (the arity table of :162-246)
+   const size_t n = chain.size();
+   std::vector<int> rin(n + 1, 0), rout(n + 1, 0);
+   std::vector<std::vector<int>> rmin(n + 1);
+   for (size_t k = n; k-- > 0;) {
+      const fz_expr* s = chain[k];
+      if (k + 1 == n) {
+         rin[k] = s->in_arity;
+         rout[k] = s->out_arity;
+         rmin[k] = min_input_delays(s);
+      } else {
+         rin[k] = s->in_arity + std::max(0, rin[k + 1] - s->out_arity);
+         rout[k] = rout[k + 1] + std::max(0, s->out_arity - rin[k + 1]);
+         std::vector<int> tail = rmin[k + 1];
+         if ((size_t)s->out_arity >= tail.size()) tail.clear();
+         else tail.erase(tail.begin(), tail.begin() + s->out_arity);
+         rmin[k] = min_input_delays(s);
+         rmin[k].insert(rmin[k].end(), tail.begin(), tail.end());
+      }
+   }
+   int lin = fb->a->out_arity, lout = fb->a->out_arity;     // the front panel: out(x) wires passed through
+   for (size_t k = 0; k < n; ++k) {
+      bool direct = false;
+      for (int w = 0; w < lout && w < (int)rmin[k].size(); ++w) direct = direct || rmin[k][(size_t)w] == 0;
+      if (!direct) {
+         const int own = lin - rout[k];
+         return own > 0 && rin[k] > lout ? (uint32_t)own : 0u;
+      }
+      const fz_expr* s = chain[k];
+      lin = lin + std::max(0, s->in_arity - lout);
+      lout = s->out_arity + std::max(0, lout - s->in_arity);
+   }
+   return 0;                                                // (no cut: a delay-free loop, rejected by the lowering)
+}
+
 // ---- recipes: an expression as text (kernel manifests, fz_kernel_cache.cpp) --------------------------------------------------
 // One line per node of the DAG in dependency order, shared sub-expressions once: "<kind letter> <fields>"; operands are line numbers.
 // Floating-point values travel as bit patterns.

@@ -115,6 +115,7 @@ struct Graph {
    uint32_t n_in = 0, n_out = 0, n_param = 0;   // n_in / n_out: frame SLOTS (floats per frame)
    uint32_t n_mod = 0;               // sample-rate modulators (fz_modulator)
    bool typed = false;               // fz_compile_typed: wire types carried through inputs, state and outputs
+   uint32_t ref_divergent = 0;       // != 0: a feedback the SHIPPED reference evaluates against its own arity table (fz_info.differs_from_reference)
    uint32_t sym_tag = 0;             // low 32 bits of graph_structure_hash: the "_g<tag>" of the kernel symbols (kernel_symbol)
    std::vector<uint8_t> in_dtype;    // per input wire: fz_dtype
    std::vector<Node> nodes;          // topological order
@@ -182,6 +183,7 @@ struct LowerOptions {
 };
 Graph lower(const fz_expr* e, const LowerOptions& opt = LowerOptions());   // throws Error
 std::vector<uint32_t> max_input_delays(const fz_expr* e);
+uint32_t feedback_promise_inputs(const fz_expr* fb);   // fz_expr.cpp; SURVEY App. C.1
 
 // ---- code generation -------------------------------------------------------------------------------
 struct Variant {
@@ -231,6 +233,7 @@ struct Kernel {
    };
    std::vector<char> code;        // code object (device independent: gfx950)
    std::string cache_path;        // on-disk cache file it came from / went to ("" = none)
+   std::string code_id;           // 16 hex digits: hash of (source, options, the compiler that BUILT this object) = its file name in the cache
    std::vector<Loaded> loaded;    // one module per device the kernel ran on
    void* function_on_current_device(const std::string& symbol);   // loads on first use (caller holds `mu`)
    ~Kernel();                     // unloads the modules (fz_kernel_cache.cpp)
@@ -314,6 +317,6 @@ struct NoJitScope {
 };
 // is the kernel's code object at hand (in memory or in the on-disk cache), i.e. can it run without a hiprtc build?
 bool kernel_at_hand(fz_program* p, const Variant& v);
-std::string kernel_code_id(const fz_program* p, const Variant& v);
+std::string kernel_code_id(fz_program* p, const Variant& v);
 int manifest_build(const std::string& path, unsigned n_workers, uint32_t counts[4]);
 }  // namespace fz

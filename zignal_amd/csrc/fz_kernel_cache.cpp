@@ -501,7 +501,18 @@ static std::string cache_file_of(const fz_program* p, const Variant& v, const st
 
 // identity of a variant's CODE (16 hex digits): the name of its code object in the kernel cache under the installation's compiler.  Two
 // kernels share it only when generated source, build options and compiler agree -- what counter tables are keyed by (profiles/)
-std::string kernel_code_id(const fz_program* p, const Variant& v) { return cache_file_of(p, v, preferred_identity()).substr(1, 16); }
+// A kernel this process already holds answers with the id of the object it actually LOADED: a process bound to another hiprtc (a PyTorch
+// wheel's) that had to build the kernel itself runs other instructions than the pre-built object of the same variant, and counters
+// measured on one must not be attached to the other.
+std::string kernel_code_id(fz_program* p, const Variant& v)
+{
+   {
+      std::lock_guard<std::mutex> lock(p->mu);
+      auto it = p->kernels.find(v);
+      if (it != p->kernels.end() && it->second && it->second->built.load() && !it->second->code_id.empty()) return it->second->code_id;
+   }
+   return cache_file_of(p, v, preferred_identity()).substr(1, 16);
+}
 
 static bool cache_in_use(const std::string& dir) { return !std::getenv("FLOWZ_HIP_NO_CACHE") && !dir.empty(); }
 
@@ -571,20 +582,28 @@ int manifest_build(const std::string& path, unsigned n_workers, uint32_t counts[
    // records -> unique (recipe, variant) pairs
    std::map<std::string, std::set<Variant>> want;
    size_t pos = 0;
+   uint32_t bad_records = 0;
    while (pos < text.size()) {
       const size_t eol = text.find('\n', pos);
       if (eol == std::string::npos) break;
       Variant v;
       size_t n = 0;
-      if (std::sscanf(text.c_str() + pos, "FZM1 %u %u %u %u %zu", &v.P, &v.U, &v.block, &v.flags, &n) != 5 || eol + 1 + n > text.size())
+      if (std::sscanf(text.c_str() + pos, "FZM1 %u %u %u %u %zu", &v.P, &v.U, &v.block, &v.flags, &n) != 5 || n > text.size() - (eol + 1))
          fail(FZ_E_INVALID, "kernel manifest: damaged record at byte " + std::to_string(pos));
-      want[text.substr(eol + 1, n)].insert(v);
       pos = eol + 1 + n;
+      // (the file is data from elsewhere: a variant no launch could have resolved -- it would divide by P or size a workgroup by `block`
+      //  further down -- is counted as failed, not built)
+      if ((v.P != 1 && v.P != 2 && v.P != 4) || v.U == 0 || v.U > 128 || v.block == 0 || v.block % 64 != 0 || v.block > 1024) {
+         ++bad_records;
+         continue;
+      }
+      want[text.substr(eol + 1, n)].insert(v);
    }
    struct Item { fz_program* p; Variant v; };
    std::vector<std::unique_ptr<fz_program>> programs;
    std::vector<Item> items;
-   counts[0] = counts[1] = counts[2] = counts[3] = 0;      // records, at hand, built, failed
+   counts[0] = counts[3] = bad_records;                    // records, at hand, built, failed
+   counts[1] = counts[2] = 0;
    for (const auto& kv : want) {
       const std::string& recipe = kv.first;
       const size_t eol = recipe.find('\n');
@@ -621,6 +640,8 @@ int manifest_build(const std::string& path, unsigned n_workers, uint32_t counts[
             ++built;
          } catch (const Error&) {
             ++failed;                                       // (a variant the graph no longer allows, a kernel that no longer compiles)
+         } catch (const std::exception&) {
+            ++failed;                                       // (anything else a damaged record provokes: never std::terminate from a worker thread)
          }
       }
       tl_force_worker = false;
@@ -662,12 +683,16 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
             } else if (ro_pkg && cache_load(pkg + name, k->code, false)) {
                found = true;                             // (no cache_path: not ours to delete)
             }
-            if (found) break;
+            if (found) {
+               k->code_id = name.substr(1, 16);
+               break;
+            }
          }
       if (!found) {
          // (the plan measurement a first big launch makes by itself never waits for a build: NoJitScope)
          if (tl_no_jit) fail(FZ_E_UNSUPPORTED, "kernel not at hand (it would have to be built)");
          k->code = jit_compile(p->g, v);
+         k->code_id = cache_file_of(p, v, rtc().identity).substr(1, 16);
          if (use_cache) {
             cache_store(dir, path, k->code);
             k->cache_path = path;
@@ -693,6 +718,7 @@ std::shared_ptr<Kernel> get_kernel(fz_program* p, const Variant& v, void** fn_ou
          k->code = jit_compile(p->g, v);
          k->res = read_resources(k->code);
          k->cache_path = cache_dir() + cache_file_of(p, v, rtc().identity);   // (under the name of the compiler that built it)
+         k->code_id = cache_file_of(p, v, rtc().identity).substr(1, 16);
          cache_store(cache_dir(), k->cache_path, k->code);
          *fn_out = k->function_on_current_device(kernel_symbol(p->g, v));
       }

@@ -179,14 +179,13 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       const auto key = std::make_tuple(n_streams, tile_streams, dev);
       bool known = false;
       (void)planned_variant(p, n_streams, tile_streams);      // first launch of this shape: a plan persisted by an earlier process?
-      // The first BIG block of a shape measures the plan by itself (round 3: on by default; FLOWZ_HIP_AUTOTUNE=0 turns it off):
-      // which variant streams fastest differs from board to board by more than the variants differ on one board (the same
-      // kernel: +5 % here, -13 % there), so the library's static choice is only the first candidate.  The measurement runs on the
-      // caller's buffers (the state is saved and restored around it, `out` is recomputed below), takes the candidates whose
-      // code objects are at hand (build() pre-builds them for the BASELINE graphs; nothing is JIT-compiled for it) and
-      // costs about ten launches each; blocks below 2^26 stream-samples (a few hundred microseconds) never trigger it.
-      const char* const at_env = std::getenv("FLOWZ_HIP_AUTOTUNE");      // (read at every launch: a process may turn it off for some of its work)
-      const bool autotune = !(at_env && *at_env == '0');
+      // A launch without a variant runs the plan fz_program_tune measured for the shape (this process or an earlier one: plans.txt), else
+      // the library's static choice.  Round 6: the measurement is never made behind the caller's back any more -- FLOWZ_HIP_AUTOTUNE=1
+      // opts in to what round 3-5 did by default: the first BIG block of a shape (>= 2^26 stream-samples) measures the candidates whose
+      // code objects are at hand on the caller's buffers (the state is saved and restored around it, `out` is recomputed below; about
+      // ten launches each, nothing is JIT-compiled for it).
+      const char* const at_env = std::getenv("FLOWZ_HIP_AUTOTUNE");      // (read at every launch: a process may turn it on for some of its work)
+      const bool autotune = at_env && *at_env == '1';
       bool may_tune = autotune && rows_total == n_samples && row0 == 0 && n_streams * (uint64_t)n_samples >= (1ull << 26);
       if (may_tune) {
          // not while the stream is being captured into a hipGraph (the measurement allocates and synchronises), and not
@@ -269,7 +268,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
                (void)hipFree(copy);
                if (e1 != hipSuccess || e2 != hipSuccess)
                   fail(FZ_E_HIP, std::string("the closure state could not be restored after the plan measurement of this shape (") +
-                                    hipGetErrorString(e1 != hipSuccess ? e1 : e2) + "): `state` is advanced by the measurement's blocks -- reset it; FLOWZ_HIP_AUTOTUNE=0 turns the measurement off");
+                                    hipGetErrorString(e1 != hipSuccess ? e1 : e2) + "): `state` is advanced by the measurement's blocks -- reset it (the measurement was asked for with FLOWZ_HIP_AUTOTUNE=1)");
             }
             if (rc == FZ_OK && (chosen.streams_per_lane || chosen.unroll || chosen.block_threads || chosen.flags)) {
                planned = chosen;

@@ -52,6 +52,7 @@ struct Elab {
    std::map<int, int> imag_of;
    std::string mix_error;   // a complex / scalar type mismatch seen while feedback wire types were still assumptions
    int fixpoint_depth = 0;
+   uint32_t promise_inputs = 0;   // a feedback whose promise part takes external inputs next to a future part that reads some
 
    int add(uint32_t kind, int a = -1, int b = -1, float value = 0.f, uint32_t n = 0)
    {
@@ -153,6 +154,7 @@ struct Elab {
          }
          case EK::Feedback: {                                           // :1031-1074, arity-table routing
             size_t k = (size_t)e->a->out_arity;
+            promise_inputs = std::max(promise_inputs, feedback_promise_inputs(e));
             if (!typed) {
                std::vector<int> in2;
                for (size_t j = 0; j < k; ++j) in2.push_back(add(K_FWD));
@@ -582,6 +584,7 @@ Graph lower(const fz_expr* e, const LowerOptions& opt)
    }
    g.n_in = n_in;
    g.typed = opt.typed;
+   g.ref_divergent = el.promise_inputs;
    g.in_dtype = in_dtype;
    g.n_out_wires = (uint32_t)out_wires.size();
    for (size_t k = 0; k < outs.size(); ++k) {

@@ -336,7 +336,9 @@ Variant remainder_variant(fz_program* p, const fz_variant* uv, uint64_t n_stream
    const Graph& g = p->g;
    const bool f64 = uv && (uv->flags & FZ_VF_OUT_F64);
    const bool sp_ok = g.split.ok && n_samples >= 16u * (g.split.atoms() - 1);
-   const fz_variant rq{1, 16, 64, (sp_ok ? (uint32_t)FZ_VF_STAGE_PACK : (uint32_t)FZ_VF_NO_STAGE_PACK) | (f64 ? (uint32_t)FZ_VF_OUT_F64 : 0u)};
+   // (far reads are prefetched a chunk ahead: the chunk is at most half the youngest ring read -- the cap resolve_variant checks requests against)
+   const uint32_t U = g.far_lines.empty() ? 16u : std::min(16u, std::max(1u, g.far_min_read ? g.far_min_read / 2 : 16u));
+   const fz_variant rq{1, U, 64, (sp_ok ? (uint32_t)FZ_VF_STAGE_PACK : (uint32_t)FZ_VF_NO_STAGE_PACK) | (f64 ? (uint32_t)FZ_VF_OUT_F64 : 0u)};
    Variant r = resolve_variant(g, &rq, rem, n_samples, 0, 0);
    const uint64_t wmax = std::max<uint64_t>(std::max(g.n_in, g.n_out), 1), out_w = (uint64_t)std::max<uint32_t>(g.n_out, 1) * (f64 ? 2 : 1);
    while (n_streams * std::max(wmax, out_w) * 4u * r.U >= (1ull << 32) && r.U > (ws_parts(r.flags) ? 8u : 1u)) r.U /= 2;   // (a chunk of U rows: one 4 GiB descriptor)

@@ -249,6 +249,8 @@ class Program:
         else:
             C.check(C.lib.fz_compile(self.expr._h, ctypes.byref(h)))
         self._adopt(h)
+        # a graph the shipped reference evaluates against its own arity table (fz_info.differs_from_reference): the library's note about it
+        self.note = C.lib.fz_last_error().decode() if self.differs_from_reference else ""
 
     def _adopt(self, h):
         self._h = h
