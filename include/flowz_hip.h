@@ -467,8 +467,9 @@ int fz_synth_fill(float* dst_dev, uint64_t n_streams, uint32_t n_samples, uint32
  * float, the literals `1.`, `2.` are double):
  *     w0 = two_pi*freq/sr (float)   cosw0 = cos(w0)   alpha = sin(w0)/(2.*Q)
  *     b0 = (1.-cosw0)/2.   b1 = 1.-cosw0   b2 = (1.-cosw0)/2.   a0 = 1.+alpha   a1 = -2.*cosw0   a2 = 1.-alpha
- * sin/cos are evaluated in double and rounded to float (within 1 ULP of the reference's
- * std::sin/std::cos on float).  raw6 [6][n_streams] receives a0 a1 a2 b0 b1 b2 (may be NULL);
+ * sin / cos of the float w0: argument reduction + polynomial in IEEE double, rounded to float once -- the correctly rounded
+ * float (a libm's sinf / cosf, which is what the reference's std::sin(float) is, stays within 1 ULP of that; glibc's agrees
+ * on 98.7 % of the arguments); |w0| >= 2^20 gives NaN coefficients.  raw6 [6][n_streams] receives a0 a1 a2 b0 b1 b2 (may be NULL);
  * df1 [5][n_streams] receives the rows a Flowz DF1 stage with fz_stream_param coefficients reads,
  * b0/a0 b1/a0 b2/a0 -a1/a0 -a2/a0 in float (may be NULL): pass a pointer into the `params` buffer. */
 int fz_rbj_lowpass(const float* freq_dev, const float* q_dev, float sample_rate, uint64_t n_streams,

@@ -216,6 +216,15 @@ def rbj_lowpass(freq, q, sr, libmf=False):
     return raw6, df1
 
 
+def sincos_f32(x, libm=False):
+    """-> (sin, cos) float32 of float32 arguments: the checker's polynomial pair (what the RBJ generator uses on both sides), or with
+    libm=True glibc's sinf / cosf -- what the reference's std::sin / std::cos of a float are on this box."""
+    x = np.ascontiguousarray(x, F32)
+    sn, cs = np.empty_like(x), np.empty_like(x)
+    lib().fzo_sincos_array(_p(x), ctypes.c_long(x.size), ctypes.c_int(1 if libm else 0), _p(sn), _p(cs))
+    return sn, cs
+
+
 def synth_fill(seed, stream0, n_streams, T, n_wires=1, t0=0, stream_major=False):
     out = np.empty((n_streams, T, n_wires) if stream_major else (T, n_streams, n_wires), F32)
     ss, ts = _strides(T, n_streams, n_wires, stream_major)

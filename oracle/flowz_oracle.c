@@ -456,16 +456,50 @@ void fzo_cdouble_resonator(double cre, double cim, double bre, double bim, const
 
 /* ---- RBJ low-pass coefficients, reactive_equations/reactive_filter_coeff.cpp:38-58, with the
  * reference's types: every PARAMETER is float, `1.` `2.` are double literals; std::cos/std::sin of a
- * float.  sin/cos are taken in double and rounded to float, which is within 1 ULP of (and almost
- * always equal to) the float libm result the reference gets.
+ * float.  PARITY UNPINNED against the reference (reactive_expressions needs Boost).  sin and cos are NOT
+ * taken from a libm -- two libms need not agree in the last bit of a double, and the device has its own --
+ * but from fzo_sincos_f32: reduction by multiples of pi/2 and Taylor polynomials, IEEE double operations in a
+ * fixed order (built with -ffp-contract=off), the result rounded to float once.  The device generator spells
+ * the same operations; tests compare it with this BIT FOR BIT, and this with glibc's sinf / cosf -- what the
+ * reference's std::sin(float) is on this box -- (fzo_rbj_lowpass_libmf below).
  * raw6: [6][n] a0 a1 a2 b0 b1 b2;  df1: [5][n] b0/a0 b1/a0 b2/a0 -a1/a0 -a2/a0 (either may be NULL) */
+void fzo_sincos_f32(float xf, float* sn, float* cs)
+{
+   static const double S[8] = {-0x1.5555555555555p-3, 0x1.1111111111111p-7, -0x1.a01a01a01a01ap-13, 0x1.71de3a556c734p-19,
+                               -0x1.ae64567f544e4p-26, 0x1.6124613a86d09p-33, -0x1.ae7f3e733b81fp-41, 0x1.952c77030ad4ap-49};   /* (-1)^k / (2k+1)! */
+   static const double C[9] = {-0x1.0000000000000p-1, 0x1.5555555555555p-5, -0x1.6c16c16c16c17p-10, 0x1.a01a01a01a01ap-16, -0x1.27e4fb7789f5cp-22,
+                               0x1.1eed8eff8d898p-29, -0x1.93974a8c07c9dp-37, 0x1.ae7f3e733b81fp-45, -0x1.6827863b97d97p-53};   /* (-1)^k / (2k)! */
+   const double x = (double)xf;
+   if (!(fabs(x) < 0x1p20)) {
+      *sn = *cs = NAN;
+      return;
+   }
+   const double t = x * 0x1.45f306dc9c883p-1;                /* 2/pi */
+   const int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
+   const double kd = (double)k;
+   double r = x - kd * 0x1.921fb54400000p+0;                 /* pi/2 in three parts; the first product is exact */
+   r = r - kd * 0x1.0b4611a600000p-34;
+   r = r - kd * 0x1.3198a2e037073p-69;
+   const double z = r * r;
+   double ps = S[7], pc = C[8];
+   for (int i = 6; i >= 0; --i) ps = S[i] + z * ps;
+   for (int i = 7; i >= 0; --i) pc = C[i] + z * pc;
+   const double s = r + r * (z * ps), c = 1.0 + z * pc;
+   switch (k & 3) {
+      case 0: *sn = (float)s; *cs = (float)c; break;
+      case 1: *sn = (float)c; *cs = (float)-s; break;
+      case 2: *sn = (float)-s; *cs = (float)-c; break;
+      default: *sn = (float)-c; *cs = (float)s; break;
+   }
+}
+
 void fzo_rbj_lowpass(const float* freq, const float* q, float sr, long n, float* raw6, float* df1)
 {
    const float two_pi = 8. * atan(1.);
    for (long s = 0; s < n; ++s) {
       const float w0 = two_pi * freq[s] / sr;
-      const float cosw0 = (float)cos((double)w0);
-      const float sinw0 = (float)sin((double)w0);
+      float sinw0, cosw0;
+      fzo_sincos_f32(w0, &sinw0, &cosw0);
       const float alpha = sinw0 / (2. * q[s]);
       const float b0 = (1. - cosw0) / 2.;
       const float b1 = 1. - cosw0;
@@ -480,6 +514,19 @@ void fzo_rbj_lowpass(const float* freq, const float* q, float sr, long n, float*
       if (df1) {
          df1[0 * n + s] = b0 / a0; df1[1 * n + s] = b1 / a0; df1[2 * n + s] = b2 / a0;
          df1[3 * n + s] = -a1 / a0; df1[4 * n + s] = -a2 / a0;
+      }
+   }
+}
+
+/* sin / cos of n floats: the checker's polynomial pair (libm = 0) or glibc's sinf / cosf (libm = 1) */
+void fzo_sincos_array(const float* x, long n, int libm, float* sn, float* cs)
+{
+   for (long i = 0; i < n; ++i) {
+      if (libm) {
+         sn[i] = sinf(x[i]);
+         cs[i] = cosf(x[i]);
+      } else {
+         fzo_sincos_f32(x[i], &sn[i], &cs[i]);
       }
    }
 }

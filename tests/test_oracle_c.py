@@ -178,8 +178,10 @@ def test_complex_double_state_and_smith_division_three_spellings_agree():
 
 
 def test_rbj_lowpass_oracle_matches_reference_spelling_within_1ulp():
-    """reactive_filter_coeff.cpp:38-58: the oracle takes sin/cos in double and rounds to float; the
-    reference calls std::sin/std::cos on float.  Coefficients agree within 1 ULP (mostly exactly)."""
+    """reactive_filter_coeff.cpp:38-58: the reference calls std::sin / std::cos on a float -- glibc's sinf / cosf on this box, accurate to
+    0.56 ULP, i.e. NOT always the correctly rounded float.  The checker (and, operation for operation, the device generator) evaluates its
+    own polynomial pair in double and rounds once: correctly rounded, hence within 1 ULP of the reference's and equal in ~98.7 % of the
+    arguments.  The coefficients inherit that bound."""
     rng = np.random.default_rng(3)
     freq = rng.uniform(20.0, 20000.0, 4096).astype(np.float32)
     q = rng.uniform(0.3, 12.0, 4096).astype(np.float32)
@@ -194,3 +196,28 @@ def test_rbj_lowpass_oracle_matches_reference_spelling_within_1ulp():
     a0, a1, a2, b0, b1, b2 = (float(v) for v in r[:, 0])
     assert abs(a0 - 1.0443) < 1e-3 and abs(a1 + 1.99607) < 1e-4 and abs(b1 - 2 * b0) < 1e-9 and b0 == b2
     assert np.allclose(d[:, 0], [b0 / a0, b1 / a0, b2 / a0, -a1 / a0, -a2 / a0], rtol=1e-7)
+
+
+def test_polynomial_sincos_is_correctly_rounded_and_within_1ulp_of_libm():
+    """fzo_sincos_f32 (oracle/flowz_oracle.c): sin / cos of a float by reduction + Taylor polynomials in IEEE double, rounded to float once --
+    the pair the RBJ generator uses on BOTH sides so that device and checker agree bit for bit.  Against a 200-bit evaluation it is the
+    correctly rounded float on every sample; against glibc's sinf / cosf (the reference's std::sin(float) here) within 1 ULP."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(0.0, np.pi, 400000), rng.uniform(-40.0, 40.0, 100000), rng.uniform(-1.0e6, 1.0e6, 100000),
+                        [0.0, -0.0, 1e-30, -1e-30, np.pi / 2, np.pi / 4, 3 * np.pi / 4, 1.0, 2.0 ** 20 - 1.0]]).astype(np.float32)
+    s, c = C.sincos_f32(x)
+    sl, cl = C.sincos_f32(x, libm=True)
+    ulps = lambda a, b: np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))   # noqa: E731
+    tiny = (np.abs(sl) < 1e-6) | (np.abs(cl) < 1e-6)          # (results next to zero: an absolute error of 2^-24 ULPs of 1 is many ULPs of 1e-7)
+    assert ulps(s, sl)[~tiny].max() <= 1 and ulps(c, cl)[~tiny].max() <= 1
+    assert (ulps(s, sl) == 0).mean() > 0.98 and (ulps(c, cl) == 0).mean() > 0.98
+    assert np.abs(s - sl).max() <= 2.0 ** -24 and np.abs(c - cl).max() <= 2.0 ** -24
+    assert s[-9] == 0.0 and c[-9] == 1.0 and s[-8] == 0.0 and s[-7] == np.float32(1e-30)
+    # out of the domain (|x| >= 2^20: k * pi/2-head would no longer be exact), inf, nan: NaN -- on the device too
+    sn, cn = C.sincos_f32(np.array([2.0 ** 20, -3e9, np.inf, np.nan], np.float32))
+    assert np.isnan(sn).all() and np.isnan(cn).all()
+    mpmath = pytest.importorskip("mpmath")
+    mpmath.mp.prec = 200
+    for i in rng.integers(0, len(x), 3000):
+        xi = mpmath.mpf(float(x[i]))
+        assert np.float32(float(mpmath.sin(xi))) == s[i] and np.float32(float(mpmath.cos(xi))) == c[i], float(x[i]).hex()

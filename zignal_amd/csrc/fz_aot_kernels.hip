@@ -11,6 +11,49 @@ namespace fz {
 // ---- AOT utility kernels ---------------------------------------------------------------------------------------
 typedef float fzr_f4 __attribute__((ext_vector_type(4)));
 
+// sin and cos of a FLOAT argument, each rounded to float once: argument reduction by multiples of pi/2 (a two-part pi/2 whose head has
+// 33 bits: k * head is exact), then the Taylor polynomials of sin / cos on [-pi/4, pi/4] by Horner's rule in r^2 -- IEEE double additions
+// and multiplications in a fixed order, no FMA (this file is built with -ffp-contract=off), no libm: the C checker (oracle/flowz_oracle.c)
+// spells the same operations and gets the same bits.  The double result is within 2^-60 of the true value, so the float is the correctly
+// rounded one except for arguments within that distance of a rounding boundary; |x| >= 2^20 (k * head no longer exact): NaN on both sides.
+__device__ __forceinline__ void fz_sincos_f32(float xf, float* sn, float* cs)
+{
+   const double x = (double)xf;
+   if (!(fabs(x) < 0x1p20)) {
+      *sn = *cs = __builtin_nanf("");
+      return;
+   }
+   const double t = x * 0x1.45f306dc9c883p-1;                               // x * 2/pi
+   const int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));                         // nearest integer (conversion truncates)
+   const double kd = (double)k;
+   double r = x - kd * 0x1.921fb54400000p+0;                                 // pi/2, first 33 bits: the product is exact
+   r = r - kd * 0x1.0b4611a600000p-34;                                       // ... next 33 bits
+   r = r - kd * 0x1.3198a2e037073p-69;                                       // ... the rest
+   const double z = r * r;
+   double ps = 0x1.952c77030ad4ap-49;                                        // 1/17!
+   ps = -0x1.ae7f3e733b81fp-41 + z * ps;
+   ps = 0x1.6124613a86d09p-33 + z * ps;
+   ps = -0x1.ae64567f544e4p-26 + z * ps;
+   ps = 0x1.71de3a556c734p-19 + z * ps;
+   ps = -0x1.a01a01a01a01ap-13 + z * ps;
+   ps = 0x1.1111111111111p-7 + z * ps;
+   ps = -0x1.5555555555555p-3 + z * ps;
+   const double s = r + r * (z * ps);
+   double pc = -0x1.6827863b97d97p-53;                                       // -1/18!
+   pc = 0x1.ae7f3e733b81fp-45 + z * pc;
+   pc = -0x1.93974a8c07c9dp-37 + z * pc;
+   pc = 0x1.1eed8eff8d898p-29 + z * pc;
+   pc = -0x1.27e4fb7789f5cp-22 + z * pc;
+   pc = 0x1.a01a01a01a01ap-16 + z * pc;
+   pc = -0x1.6c16c16c16c17p-10 + z * pc;
+   pc = 0x1.5555555555555p-5 + z * pc;
+   pc = -0x1.0000000000000p-1 + z * pc;
+   const double c = 1.0 + z * pc;
+   const int q = k & 3;
+   *sn = (float)(q == 0 ? s : q == 1 ? c : q == 2 ? -s : -c);
+   *cs = (float)(q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s);
+}
+
 // reactive_equations/reactive_filter_coeff.cpp:38-58, one stream per thread
 __global__ void __launch_bounds__(256) fz_rbj_lowpass_kernel(const float* __restrict__ freq, const float* __restrict__ q, float sr,
                                                              unsigned long long n, float* raw6, float* df1)
@@ -19,8 +62,8 @@ __global__ void __launch_bounds__(256) fz_rbj_lowpass_kernel(const float* __rest
    if (s >= n) return;
    const float two_pi = (float)(8. * 0.78539816339744830962);     // const float two_pi = 8. * std::atan(1.)
    const float w0 = two_pi * freq[s] / sr;
-   const float cosw0 = (float)cos((double)w0);                      // std::cos(float) to within 1 ULP
-   const float sinw0 = (float)sin((double)w0);
+   float sinw0, cosw0;                                              // std::sin / std::cos of a float (see fz_sincos_f32)
+   fz_sincos_f32(w0, &sinw0, &cosw0);
    const float alpha = (float)(sinw0 / (2. * q[s]));
    const float b0 = (float)((1. - cosw0) / 2.);
    const float b1 = (float)(1. - cosw0);
