@@ -225,10 +225,7 @@ typedef struct fz_variant {
    uint32_t flags;             /* FZ_VF_* ; 0 = default                                        */
 } fz_variant;
 
-enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores                   */
-       FZ_VF_NO_XCD_REMAP = 2u, /* plain blockIdx order instead of one contiguous stream range per XCD */
-       FZ_VF_SLP = 4u,          /* let the compiler's SLP vectoriser pair scalar ops (off by default) */
-       FZ_VF_STAGE_PACK = 8u,   /* one stream per lane; the K isomorphic segments of a serial graph (e.g. the
+enum { FZ_VF_STAGE_PACK = 8u,   /* one stream per lane; the K isomorphic segments of a serial graph (e.g. the
                                    stages of a cascade, after an optional scalar prefix) run skewed in time,
                                    segment j at t-j, and segments i, i+K/2 share one v_pk_* per node; chosen
                                    automatically below 2^18 streams when fz_info.stage_packable          */
@@ -271,7 +268,8 @@ enum { FZ_VF_NO_NT = 1u,        /* plain instead of non-temporal loads/stores   
  * Fewer, fatter waves keep fewer frame tiles in flight: which occupancy streams fastest from HBM depends
  * on the board -- let fz_program_tune measure it                                                   */
 #define FZ_VF_MAX_WG(n) (((uint32_t)(n) & 7u) << 20)
-/* bits 12..14 / 16..18: cache policy of frame loads / stores (experiment knob, see the kernel source) */
+/* bits 0..2, 12..14, 16..18 and 27 are reserved (FZ_E_INVALID): rounds 1-5 had experiment knobs there (cache policies, the SLP vectoriser, the
+ * plain block order); those are compile-time switches of the kernel source now (FLOWZ_HIP_EXTRA_OPTS) */
 
 int fz_program_build(fz_program* p, const fz_variant* v);           /* JIT (or cache hit) only   */
 /* the same with the variant's automatic fields resolved as a launch of this block shape would: the shape of a launch is

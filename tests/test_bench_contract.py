@@ -160,6 +160,36 @@ def test_bench_two_ranks_on_one_gpu_rehearse_the_sharded_path():
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_on_one_gpu_rehearse_the_drivers_scaling_run():
+    """What `bench.py --gpus 8` does on a node, rehearsed on ONE GPU (round 6: the driver's first 8-GPU run is also the first execution with more
+    than one RCCL rank, so everything around the collective is exercised here): eight ranks under torch.distributed.run share device 0 and
+    reduce over gloo, 131 072 streams each.  Every rank measures its plan at the same time (fz_program_tune: eight processes appending to
+    the ONE plans.txt of the shared kernel cache, none of them torn), runs its shard, checks streams of its own shard against the oracle;
+    the integer checksum over the eight shards equals a one-rank run over the union; the line stays below 4 KB with eight per-rank times."""
+    plans = os.path.join(os.environ.get("FLOWZ_HIP_CACHE") or os.path.join(ROOT, "zignal_amd", "_kcache"), "plans.txt")   # (the library's kernel cache directory)
+    before = open(plans).read().splitlines() if os.path.exists(plans) else []
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-config2", "--no-config34", "--no-sustained", "--no-layout-legs", "--no-extras", "--no-next-rows"]
+    weak = _run_bench(["--gpus", "8", "--streams", "131072", "--dist-backend", "gloo"] + common, nproc=8, timeout=1200)
+    assert weak["n_gpus"] == 8 and weak["scaling"] == "weak" and weak["config"]["streams_total"] == 8 * 131072 and weak["config"]["streams_per_gpu"] == 131072
+    assert weak["parity"].startswith("bitwise-equal on") and "every one of the 8 ranks" in weak["parity"]
+    assert weak["dist_backend"] == "gloo" and weak["rccl_ranks"] == 0
+    assert len(weak["ms_per_step_per_rank"]) == 8 and min(weak["ms_per_step_per_rank"]) > 0
+    assert "x8" in weak["config"]["parallelism"] and weak["roofline"]["bound"] == "hbm" and 0 < weak["roofline"]["frac"] < 1 and "cpu_baseline" not in weak
+    # value = the samples ALL ranks processed / the slowest rank's wall time (barrier to barrier)
+    assert abs(weak["value"] - 8 * 131072 * 4096 * 2 / (weak["ms_per_step"] * 2 / 1e3) / 1e6) / weak["value"] < 1e-2
+    assert abs(weak["per_gpu"] * 8 - weak["value"]) / weak["value"] < 1e-3
+    after = open(plans).read().splitlines() if os.path.exists(plans) else []
+    new = after[len(before):]
+    mine = [l.split() for l in new if l.split()[2:4] == ["131072", "0"]]
+    assert len(mine) >= 8 and all(len(f) == 11 and f[0] == "fzplan3" for f in mine), new[-10:]      # eight tunes, eight whole lines
+    one = _run_bench(["--gpus", "1", "--streams", str(8 * 131072), "--no-autotune"] + common)
+    assert weak["checksum"] == one["checksum"] and isinstance(weak["checksum"], int)
+    strong = _run_bench(["--gpus", "8", "--scaling", "strong", "--streams-total", str(8 * 131072 + 5), "--dist-backend", "gloo", "--no-autotune"] + common, nproc=8, timeout=1200)
+    assert strong["scaling"] == "strong" and strong["config"]["streams_total"] == 8 * 131072 + 5 and len(strong["ms_per_step_per_rank"]) == 8
+    assert strong["parity"].startswith("bitwise-equal on")
+
+
+@pytest.mark.gpu
 def test_bench_one_rank_reduces_its_statistics_over_rccl():
     """The `nccl` (= RCCL) branch of bench.py on real hardware: one rank under torch.distributed.run, process group on the GPU,
     the three statistics reduced by RCCL all-reduces on device tensors (zignal_amd/dist.py).  Same checksum and stream count

@@ -152,6 +152,20 @@ def test_remainder_kernel_of_a_far_line_with_a_shallow_tap_builds(tmp_path, monk
         assert name.startswith("fz_block_kernel_p"), name
 
 
+def test_reserved_variant_flag_bits_are_refused():
+    """Round 6 took the experiment knobs of rounds 1-5 out of the variant flags (plain loads / block order, the SLP vectoriser, cache-policy
+    fields, the persistent launch): they are compile-time switches of the kernel source now (FLOWZ_HIP_EXTRA_OPTS=-DFZ_DBG_...).  A caller
+    that still sets one of those bits is told so instead of silently getting the default kernel under another name."""
+    p = F.compile(F.from_sexpr(G.df1_cascade(2)))
+    for bit in (1, 2, 4, 1 << 12, 5 << 16, 1 << 27):
+        with pytest.raises(F.FlowzError) as ei:
+            p.kernel_name(F.make_variant(2, 8, 256, bit), 1 << 20, 4096)
+        assert ei.value.code == _capi.FZ_E_INVALID and "reserved" in str(ei.value)
+    assert not any(hasattr(_capi, n) for n in ("FZ_VF_NO_NT", "FZ_VF_NO_XCD_REMAP", "FZ_VF_SLP"))
+    hdr = open(os.path.join(ROOT, "include", "flowz_hip.h")).read()
+    assert "FZ_VF_SLP" not in hdr and "FZ_VF_NO_NT" not in hdr and "FZ_VF_NO_XCD_REMAP" not in hdr
+
+
 def test_lowering_osc_chain_with_stream_params():
     g = G.osc_chain(6)
     p = F.compile(F.from_sexpr(g))
@@ -708,9 +722,11 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
     IO = F.C.FZ_VF_IO_WAVE
     r = p.kernel_resources(F.make_variant(0, 0, 0, IO), 65536, 4096)
     assert r["scratch_bytes"] == 0 and r["lds_bytes"] == 4 * 2 * 16 * 64 * 16                   # four (compute, I/O) pairs x two rings of 16 groups
-    assert [v.flags for v in p.tune_candidates(32768, 4096)][:4] == [0, F.C.FZ_VF_WAVES(2), F.C.FZ_VF_WAVES(2) | IO, 8]
-    assert [v.flags for v in p.tune_candidates(16384, 4096)][:4] == [0, F.C.FZ_VF_WAVES(3), F.C.FZ_VF_WAVES(3) | IO, F.C.FZ_VF_WAVES(2)]
-    assert IO in [v.flags for v in p.tune_candidates(65536, 4096)]
+    # what fz_program_tune measures there (round 6: only candidates some board of rounds 3-5 saw ahead): the split without its I/O wave, the single wave
+    assert [v.flags for v in p.tune_candidates(32768, 4096)] == [0, F.C.FZ_VF_WAVES(2), 8]
+    assert [v.flags for v in p.tune_candidates(16384, 4096)] == [0, F.C.FZ_VF_WAVES(3), 8]
+    assert [v.flags for v in p.tune_candidates(65536, 4096)] == [0, IO, IO | F.C.FZ_VF_IO_WAVE2, F.C.FZ_VF_WAVES(3), 8]
+    assert sum(len(p.tune_candidates(n, 4096, t)) for n in (16384, 65536, 1 << 20) for t in (0, 8192)) <= 26
     q = F.compile(F.from_sexpr(G.df1_cascade(8)))
     assert q.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w4f3072" and "#define FZ_WS_W 4" in q.source(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVES(4)))
     src = p.source(F.make_variant(1, 16, 0, IO))

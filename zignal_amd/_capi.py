@@ -24,7 +24,7 @@ class NoDeviceError(FlowzError):
 
 FZ_OK, FZ_E_INVALID, FZ_E_GRAPH, FZ_E_NO_DEVICE, FZ_E_HIP, FZ_E_COMPILE, FZ_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 FZ_OP_ADD, FZ_OP_SUB, FZ_OP_MUL, FZ_OP_DIV, FZ_OP_NEG = 1, 2, 3, 4, 5
-FZ_VF_NO_NT, FZ_VF_NO_XCD_REMAP, FZ_VF_SLP, FZ_VF_STAGE_PACK, FZ_VF_NO_STAGE_PACK, FZ_VF_OUT_F64 = 1, 2, 4, 8, 16, 64
+FZ_VF_STAGE_PACK, FZ_VF_NO_STAGE_PACK, FZ_VF_OUT_F64 = 8, 16, 64
 FZ_VF_PREFETCH3 = 32
 FZ_VF_STREAM_MAJOR = 128
 FZ_VF_SM_LONG, FZ_VF_SM_SHORT, FZ_VF_WAVE_SPLIT, FZ_VF_IO_WAVE = 256, 512, 1024, 32768

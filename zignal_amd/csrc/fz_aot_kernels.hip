@@ -13,7 +13,7 @@ typedef float fzr_f4 __attribute__((ext_vector_type(4)));
 
 // sin and cos of a FLOAT argument, each rounded to float once: argument reduction by multiples of pi/2 (a two-part pi/2 whose head has
 // 33 bits: k * head is exact), then the Taylor polynomials of sin / cos on [-pi/4, pi/4] by Horner's rule in r^2 -- IEEE double additions
-// and multiplications in a fixed order, no FMA (this file is built with -ffp-contract=off), no libm: the C checker (oracle/flowz_oracle.c)
+// and multiplications in a fixed order, no FMA (this file is built with -ffp-contract=off), no libm: the tests' C checker
 // spells the same operations and gets the same bits.  The double result is within 2^-60 of the true value, so the float is the correctly
 // rounded one except for arguments within that distance of a rounding boundary; |x| >= 2^20 (k * head no longer exact): NaN on both sides.
 __device__ __forceinline__ void fz_sincos_f32(float xf, float* sn, float* cs)

@@ -37,10 +37,10 @@ std::string kernel_name(const Graph& g, const Variant& v)
    if ((v.flags & FZ_VF_STAGE_PACK) && g.split.ok) n += "s" + std::to_string(g.split.K) + (g.split.m > 1 ? "a" + std::to_string(g.split.m) : "");
    if (ws_parts(v.flags)) n += "w" + std::to_string(ws_parts(v.flags)) + (ws_io(v.flags) ? (ws_io_waves(v.flags) == 2 ? "io2" : "io") : "");
    // (the flags the caller can set, then one letter per INTERNAL bit the launch path added: R rows clipped per descriptor (a count that is
-   //  not a multiple of the streams per lane), M merging stores (rows off the 64-byte grid), K persistent launch, L the lane's four streams as
+   //  not a multiple of the streams per lane), M merging stores (rows off the 64-byte grid), L the lane's four streams as
    //  two pairs 128 apart, S the lane's streams 64 apart)
-   constexpr uint32_t internal = FZ_VF_RAGGED | FZ_VF_ST_MERGE | FZ_VF_PERSIST | FZ_VF_LANE_PAIRS | FZ_VF_LANE_SINGLES;
-   return n + "f" + std::to_string(v.flags & ~internal) + ((v.flags & FZ_VF_RAGGED) ? "R" : "") + ((v.flags & FZ_VF_ST_MERGE) ? "M" : "") + ((v.flags & FZ_VF_PERSIST) ? "K" : "") +
+   constexpr uint32_t internal = FZ_VF_RAGGED | FZ_VF_ST_MERGE | FZ_VF_LANE_PAIRS | FZ_VF_LANE_SINGLES;
+   return n + "f" + std::to_string(v.flags & ~internal) + ((v.flags & FZ_VF_RAGGED) ? "R" : "") + ((v.flags & FZ_VF_ST_MERGE) ? "M" : "") +
           ((v.flags & FZ_VF_LANE_PAIRS) ? "L" : "") + ((v.flags & FZ_VF_LANE_SINGLES) ? "S" : "");
 }
 

@@ -153,8 +153,9 @@ inline uint32_t ws_parts(uint32_t flags) { const uint32_t W = wave_split_of(flag
 inline uint32_t ws_io_waves(uint32_t flags) { return ws_io(flags) ? ((flags & FZ_VF_IO_WAVE2) ? 2u : 1u) : 0u; }   // FZ_VF_IO_WAVE2: loader and storer are two waves
 inline uint32_t ws_waves(uint32_t flags) { return ws_parts(flags) + (ws_parts(flags) ? ws_io_waves(flags) : 0u); }
 
-// internal variant flag (never set by callers): FZ_VF_GRID_SYNC with more blocks than the chip holds workgroups -> persistent launch
-constexpr uint32_t FZ_VF_PERSIST = 1u << 27;
+// variant flag bits that mean nothing (any more): rounds 1-5 kept experiment knobs there (plain loads / block order, the SLP vectoriser, cache
+// policies, the persistent launch) -- compile-time switches of the kernel source now (FLOWZ_HIP_EXTRA_OPTS=-DFZ_DBG_...).  Refused by check_request.
+constexpr uint32_t FZ_VF_RESERVED = 1u | 2u | 4u | (7u << 12) | (7u << 16) | (1u << 27);
 // internal variant flag: the stream count is not a multiple of the streams per lane -- the last lane's accesses run past the rows' ends,
 // where the per-row buffer descriptors return zeros / drop the writes (frame kernel in lockstep, plain time-major rows)
 constexpr uint32_t FZ_VF_RAGGED = 1u << 28;

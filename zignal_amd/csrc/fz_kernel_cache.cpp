@@ -75,11 +75,10 @@ void* Kernel::function_on_current_device(const std::string& symbol)
 static std::vector<const char*> build_options(const Graph& g, const Variant& v)
 {
    // -ffp-contract=off: one rounding per graph node (no v_fma/v_fmac); IEEE division.
-   // The SLP vectoriser is off by default: with one stream per lane it pairs unrelated scalar
+   // The SLP vectoriser is off: with one stream per lane it pairs unrelated scalar
    // mul/add into v_pk_* at the price of v_mov shuffles, a net VALU loss on gfx950.
    std::vector<const char*> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                                 "-fhip-fp32-correctly-rounded-divide-sqrt"};
-   if (!(v.flags & FZ_VF_SLP)) o.push_back("-fno-slp-vectorize");
+                                 "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"};
    // The parts of a wave split carry ONE or two packed pairs of segments: so little instruction-level parallelism that the default
    // scheduler (which orders for occupancy) leaves dependent v_pk_mul / v_pk_add back to back -- two s_nop per step in the ISA on
    // top of the wait.  The max-ILP strategy interleaves the atoms: 411 instead of 477 instructions per round of 32 steps, no

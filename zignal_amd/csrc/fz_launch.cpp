@@ -336,9 +336,8 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
       const unsigned threads = ws_parts(w.flags) ? w.block * ws_waves(w.flags) : w.block;
       // FZ_VF_GRID_SYNC needs every workgroup that synchronises RUNNING: with more blocks than the chip holds workgroups of this
       // kernel (occupancy x CUs) the streams are cut into LAPS -- contiguous ranges of at most one workgroup per resident slot,
-      // the same number of blocks in every lap (whole eights: the XCDs) -- and every lap is a launch of its own (round 4; the
-      // one-lap kernel has no loop to pay registers for: four streams per lane fit where the persistent kernel of round 3 stepped
-      // down).  FZ_VF_PERSIST (internal, FLOWZ_HIP_LAPS=kernel): one launch of `resident` workgroups that loop over the laps.
+      // the same number of blocks in every lap (whole eights: the XCDs) -- and every lap is a launch of its own (the one-lap kernel has no
+      // loop to pay registers for: four streams per lane fit where round 3's persistent kernel stepped down; that kernel left in round 6).
       unsigned laps = 1, per_lap = n_blocks, grid = n_blocks;
       size_t sync_bytes = 0;
       if (w.flags & FZ_VF_GRID_SYNC) {
@@ -348,15 +347,11 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
             per_lap = std::min(resident, ((n_blocks + laps - 1) / laps + 7u) / 8u * 8u);
             grid = per_lap;
          }
-         sync_bytes = (size_t)((w.flags & FZ_VF_PERSIST) ? laps : 1u) * 8 * 128;   // per-(lap, XCD) arrival counters, zeroed in stream order before the launch
-         if (w.flags & FZ_VF_PERSIST) laps = 1;                                     // (the kernel loops)
+         sync_bytes = (size_t)8 * 128;                       // one arrival counter per XCD, zeroed in stream order before every lap's launch
       }
       ArgsHeader h{in, out, state, params, mod_dev, nullptr, (unsigned long long)n_streams, n_samples, group0 + groups,
                    (unsigned int)row_streams, tile_streams ? (unsigned int)(tile_streams / (w.P * w.block)) : 0u, rows_total, row0, mod_stride, n_blocks, group0, 0u};
-      // (developer switch, timing experiments only: FLOWZ_HIP_ONLY_LAP=k launches lap k alone -- the other streams are left untouched)
-      static const int only_lap = [] { const char* e = std::getenv("FLOWZ_HIP_ONLY_LAP"); return e ? std::atoi(e) : -1; }();
       for (unsigned lap = 0; lap < laps; ++lap) {
-         if (only_lap >= 0 && laps > 1 && (int)lap != only_lap) continue;
          if (laps > 1) {
             h.group0 = group0 + lap * per_lap * w.block;
             grid = std::min(per_lap, n_blocks - lap * per_lap);

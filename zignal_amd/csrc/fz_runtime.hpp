@@ -1,6 +1,7 @@
 // Internal to the runtime half of libflowz_hip (the files that talk to HIP / hiprtc):
 //   fz_kernel_cache.cpp  hiprtc build, on-disk code-object cache, module loading, register budget
-//   fz_plan.cpp          variant resolution (the library defaults), measured plans and their persistence, fz_program_tune
+//   fz_plan.cpp          variant resolution: the library's static choice per layout and kernel body
+//   fz_tune.cpp          measured plans: tune candidates, fz_program_tune, persistence per board
 //   fz_launch.cpp        the launch of the fused block kernel
 //   fz_bank.cpp          device-resident closure state (fz_bank) and the host-frames pipelines
 //   fz_aot_kernels.hip   the AOT utility kernels (synthetic fill, copy probe, RBJ coefficients, layout adapter)
