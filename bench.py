@@ -12,7 +12,7 @@ already resident in HBM.  Rank 0 prints ONE JSON line.
              events recorded on the launch stream (torch's current stream, which run_block uses);
              peak = 8000 GB/s (HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md);
              traffic = PMC bytes of THIS kernel symbol on THIS workload (profiles/pmc_traffic.json,
-             collected by tools/profile_round.sh), null when that symbol was not profiled;
+             collected by tools/profile_bench.sh, keyed by the kernel's code id), null when that code was not profiled;
              sustained = the same launches back to back for >= 2 s (power-managed clocks settle), with
              sustained.board = package power / power cap / shader clock sampled through rocm-smi meanwhile
              (this workload runs at the board's power cap: profiles/r03/power_and_clocks.txt)

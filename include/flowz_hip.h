@@ -43,7 +43,15 @@ const char* fz_version(void);
  * ---------------------------------------------------------------------------------------- */
 typedef struct fz_expr fz_expr;
 
-typedef enum fz_op { FZ_OP_ADD = 1, FZ_OP_SUB = 2, FZ_OP_MUL = 3, FZ_OP_DIV = 4, FZ_OP_NEG = 5 } fz_op;
+typedef enum fz_op { FZ_OP_ADD = 1, FZ_OP_SUB = 2, FZ_OP_MUL = 3, FZ_OP_DIV = 4, FZ_OP_NEG = 5,
+                     /* the comparison and logical operators of C++ (proto::_default applies whatever operator a node is, flowz.hpp:51-55,
+                        :769-772): the result is the operator's bool as it behaves in arithmetic -- 1 or 0, taking the type of what it
+                        meets next (bool * float is a float multiplication, bool * double a double one); an output frame or a delay
+                        line receives it as 1.0f / 0.0f.  Operands are compared in their common type (double if one is), IEEE semantics
+                        (every comparison with a NaN is false, != true).  Not for std::complex wires.  a && b, a || b, !a test their
+                        operands against zero as C++ does for arithmetic types; both sides are always evaluated (no side effects to skip). */
+                     FZ_OP_LT = 6, FZ_OP_LE = 7, FZ_OP_GT = 8, FZ_OP_GE = 9, FZ_OP_EQ = 10, FZ_OP_NE = 11,
+                     FZ_OP_NOT = 12, FZ_OP_AND = 13, FZ_OP_OR = 14 } fz_op;
 
 fz_expr* fz_placeholder(uint32_t i);                 /* _i          make_placeholder<i>() :78-82   */
 fz_expr* fz_delayed(uint32_t i, uint32_t n);         /* _i[_n]      delayed_placeholder   :84-85   */
@@ -84,8 +92,9 @@ fz_expr* fz_modulator(uint32_t k);                   /* the std::ref(x) terminal
                                                         sample): modulator k has one value per sample of a block, the same
                                                         for all streams, read from the array fz_program_set_modulation names --
                                                         an input wire without the per-stream HBM traffic (scalar loads)       */
-fz_expr* fz_arith(fz_op op, fz_expr* a, fz_expr* b); /* any C++ arithmetic operator, _default :769-772;
-                                                        b is ignored (may be NULL) for FZ_OP_NEG      */
+fz_expr* fz_arith(fz_op op, fz_expr* a, fz_expr* b); /* any C++ arithmetic, comparison or logical operator,
+                                                        _default :769-772; b is ignored (may be NULL) for
+                                                        FZ_OP_NEG and FZ_OP_NOT                       */
 fz_expr* fz_channel (fz_expr* a, fz_expr* b);        /* a , b       channel_operator   :90           */
 fz_expr* fz_parallel(fz_expr* a, fz_expr* b);        /* a | b       parallel_operator  :91           */
 fz_expr* fz_sequence(fz_expr* a, fz_expr* b);        /* a |= b      sequence_operator  :92           */
@@ -173,7 +182,9 @@ typedef enum fz_ir_kind {
                          inside an operator: the float complex division of libgcc's __divsc3, see fz_arith)           */
    FZ_IR_MOD = 12,    /* a = modulator index: value of sample-rate modulator a at this sample (fz_modulator)          */
    FZ_IR_ABSLT = 13,  /* |a| < |b| ? 1 : 0  (in the operands' type)                                                    */
-   FZ_IR_SELECT = 14  /* a != 0 ? b : c   (the data-dependent branch of __divdc3; both sides are evaluated)            */
+   FZ_IR_SELECT = 14, /* a != 0 ? b : c   (the data-dependent branch of __divdc3; both sides are evaluated)            */
+   FZ_IR_LT = 15, FZ_IR_LE = 16, FZ_IR_GT = 17, FZ_IR_GE = 18, FZ_IR_EQ = 19, FZ_IR_NE = 20
+                      /* a (cmp) b ? 1.0f : 0.0f -- a float32 node (dtype 0) whose operands are compared in double when one of them is     */
 } fz_ir_kind;
 
 typedef struct fz_ir_node {

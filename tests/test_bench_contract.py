@@ -117,7 +117,7 @@ def test_bench_json_contract_small_workload(tmp_path):
     assert 0.5 < c["Msamples_per_s_per_core"] * c["cores"] / c["value"] < 2.0
 
 
-def _run_bench(args, nproc=1, timeout=900, launcher=False):
+def _run_bench(args, nproc=1, timeout=900, launcher=False, env=None):
     if nproc > 1 or launcher:
         import socket
         s = socket.socket()
@@ -130,7 +130,7 @@ def _run_bench(args, nproc=1, timeout=900, launcher=False):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     import tempfile
     with tempfile.TemporaryDirectory() as td:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, BENCH_DETAILS=os.path.join(td, "details.json")))
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, BENCH_DETAILS=os.path.join(td, "details.json"), **(env or {})))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and len(lines[0]) < LINE_LIMIT, out.stdout[-2000:]
@@ -169,7 +169,9 @@ def test_bench_eight_ranks_on_one_gpu_rehearse_the_drivers_scaling_run():
     plans = os.path.join(os.environ.get("FLOWZ_HIP_CACHE") or os.path.join(ROOT, "zignal_amd", "_kcache"), "plans.txt")   # (the library's kernel cache directory)
     before = open(plans).read().splitlines() if os.path.exists(plans) else []
     common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-config2", "--no-config34", "--no-sustained", "--no-layout-legs", "--no-extras", "--no-next-rows"]
-    weak = _run_bench(["--gpus", "8", "--streams", "131072", "--dist-backend", "gloo"] + common, nproc=8, timeout=1200)
+    # (bench.py switches the persisted plans off for itself -- every run measures; the rehearsal switches them back on so that the eight tunes also
+    #  meet at the one plans.txt, which a caller's eight processes would)
+    weak = _run_bench(["--gpus", "8", "--streams", "131072", "--dist-backend", "gloo"] + common, nproc=8, timeout=1200, env={"FLOWZ_HIP_NO_PLAN_CACHE": "0"})
     assert weak["n_gpus"] == 8 and weak["scaling"] == "weak" and weak["config"]["streams_total"] == 8 * 131072 and weak["config"]["streams_per_gpu"] == 131072
     assert weak["parity"].startswith("bitwise-equal on") and "every one of the 8 ranks" in weak["parity"]
     assert weak["dist_backend"] == "gloo" and weak["rccl_ranks"] == 0

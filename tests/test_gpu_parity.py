@@ -1572,6 +1572,30 @@ def test_block_windows_and_control_rate_coefficients(torch_cuda, F):
         prog.run_window(xd, od, st, T - 10, 20, params=pb[0])          # window beyond the buffer
 
 
+def test_lds_rings_take_the_row_walk_in_lockstep_on_plain_rows(torch_cuda, F):
+    """Round 6: graphs with LDS rings on plain time-major rows of many streams run 256-lane workgroups in lockstep, XCD-synchronised, the
+    resident workgroups as one lap of many (ahead of the free-running kernel on every one of six fresh allocations: profiles/r06/placement.txt).
+    A stream count that fills neither the last workgroup nor the last lap, two chained blocks: the library's default by name, sampled streams
+    against the oracle, the whole output and the state against the free-running kernel."""
+    torch = torch_cuda
+    g = G.lds_ring_comb()
+    prog = F.compile(F.from_sexpr(g))
+    ns, T = 300_000 + 37, 1100
+    assert prog.kernel_name(None, ns, T) == "fz_block_kernel_p1u16b256f8912896M"          # (rows off the 64-byte grid: merging stores)
+    assert prog.kernel_name(None, 1 << 20, 4096) == "fz_block_kernel_p1u16b256f8912896" and prog.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p1u32b256f0"
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED + 61)
+    y1, st1 = prog.run_block(x[:600].contiguous())
+    y2, st2 = prog.run_block(x[600:].contiguous(), state=st1.clone())
+    r1, sr1 = prog.run_block(x[:600].contiguous(), variant=F.make_variant(1, 32, 256))
+    r2, sr2 = prog.run_block(x[600:].contiguous(), state=sr1.clone(), variant=F.make_variant(1, 32, 256))
+    assert torch.equal(y1, r1) and torch.equal(y2, r2) and torch.equal(st1, sr1) and torch.equal(st2, sr2)
+    ids = np.concatenate([np.arange(3), np.random.default_rng(5).integers(0, ns, 90), np.arange(ns - 40, ns)])
+    want = O.compile(g, len(ids)).run(O.synth_input(SEED + 61, ids, T))
+    got = torch.cat([y1, y2])[:, torch.as_tensor(ids, device="cuda")].cpu().numpy()
+    assert ndiff(got, want) == 0
+
+
 SM_GRAPHS = {"cascade6": lambda: G.df1_cascade(6), "par4": G.par4_sum, "cross_wire": G.cross_wire, "integrator": G.integrator,
              "lds_ring": lambda: G.seq(G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 40))), G.fb(G.add(G.mul(G.lit(0.7), G.DEL(1, 23)), G.IN(2)))),
              "df2t": G.df2t}

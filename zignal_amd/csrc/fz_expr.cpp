@@ -412,8 +412,21 @@ fz_expr* fz_arith(fz_op op, fz_expr* a, fz_expr* b)
          e->in_arity = a->in_arity;
          return e;
       }
+      // the logical operators of C++ on arithmetic operands, spelled with comparisons (values identical; nothing to short-circuit):
+      //   !a = (a == 0)     a && b = (a != 0) * (b != 0)     a || b = ((a != 0) + (b != 0)) != 0
+      if (op == FZ_OP_NOT || op == FZ_OP_AND || op == FZ_OP_OR) {
+         if (op != FZ_OP_NOT && !b) fail(FZ_E_INVALID, "null operand");
+         struct Hold { fz_expr* e; ~Hold() { if (e) fz_expr_release(e); } };
+         auto check = [](fz_expr* e) { if (!e) throw Error{FZ_E_GRAPH, fz_last_error()}; return e; };
+         Hold zero{check(fz_literal(0.f))};
+         if (op == FZ_OP_NOT) return check(fz_arith(FZ_OP_EQ, a, zero.e));
+         Hold ta{check(fz_arith(FZ_OP_NE, a, zero.e))}, tb{check(fz_arith(FZ_OP_NE, b, zero.e))};
+         if (op == FZ_OP_AND) return check(fz_arith(FZ_OP_MUL, ta.e, tb.e));
+         Hold sum{check(fz_arith(FZ_OP_ADD, ta.e, tb.e))};
+         return check(fz_arith(FZ_OP_NE, sum.e, zero.e));
+      }
       if (!b) fail(FZ_E_INVALID, "null operand");
-      if (op < FZ_OP_ADD || op > FZ_OP_DIV) fail(FZ_E_INVALID, "unknown arithmetic operator");
+      if (!((op >= FZ_OP_ADD && op <= FZ_OP_DIV) || (op >= FZ_OP_LT && op <= FZ_OP_NE))) fail(FZ_E_INVALID, "unknown arithmetic operator");
       if (a->out_arity != 1 || b->out_arity != 1)
          fail(FZ_E_GRAPH, "arithmetic operand must have exactly one output wire");
       auto* e = mk(EK::Arith, a, b);

@@ -119,6 +119,10 @@ struct Elab {
          case EK::Modulator: return {add(FZ_IR_MOD, -1, -1, 0.f, e->i)};
          case EK::Arith: {                                              // _default<eval_it> :769-772
             int a = one(e->a, ins), b = one(e->b, ins);
+            if (e->op >= FZ_OP_LT && e->op <= FZ_OP_NE) {               // a comparison: 1.0f / 0.0f, a float whatever was compared
+               if (imag_of.count(a) || imag_of.count(b)) fail(FZ_E_GRAPH, "comparison operators do not apply to std::complex wires");
+               return {add(FZ_IR_LT + (uint32_t)(e->op - FZ_OP_LT), a, b)};
+            }
             uint32_t k = e->op == FZ_OP_ADD ? FZ_IR_ADD : e->op == FZ_OP_SUB ? FZ_IR_SUB
                        : e->op == FZ_OP_MUL ? FZ_IR_MUL : FZ_IR_DIV;
             if (imag_of.count(a) || imag_of.count(b)) return {complex_arith(k, a, b)};

@@ -43,7 +43,11 @@ static std::string board_id()
    return "dev" + std::to_string(dev);
 }
 
-static bool plan_cache_on() { return !std::getenv("FLOWZ_HIP_NO_PLAN_CACHE") && !std::getenv("FLOWZ_HIP_NO_CACHE"); }
+static bool plan_cache_on()
+{
+   const char* off = std::getenv("FLOWZ_HIP_NO_PLAN_CACHE");             // (set to anything but "" / "0": neither read nor written)
+   return !(off && *off && std::strcmp(off, "0") != 0) && !std::getenv("FLOWZ_HIP_NO_CACHE");
+}
 
 // One line per tune: "<format tag> <graph hash> <n_streams> <tile> <board> <P> <U> <block> <flags> <ms> <n_samples>".  The tag names
 // the layout of the line AND of the flag bits (they were re-assigned between rounds): lines with another tag are not ours to read.
@@ -140,6 +144,8 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
       const uint32_t Wp = g.split.K / 2;
       if (n_streams <= 65536 && n_streams % 256 == 0 && Wp >= 2 && Wp <= 4 && g.wave_roles(Wp)) cands.push_back(fz_variant{1, 16, 256, FZ_VF_WAVES(Wp)});
       cands.push_back(fz_variant{1, 24, 0, FZ_VF_STAGE_PACK});
+   } else if ((d.flags & FZ_VF_LOCKSTEP) && g.n_lds_slots) {   // LDS rings in step: against the free-running four-wave workgroups with 32-row chunks
+      cands.push_back(fz_variant{1, 32, 256, 0});
    } else if (d.flags & FZ_VF_LOCKSTEP) {                 // plain rows, many streams: the walk in lockstep against its neighbours in the geometry table
       const uint32_t G = d.flags & FZ_VF_GRID_SYNC;
       cands.push_back(fz_variant{std::min(d.P, 2u), 16, 256, 0});                                  // four-wave workgroups running free
@@ -160,8 +166,8 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
       cands.push_back(fz_variant{4, 8, 256, FZ_VF_MAX_WG(1)});
    } else {                                               // one stream per lane, free-running (wide frames on tiles, rings, short blocks)
       cands.push_back(fz_variant{1, d.U == 32 ? 16u : 32u, 0, 0});
-      if (n_streams >= (1u << 18) && (!tile_streams || tile_streams % 1024 == 0)) cands.push_back(fz_variant{1, 4, 1024, LG});
-      if (n_streams >= (1u << 17) && n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) cands.push_back(fz_variant{2, 16, 0, 0});
+      if (!g.n_lds_slots && n_streams >= (1u << 18) && (!tile_streams || tile_streams % 1024 == 0)) cands.push_back(fz_variant{1, 4, 1024, LG});
+      if (!g.n_lds_slots && n_streams >= (1u << 17) && n_streams % 2 == 0 && g.n_in <= 2 && g.n_out <= 2) cands.push_back(fz_variant{2, 16, 0, 0});
    }
    return cands;
 }
