@@ -244,7 +244,24 @@ FLOWZ_BINARY_OP(+, FZ_OP_ADD)
 FLOWZ_BINARY_OP(-, FZ_OP_SUB)
 FLOWZ_BINARY_OP(*, FZ_OP_MUL)
 FLOWZ_BINARY_OP(/, FZ_OP_DIV)
+// the comparison and logical operators: the bool C++ yields, as it behaves in arithmetic -- 1 or 0, taking the type of what it meets
+// (a result tuple or a delay line receives 1.0f / 0.0f).  && and || evaluate both sides (there is nothing to skip).
+FLOWZ_BINARY_OP(<, FZ_OP_LT)
+FLOWZ_BINARY_OP(<=, FZ_OP_LE)
+FLOWZ_BINARY_OP(>, FZ_OP_GT)
+FLOWZ_BINARY_OP(>=, FZ_OP_GE)
+FLOWZ_BINARY_OP(==, FZ_OP_EQ)
+FLOWZ_BINARY_OP(!=, FZ_OP_NE)
+FLOWZ_BINARY_OP(&&, FZ_OP_AND)
+FLOWZ_BINARY_OP(||, FZ_OP_OR)
 #undef FLOWZ_BINARY_OP
+
+template <int I, int O>
+expr<I, 1> operator!(const expr<I, O>& a)
+{
+   static_assert(O == 1, "flowz: an arithmetic operand must have exactly one output wire");
+   return expr<I, 1>(detail::handle(fz_arith(FZ_OP_NOT, a.h.get(), nullptr)), a.refs);
+}
 
 template <int I, int O>
 expr<I, 1> operator-(const expr<I, O>& a)

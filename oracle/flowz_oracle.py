@@ -61,6 +61,7 @@ Graph notation ("s-expressions", plain nested tuples; a shared data format, no c
                          (flowz/README.md:42-61: the reference re-reads it on every call); one value per sample, the same
                          for all streams: step(..., mod=[...]) / run(x, mod=[n_mod, T])
     ('add'|'sub'|'mul'|'div', a, b), ('neg', a)             flowz.hpp:769-772
+    ('lt'|'le'|'gt'|'ge'|'eq'|'ne'|'and'|'or', a, b), ('not', a)   the comparison / logical operators through the same _default: 1.0 / 0.0
     ('chan', a, b)       a , b                              flowz.hpp:90
     ('par', a, b)        a | b                              flowz.hpp:91
     ('seq', a, b)        a |= b                             flowz.hpp:92
@@ -73,6 +74,9 @@ import numpy as np
 F32 = np.float32
 
 _ARITH = ("add", "sub", "mul", "div")
+# comparison and logical operators of C++ (proto::_default applies whatever operator the node is, flowz.hpp:51-55, :769-772): the bool they
+# yield, as it behaves in arithmetic -- 1 or 0 taking the type of what it meets (here: a float32 1.0 / 0.0, which numpy promotes the same way)
+_CMP = ("lt", "le", "gt", "ge", "eq", "ne", "and", "or")
 
 
 class GraphError(ValueError):
@@ -95,9 +99,9 @@ def input_arity(e) -> int:
         return input_arity(e[1]) + input_arity(e[2])
     if k == "seq":                            # :199-208
         return input_arity(e[1]) + max(0, input_arity(e[2]) - output_arity(e[1]))
-    if k in _ARITH or k == "chan":            # :209-212  nary_expr -> max over children
+    if k in _ARITH or k in _CMP or k == "chan":   # :209-212  nary_expr -> max over children
         return max(input_arity(e[1]), input_arity(e[2]))
-    if k == "neg":
+    if k in ("neg", "not"):
         return input_arity(e[1])
     raise GraphError(f"unknown node {k!r}")
 
@@ -139,9 +143,9 @@ def max_input_delays(e) -> tuple:
         return max_input_delays(e[1]) + max_input_delays(e[2])
     if k == "seq":                            # :483-492
         return max_input_delays(e[1]) + max_input_delays(e[2])[output_arity(e[1]):]
-    if k == "neg":
+    if k in ("neg", "not"):
         return max_input_delays(e[1])
-    if k in _ARITH or k == "chan":            # :493-496 fold with max-zip
+    if k in _ARITH or k in _CMP or k == "chan":   # :493-496 fold with max-zip
         return zipmax(max_input_delays(e[2]), max_input_delays(e[1]))
     raise GraphError(f"unknown node {k!r}")
 
@@ -445,6 +449,20 @@ class FlowzOracle:
         if k == "neg":
             a = self._one(e[1], ins)
             return [self._new(lambda a=a: -self._value(a))]
+        if k in _CMP or k == "not":                             # the same _default<eval_it>: C++'s operator on the operands' common type, a bool
+            a = self._one(e[1], ins)
+            b = self._one(e[2], ins) if k != "not" else None
+
+            def truth(k=k, a=a, b=b):
+                x = self._value(a)
+                y = self._value(b) if b is not None else None
+                if isinstance(x, _Cplx) or isinstance(y, _Cplx):
+                    raise GraphError("comparison operators do not apply to std::complex wires")
+                with np.errstate(invalid="ignore"):
+                    m = {"lt": lambda: x < y, "le": lambda: x <= y, "gt": lambda: x > y, "ge": lambda: x >= y, "eq": lambda: x == y, "ne": lambda: x != y,
+                         "and": lambda: (x != 0) & (y != 0), "or": lambda: (x != 0) | (y != 0), "not": lambda: x == 0}[k]()
+                return np.where(m, F32(1), F32(0)).astype(F32)
+            return [self._new(truth)]
         if k == "chan":                                         # :765-768 same inputs to both
             return self._elab(e[1], ins) + self._elab(e[2], ins)
         if k == "par":                                          # :1087-1099 split at in(a)

@@ -63,6 +63,20 @@ int main()
          CHECK(std::make_tuple(want[k]) == i3(xs[k]));
       }
    }
+   {  // comparison and logical operators through the same call protocol: a hard clipper spelled with them
+      auto clip = compile(_1 * ((_1 > -0.5f) && (_1 < 0.5f)) + 0.5f * (_1 >= 0.5f) + -0.5f * (_1 <= -0.5f));
+      CHECK(std::make_tuple(0.25f) == clip(0.25f));
+      CHECK(std::make_tuple(0.5f) == clip(3.f));
+      CHECK(std::make_tuple(-0.5f) == clip(-0.5f));
+      CHECK(std::make_tuple(-0.5f) == clip(-7.f));
+      auto less = compile(_1 < _2);
+      CHECK(std::make_tuple(1.f) == less(1.f, 2.f));
+      CHECK(std::make_tuple(0.f) == less(2.f, 2.f));
+      auto either = compile(!(_1 == _2) || (_1 > 10.f));
+      CHECK(std::make_tuple(0.f) == either(3.f, 3.f));
+      CHECK(std::make_tuple(1.f) == either(3.f, 4.f));
+      CHECK(std::make_tuple(1.f) == either(11.f, 11.f));
+   }
    {  // README integrator, flowz/README.md:33-37
       auto integrator = compile(~(_1[_1] + _2));
       const int want[4] = {1, 3, 6, 10};

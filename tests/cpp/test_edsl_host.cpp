@@ -55,6 +55,18 @@ int main()
    auto one_pole = compile(~(std::ref(a) * _1[_1] + 0.1 * _2));
    CHECK(one_pole.info().n_const == 1 && one_pole.info().n_const64 == 1);   // 0.1 is a double literal
 
+   {  // comparison and logical operators: proto::_default applies whatever C++ operator a node is (flowz.hpp:51-55, :769-772)
+      auto clip = compile(_1 * ((_1 > -0.5f) && (_1 < 0.5f)) + 0.5f * (_1 >= 0.5f) + -0.5f * (_1 <= -0.5f));
+      static_assert(decltype(clip)::ins == 1 && decltype(clip)::outs == 1, "");
+      CHECK(clip.info().n_ops == 12 && clip.info().stage_packable == 0);
+      CHECK(compile(!_1).info().n_ops == 1);
+      auto pick = compile((_1 == _2) || (_1 != 1.0));
+      static_assert(decltype(pick)::ins == 2 && decltype(pick)::outs == 1, "");
+      CHECK(pick.info().n_const64 == 1);                                                       // compared in double, the result a float
+      CHECK(compile_typed((_1 < 1.0) * _1).output_dtypes() == std::vector<uint32_t>{FZ_DT_F32});   // bool * float: a float multiplication
+      CHECK(compile_typed((_1 < 1.0) * 2.0).output_dtypes() == std::vector<uint32_t>{FZ_DT_F64});  // bool * double: a double one
+   }
+
    // malformed graphs throw at compile() instead of failing template instantiation
    bool threw = false;
    try { compile(~(_1 + _2)); } catch (const flowz::error& e) { threw = e.code == FZ_E_GRAPH; }

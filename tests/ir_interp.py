@@ -76,6 +76,9 @@ def run_ir(prog, x, params=None, state=None, mod=None):
                     v[i] = v[a] / v[b]
                 elif kind == "neg":
                     v[i] = -v[a]
+                elif kind in ("lt", "le", "gt", "ge", "eq", "ne"):      # a float 1.0 / 0.0; operands compared in their common type
+                    m = {"lt": np.less, "le": np.less_equal, "gt": np.greater, "ge": np.greater_equal, "eq": np.equal, "ne": np.not_equal}[kind](v[a], v[b])
+                    v[i] = np.where(m, F32(1), F32(0)).astype(F32)
                 elif kind == "abslt":
                     v[i] = (np.abs(v[a]) < np.abs(v[b])).astype(v[a].dtype)
                 elif kind == "select":

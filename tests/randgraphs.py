@@ -130,3 +130,30 @@ def make_typed(seed, max_in=3, depth=3):
             post = ("div", mul(lit(0.5), IN(1)), add(("litc", float(rng.uniform(2, 3)), float(rng.uniform(-1, 1))), mul(lit(0.01), post)))
         return seq(g, post), n_in, n_out, "complex"
     return _retype(rng, g, 0.35), n_in, n_out, "double"
+
+
+def _gate(rng, e, p):
+    """sprinkle comparison / logical operators over arithmetic nodes: (a op b) becomes (a op b) * (a cmp b), (a op b) + c * ((a cmp x) && / || (b cmp y))
+    or (a op b) * !(a cmp b) -- the operands of the node itself are compared, so arities and delays stay what they were"""
+    if not isinstance(e, tuple):
+        return e
+    e = tuple(_gate(rng, c, p) if isinstance(c, tuple) else c for c in e)
+    if e[0] in ("add", "sub", "mul") and rng.random() < p:
+        a, b = e[1], e[2]
+        cmp_ = lambda x, y: (str(rng.choice(["lt", "le", "gt", "ge", "eq", "ne"])), x, y)   # noqa: E731
+        th = lambda: lit(float(rng.uniform(-0.3, 0.3)))                                   # noqa: E731
+        r = rng.random()
+        if r < 0.4:
+            return ("mul", e, cmp_(a, b))
+        if r < 0.7:
+            return ("add", e, ("mul", lit(float(rng.uniform(-0.1, 0.1))), (str(rng.choice(["and", "or"])), cmp_(a, th()), cmp_(b, th()))))
+        if r < 0.85:
+            return ("mul", e, ("not", cmp_(a, b)))
+        return ("sub", e, ("mul", lit(0.05), cmp_(("mul", ("lit64", 1.0), a), b)))             # compared in double
+    return e
+
+
+def make_cmp(seed, max_in=3, depth=3, p=0.35):
+    """as make(), with C++ comparison and logical operators among the arithmetic (round 6: proto::_default applies whatever operator a node is)"""
+    g, n_in, n_out = make(seed, max_in, depth)
+    return _gate(np.random.default_rng(seed + 55000), g, p), n_in, n_out

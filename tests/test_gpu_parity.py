@@ -1596,6 +1596,71 @@ def test_lds_rings_take_the_row_walk_in_lockstep_on_plain_rows(torch_cuda, F):
     assert ndiff(got, want) == 0
 
 
+def _cmp_graphs():
+    return {"hard_clipper": G.hard_clipper(), "clipped_biquad": G.clipped_biquad(),
+            "clipped_biquad_cascade": G.seq(G.clipped_biquad(), G.clipped_biquad(-0.25, 0.4), G.df1()),
+            "logic": ("chan", ("chan", ("not", G.IN(1)), ("or", G.IN(1), G.lit(0.0))), ("mul", ("lit64", 2.0), ("lt", G.IN(1), ("lit64", 0.25)))),
+            "compare_in_double": G.mul(("ge", G.mul(("lit64", 1.0000000001), G.IN(1)), G.IN(1)), G.IN(1)),
+            "gated_feedback": G.fb(G.add(G.mul(G.mul(G.lit(0.9), G.DEL(1, 1)), ("lt", G.DEL(1, 1), G.lit(0.8))), G.IN(2))),
+            "two_wire_select": G.add(G.mul(G.IN(1), ("gt", G.IN(1), G.IN(2))), G.mul(G.IN(2), ("le", G.IN(1), G.IN(2))))}
+
+
+def _edge_input(seed, ns, T, n_wires=1):
+    """noise with the values comparisons are sensitive to: +-0, the thresholds themselves, NaN, +-inf, denormals"""
+    x = O.synth_input(seed, np.arange(ns), T, n_wires=n_wires)
+    special = np.array([0.0, -0.0, 0.5, -0.5, 0.8, 0.25, np.nan, np.inf, -np.inf, 1e-40, -1e-40, np.float32(0.5) - np.float32(2 ** -25)], np.float32)
+    rng = np.random.default_rng(seed)
+    k = rng.integers(0, T, 16 * len(special)), rng.integers(0, ns, 16 * len(special)), rng.integers(0, n_wires, 16 * len(special))
+    x[k] = np.tile(special, 16)
+    return x
+
+
+@pytest.mark.parametrize("name", sorted(_cmp_graphs()))
+def test_comparison_and_logical_operators_on_gpu(torch_cuda, F, name):
+    """SURVEY 8 row a4, widened in round 6: the comparison and logical operators of C++ in a flow-graph (a hard clipper and a biquad whose recursion
+    runs through it, spelled with < <= > >= && only; !, ||, ==-style gating; a comparison decided in double).  Every lane packing, chained blocks,
+    stream-major buffers, stream tiles -- against the oracle on inputs that hold +-0, the thresholds, NaN, +-inf and denormals; NaNs of any payload equal."""
+    torch = torch_cuda
+    g = _cmp_graphs()[name]
+    prog = F.compile(F.from_sexpr(g))
+    ns, T = 520, 132
+    x = _edge_input(SEED + 77, ns, T, n_wires=max(prog.n_in, 1))
+    with np.errstate(all="ignore"):
+        want = O.compile(g, ns).run(x)
+    xd = torch.from_numpy(x).cuda()
+    for P in (1, 2, 4):
+        y, st = prog.run_block(xd, variant=F.make_variant(P, 8))
+        assert ndiff_nan_aware(y.cpu().numpy(), want) == 0, P
+    ya, sta = prog.run_block(xd[:51].contiguous())
+    yb, stb = prog.run_block(xd[51:].contiguous(), state=sta)
+    assert ndiff_nan_aware(torch.cat([ya, yb]).cpu().numpy(), want) == 0
+    ys, _ = prog.run_block_stream_major(xd.permute(1, 0, 2).contiguous())
+    assert ndiff_nan_aware(ys.permute(1, 0, 2).contiguous().cpu().numpy(), want) == 0
+    yt, _ = prog.run_block(F.to_tiled(xd[:, :512].contiguous(), 128))
+    assert ndiff_nan_aware(F.from_tiled(yt).cpu().numpy(), want[:, :512]) == 0
+
+
+def test_clipped_biquad_at_scale_in_lockstep(torch_cuda, F):
+    """the clipped biquad on 300 000 streams x 1100 samples of plain time-major rows: the library's default there is the CU-wide lockstep walk
+    (graphs with comparisons are not stage-packed: lanes are packed instead); sampled streams against the oracle, everything against another variant"""
+    torch = torch_cuda
+    g = G.clipped_biquad()
+    prog = F.compile(F.from_sexpr(g))
+    ns, T = 300_000, 1100
+    assert "b1024f" in prog.kernel_name(None, ns, T) and prog.stage_packable == 0
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED + 78)
+    x.mul_(2.0)                                                   # (into the clipper)
+    y, st = prog.run_block(x)
+    r, sr = prog.run_block(x, variant=F.make_variant(1, 8))
+    assert torch.equal(y, r) and torch.equal(st, sr)
+    ids = np.concatenate([np.arange(4), np.random.default_rng(6).integers(0, ns, 120), np.arange(ns - 4, ns)])
+    xi = (O.synth_input(SEED + 78, ids, T) * np.float32(2.0)).astype(np.float32)
+    want = O.compile(g, len(ids)).run(xi)
+    assert ndiff(y[:, torch.as_tensor(ids, device="cuda")].cpu().numpy(), want) == 0
+    assert float(np.abs(want).max()) <= 0.5 and float((np.abs(want) == 0.5).mean()) > 0.01   # the clipper is at work
+
+
 SM_GRAPHS = {"cascade6": lambda: G.df1_cascade(6), "par4": G.par4_sum, "cross_wire": G.cross_wire, "integrator": G.integrator,
              "lds_ring": lambda: G.seq(G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 40))), G.fb(G.add(G.mul(G.lit(0.7), G.DEL(1, 23)), G.IN(2)))),
              "df2t": G.df2t}

@@ -166,6 +166,76 @@ def test_reserved_variant_flag_bits_are_refused():
     assert "FZ_VF_SLP" not in hdr and "FZ_VF_NO_NT" not in hdr and "FZ_VF_NO_XCD_REMAP" not in hdr
 
 
+CMP_GRAPHS = {
+    "hard_clipper": G.hard_clipper,
+    "clipped_biquad": G.clipped_biquad,
+    "clipped_biquad_cascade": lambda: G.seq(G.clipped_biquad(), G.clipped_biquad(-0.25, 0.4), G.df1()),
+    "logic": lambda: ("chan", ("chan", ("not", G.IN(1)), ("or", G.IN(1), G.lit(0.0))), ("mul", ("lit64", 2.0), ("lt", G.IN(1), ("lit64", 0.25)))),
+    "compare_in_double": lambda: G.mul(("ge", G.mul(("lit64", 1.0000000001), G.IN(1)), G.IN(1)), G.IN(1)),     # x * 1.0000000001 >= x decided in double
+    "gated_feedback": lambda: G.fb(G.add(G.mul(G.mul(G.lit(0.9), G.DEL(1, 1)), ("lt", G.DEL(1, 1), G.lit(0.8))), G.IN(2))),   # an integrator that drops its state above 0.8
+    "two_wire_select": lambda: G.add(G.mul(G.IN(1), ("gt", G.IN(1), G.IN(2))), G.mul(G.IN(2), ("le", G.IN(1), G.IN(2)))),          # max(_1, _2), as C++ spells it without <algorithm>
+}
+
+
+def edge_input(seed, ns, T, n_wires=1):
+    """noise with the values comparisons are sensitive to: +-0, the thresholds themselves, NaN, +-inf, denormals"""
+    x = O.synth_input(seed, np.arange(ns), T, n_wires=n_wires)
+    special = np.array([0.0, -0.0, 0.5, -0.5, 0.8, 0.25, np.nan, np.inf, -np.inf, 1e-40, -1e-40, np.float32(0.5) - np.float32(2 ** -25)], np.float32)
+    rng = np.random.default_rng(seed)
+    k = rng.integers(0, T, 4 * len(special)), rng.integers(0, ns, 4 * len(special)), rng.integers(0, n_wires, 4 * len(special))
+    x[k] = np.tile(special, 4)
+    return x
+
+
+@pytest.mark.parametrize("name", sorted(CMP_GRAPHS))
+def test_comparison_and_logical_operators_lower_like_the_oracle(name):
+    """SURVEY 8 row a4, widened in round 6: proto::_default applies whatever C++ operator a node is (flowz.hpp:51-55, :769-772), so < <= > >= == != !
+    && || are legal in a flow-graph.  They yield the operator's bool as it behaves in arithmetic: 1 or 0, a float until it meets a double;
+    operands are compared in their common type; IEEE rules for NaN.  Lowering == oracle on inputs with +-0, the thresholds, NaN, +-inf, denormals."""
+    g = CMP_GRAPHS[name]()
+    p = F.compile(F.from_sexpr(g))
+    assert (p.n_in, p.n_out) == (O.input_arity(g), O.output_arity(g)) and not p.stage_packable
+    ns, T = 5, 120
+    x = edge_input(31, ns, T, n_wires=max(p.n_in, 1))
+    with np.errstate(all="ignore"):
+        want = O.compile(g, ns).run(x)
+        got, _ = run_ir(p, x)
+    nan = np.isnan(got) & np.isnan(want)
+    assert np.array_equal(np.where(nan, 0, got).view(np.uint32), np.where(nan, 0, want).view(np.uint32))
+    assert all(d == "f32" for d, (k, *_r) in zip(p.ir_dtypes(), p.ir()) if k in ("lt", "le", "gt", "ge", "eq", "ne"))
+    # the recipe of a kernel manifest carries the new operators
+    lib = _capi.lib
+    buf = ctypes.create_string_buffer(1 << 16)
+    e1 = F.from_sexpr(g)                                         # (kept alive across the call: the handle is the object's)
+    n = lib.fz_expr_recipe(e1._h, buf, len(buf))
+    e2 = F.Expr(lib.fz_expr_from_recipe(buf.raw[:n]))
+    assert F.compile(e2).ir() == p.ir()
+
+
+def test_comparison_operators_python_spelling_typing_and_isa(tmp_path, monkeypatch):
+    monkeypatch.setenv("FLOWZ_HIP_CACHE", str(tmp_path))
+    x = F._1
+    a = F.compile(x * ((x > -0.5).logical_and(x < 0.5)) + 0.5 * (x >= 0.5) + -0.5 * (x <= -0.5))
+    assert a.ir() == F.compile(F.from_sexpr(G.hard_clipper())).ir() and a.n_ops == 12
+    assert F.compile(x.eq(F._2).logical_or(x.ne(1.0)).logical_not()).n_in == 2
+    # the bool takes the type of what it meets: a float multiplication, a double one
+    assert F.compile((x < F.lit64(1.0)) * x, typed=True).output_dtypes() == ["f32"]
+    assert F.compile((x < 1.0) * F.lit64(2.0), typed=True).output_dtypes() == ["f64"]
+    with pytest.raises(F.FlowzError) as ei:
+        F.compile(F.litc(1.0, 0.0) * x < x)                       # std::complex has no ordering
+    assert ei.value.code == _capi.FZ_E_GRAPH
+    # the kernel: compares and selects, and still no contraction anywhere
+    import subprocess
+    for P in (1, 2, 4):
+        F.compile(F.from_sexpr(G.clipped_biquad())).build(F.make_variant(P, 8))
+    objs = list(tmp_path.glob("*.hsaco"))
+    assert len(objs) == 3
+    for obj in objs:
+        dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", str(obj)], text=True)
+        assert "v_cmp_" in dis and "v_cndmask" in dis
+        assert not re.search(r"v_(pk_)?(fma|fmac|mad|mac)(_mix|_mixlo|_mixhi|_legacy)?_(f16|f32|f64|bf16)", dis)
+
+
 def test_lowering_osc_chain_with_stream_params():
     g = G.osc_chain(6)
     p = F.compile(F.from_sexpr(g))

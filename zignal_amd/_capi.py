@@ -25,6 +25,7 @@ class NoDeviceError(FlowzError):
 FZ_OK, FZ_E_INVALID, FZ_E_GRAPH, FZ_E_NO_DEVICE, FZ_E_HIP, FZ_E_COMPILE, FZ_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 FZ_OP_ADD, FZ_OP_SUB, FZ_OP_MUL, FZ_OP_DIV, FZ_OP_NEG = 1, 2, 3, 4, 5
 FZ_VF_STAGE_PACK, FZ_VF_NO_STAGE_PACK, FZ_VF_OUT_F64 = 8, 16, 64
+FZ_OP_LT, FZ_OP_LE, FZ_OP_GT, FZ_OP_GE, FZ_OP_EQ, FZ_OP_NE, FZ_OP_NOT, FZ_OP_AND, FZ_OP_OR = 6, 7, 8, 9, 10, 11, 12, 13, 14
 FZ_VF_PREFETCH3 = 32
 FZ_VF_STREAM_MAJOR = 128
 FZ_VF_SM_LONG, FZ_VF_SM_SHORT, FZ_VF_WAVE_SPLIT, FZ_VF_IO_WAVE = 256, 512, 1024, 32768
@@ -41,7 +42,7 @@ def FZ_VF_WAVES(n):
 def FZ_VF_MAX_WG(n):
     """at most n workgroups per CU (flags bits 20..22)"""
     return (int(n) & 7) << 20
-IR_KINDS = {1: "input", 2: "const", 3: "param", 4: "delay", 5: "add", 6: "sub", 7: "mul", 8: "div", 9: "neg", 10: "widen", 11: "narrow", 12: "mod", 13: "abslt", 14: "select"}
+IR_KINDS = {1: "input", 2: "const", 3: "param", 4: "delay", 5: "add", 6: "sub", 7: "mul", 8: "div", 9: "neg", 10: "widen", 11: "narrow", 12: "mod", 13: "abslt", 14: "select", 15: "lt", 16: "le", 17: "gt", 18: "ge", 19: "eq", 20: "ne"}
 FZ_DT_F32, FZ_DT_F64, FZ_DT_CF32, FZ_DT_CF64 = 0, 1, 2, 3
 DTYPES = {"f32": 0, "f64": 1, "cf32": 2, "cf64": 3}
 

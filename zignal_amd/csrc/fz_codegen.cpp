@@ -217,6 +217,21 @@ std::string gen_body(const Graph& g, const Variant& v)
    // literal values share one code object and one kernel-cache entry)
    o << "__device__ __forceinline__ V fz_div(V a, V b) { return a / b; }\n";
    o << "__device__ __forceinline__ VD fz_div(VD a, VD b) { return a / b; }\n";
+   bool has_cmp = false;
+   for (const Node& nd : g.nodes) has_cmp = has_cmp || (nd.kind >= FZ_IR_LT && nd.kind <= FZ_IR_NE);
+   if (has_cmp) {
+      // the comparison operators of C++ on the streams of a lane: 1.0f / 0.0f (IEEE: every comparison with a NaN is false, != true); operands in
+      // their common type.  Part of the GRAPH's text: kernels of graphs without comparisons keep their code.
+      o << "template <int K, typename T> __device__ __forceinline__ bool fz_cmp1(T a, T b) { return K == " << FZ_IR_LT << " ? a < b : K == " << FZ_IR_LE
+        << " ? a <= b : K == " << FZ_IR_GT << " ? a > b : K == " << FZ_IR_GE << " ? a >= b : K == " << FZ_IR_EQ << " ? a == b : a != b; }\n";
+      o << "#if FZ_P == 1\n";
+      o << "template <int K> __device__ __forceinline__ V fz_cmp(V a, V b) { return fz_cmp1<K>(a, b) ? 1.f : 0.f; }\n";
+      o << "template <int K> __device__ __forceinline__ V fz_cmp(VD a, VD b) { return fz_cmp1<K>(a, b) ? 1.f : 0.f; }\n";
+      o << "#else\n";
+      for (const char* T : {"V", "VD"})
+         o << "template <int K> __device__ __forceinline__ V fz_cmp(" << T << " a, " << T << " b)\n{\n   V r;\n#pragma unroll\n   for (int j = 0; j < FZ_P; ++j) r[j] = fz_cmp1<K>(a[j], b[j]) ? 1.f : 0.f;\n   return r;\n}\n";
+      o << "#endif\n";
+   }
    // operand `id` as seen by a node of type f64/f32 (C++ usual arithmetic conversions: float -> double is exact)
    auto opnd = [&](uint32_t id, bool want64) {
       return (want64 && !g.nodes[id].f64) ? "fz_cvt_d(" + val(id) + ")" : val(id);
@@ -440,6 +455,11 @@ std::string gen_body(const Graph& g, const Variant& v)
          case FZ_IR_MUL: o << opnd(nd.a, d) << " * " << opnd(nd.b, d); break;
          case FZ_IR_DIV: o << "fz_div(" << opnd(nd.a, d) << ", " << opnd(nd.b, d) << ")"; break;
          case FZ_IR_NEG: o << "-" << val(nd.a); break;
+         case FZ_IR_LT: case FZ_IR_LE: case FZ_IR_GT: case FZ_IR_GE: case FZ_IR_EQ: case FZ_IR_NE: {
+            const bool dd = g.nodes[nd.a].f64 || g.nodes[nd.b].f64;   // compared in double when one operand is; the node itself is a float
+            o << "fz_cmp<" << nd.kind << ">(" << opnd(nd.a, dd) << ", " << opnd(nd.b, dd) << ")";
+            break;
+         }
          case FZ_IR_ABSLT: o << "fz_abs_lt(" << opnd(nd.a, d) << ", " << opnd(nd.b, d) << ")"; break;
          case FZ_IR_SELECT: o << "fz_select(" << val(nd.a) << ", " << opnd(nd.b, d) << ", " << opnd(nd.c, d) << ")"; break;
          case FZ_IR_WIDEN: o << "fz_cvt_d(" << val(nd.a) << ")"; break;

@@ -97,7 +97,8 @@ StageSplit find_stage_split(const Graph& g, bool plain, uint32_t divisor, uint32
    StageSplit none;
    if (g.n_in != 1 || g.n_out != 1 || g.n_lds_slots != 0 || !g.far_lines.empty() || g.n_ops < 2) return none;
    for (const Node& n : g.nodes)
-      if (n.f64 || n.kind == FZ_IR_MOD) return none;       // packed halves are float32 pairs; a modulator has ONE value per time step
+      // packed halves are float32 pairs; a modulator has ONE value per time step; comparisons / selections have no packed instruction to share
+      if (n.f64 || n.kind == FZ_IR_MOD || n.kind >= FZ_IR_ABSLT) return none;
    const uint32_t N = (uint32_t)g.nodes.size();
    uint32_t in = N;
    for (uint32_t i = 0; i < N; ++i)

@@ -75,6 +75,18 @@ class Expr:
     def __rtruediv__(self, o): return self._ar(C.FZ_OP_DIV, o, True)
     def __neg__(self): return Expr(C.lib.fz_arith(C.FZ_OP_NEG, self._h, None))
 
+    # -- comparison and logical operators (proto::_default applies whatever C++ operator a node is, flowz.hpp:769-772): 1.0 / 0.0 -----------
+    # (== and != are the methods eq / ne: Python needs __eq__ for its own purposes; `and` / `or` / `not` cannot be overloaded at all)
+    def __lt__(self, o): return self._ar(C.FZ_OP_LT, o)
+    def __le__(self, o): return self._ar(C.FZ_OP_LE, o)
+    def __gt__(self, o): return self._ar(C.FZ_OP_GT, o)
+    def __ge__(self, o): return self._ar(C.FZ_OP_GE, o)
+    def eq(self, o): return self._ar(C.FZ_OP_EQ, o)
+    def ne(self, o): return self._ar(C.FZ_OP_NE, o)
+    def logical_and(self, o): return self._ar(C.FZ_OP_AND, o)
+    def logical_or(self, o): return self._ar(C.FZ_OP_OR, o)
+    def logical_not(self): return Expr(C.lib.fz_arith(C.FZ_OP_NOT, self._h, None))
+
     # -- combinators -----------------------------------------------------------------------
     def __or__(self, o): return Expr(C.lib.fz_parallel(self._h, as_expr(o)._h))
     def __ror__(self, o): return Expr(C.lib.fz_parallel(as_expr(o)._h, self._h))
@@ -175,6 +187,9 @@ def seq(*xs) -> Expr:
     return r
 
 
+_CMP_OPS = {"lt": C.FZ_OP_LT, "le": C.FZ_OP_LE, "gt": C.FZ_OP_GT, "ge": C.FZ_OP_GE, "eq": C.FZ_OP_EQ, "ne": C.FZ_OP_NE, "and": C.FZ_OP_AND, "or": C.FZ_OP_OR}
+
+
 def from_sexpr(e) -> Expr:
     """Build from the neutral s-expression notation shared with the test-suite."""
     k = e[0]
@@ -188,12 +203,14 @@ def from_sexpr(e) -> Expr:
     if k == "mod": return modulator(e[1])
     if k == "uniform": return uniform(e[1], e[2])
     if k == "neg": return -from_sexpr(e[1])
+    if k == "not": return from_sexpr(e[1]).logical_not()
     if k == "fb": return ~from_sexpr(e[1])
     a, b = from_sexpr(e[1]), from_sexpr(e[2])
     if k == "add": return a + b
     if k == "sub": return a - b
     if k == "mul": return a * b
     if k == "div": return a / b
+    if k in _CMP_OPS: return a._ar(_CMP_OPS[k], b)
     if k == "chan": return chan(a, b)
     if k == "par": return a | b
     if k == "seq": return a >> b

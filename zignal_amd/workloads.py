@@ -38,6 +38,25 @@ def mul(a, b):
     return ("mul", a, b)
 
 
+def cmp(op, a, b):
+    """('lt'|'le'|'gt'|'ge'|'eq'|'ne'|'and'|'or', a, b): the C++ comparison / logical operators, 1.0 or 0.0"""
+    return (op, a, b)
+
+
+def hard_clipper(lo=-0.5, hi=0.5):
+    """x limited to [lo, hi] with comparison operators only, as a C++ user of the reference would spell it without <algorithm>:
+    x * ((x > lo) && (x < hi)) + hi * (x >= hi) + lo * (x <= lo)"""
+    x = IN(1)
+    return add(add(mul(x, cmp("and", cmp("gt", x, lit(lo)), cmp("lt", x, lit(hi)))), mul(lit(hi), cmp("ge", x, lit(hi)))), mul(lit(lo), cmp("le", x, lit(lo))))
+
+
+def clipped_biquad(lo=-0.5, hi=0.5):
+    """a DF1 biquad whose recursion runs through the hard clipper: fwd |= ~( clip( a1 _1[_1] + a2 _1[_2] + _2 ) )"""
+    clip_of = lambda e: add(add(mul(e, cmp("and", cmp("gt", e, lit(lo)), cmp("lt", e, lit(hi)))), mul(lit(hi), cmp("ge", e, lit(hi)))), mul(lit(lo), cmp("le", e, lit(lo))))   # noqa: E731
+    rec = add(add(mul(DEL(1, 1), lit(STABLE[3])), mul(DEL(1, 2), lit(STABLE[4]))), IN(2))
+    return seq(fwd(*STABLE[:3]), fb(clip_of(rec)))
+
+
 def seq(*xs):
     """a |= b |= c ... ; C++ `|=` is right-associative: a |= (b |= c)."""
     r = xs[-1]
