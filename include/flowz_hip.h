@@ -249,7 +249,7 @@ enum { FZ_VF_STAGE_PACK = 8u,   /* one stream per lane; the K isomorphic segment
                                    blocks of >= 256 samples; FZ_VF_SM_SHORT keeps the 32-sample chunks.  With streams_per_lane = 2
                                    (unroll 64): the PAIR body -- two streams per lane, every node one packed instruction, halves of
                                    64 samples, 256-byte in-runs and 512-byte out-runs; the default for deep graphs with uniform
-                                   coefficients from 2^19 (even) streams on, from 2^17 on where its workgroups fill the chip     */
+                                   coefficients from 2^19 (even) streams on                                              */
        FZ_VF_SM_SHORT = 512u,
        FZ_VF_WAVE_SPLIT = 1024u, /* fewer streams than lanes: a serial graph of K isomorphic segments is cut into W parts of K / W
                                    segments, W waves of a workgroup evaluate the parts for the same 64 streams (the cut wires

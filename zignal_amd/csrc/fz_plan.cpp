@@ -198,12 +198,9 @@ static Variant resolve_stream_major(const Graph& g, const Request& rq, Variant v
    if (!g.far_lines.empty()) fail(FZ_E_UNSUPPORTED, "stream-major frames: delay lines beyond 256 samples are not supported");
    if (v.flags & (FZ_VF_OUT_F64 | FZ_VF_PREFETCH3)) fail(FZ_E_UNSUPPORTED, "stream-major frames: float32 frames, double buffering only");
    v.P = rq.P ? rq.P : 1u;
-   // the pair body when its 512-stream workgroups fill the chip's rounds as well as the one-stream body's 256-stream ones do
-   auto fill = [](uint64_t ns, uint64_t per_wg) {
-      const uint64_t cus = chip_cus(), wg = (ns + per_wg - 1) / per_wg, rounds = (wg + cus - 1) / cus;
-      return (double)wg / (double)(rounds * cus);
-   };
-   const bool enough = n_streams >= (1u << 19) || (n_streams >= (1u << 17) && fill(n_streams, 512) >= fill(n_streams, 256) - 0.02);
+   // the pair body from 2^19 streams on.  (Rounds 3-5 also took it from 2^17 on where its workgroups filled the chip's rounds; at 262 144 streams the
+   //  one-stream body was level or ahead on every bench line since -- +1 ... +5 %, never behind: profiles/NOTES.md "Round 6")
+   const bool enough = n_streams >= (1u << 19);
    if (!uv_has_shape(uv) && g.n_in == 1 && g.n_out == 1 && g.n_lds_slots == 0 && g.far_lines.empty() && g.n_param <= 32 && g.n_mod == 0 &&
        !g.typed && g.n_ops > 27 && g.n_state <= 20 && enough && n_streams % 2 == 0 && n_samples >= 256) {
       v.P = 2;
