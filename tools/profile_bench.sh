@@ -1,11 +1,11 @@
 #!/usr/bin/env bash
 # GPU box: the rocprofv3 evidence of the bench line (round 5: the counter tables are keyed by the kernels' CODE ids).
 #   usage: gpurun -- "FZ_COMMIT=$(git rev-parse --short HEAD) tools/profile_bench.sh <name>"   -> gpurun_out/<name>/...
-#   then here: tools/merge_profile.py gpurun_out/<name> profiles/r05      (refreshes profiles/pmc_traffic.json, sq_issue_share.json)
+#   then here: tools/merge_profile.py gpurun_out/<name> profiles/r06      (refreshes profiles/pmc_traffic.json, sq_issue_share.json)
 # 1. the DEFAULT bench command plain, then under --kernel-trace --stats (what the driver runs);
 # 2. per workload x layout of the line (bench.py --only <spec>:<layout>[:tile], the library's static choice): separate --pmc passes --
 #    never combined with tracing -- of FETCH_SIZE, WRITE_SIZE (HBM traffic) and of the SQ counters (issue share, real clock).
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-prof_r05}; mkdir -p $O; echo "${FZ_COMMIT:-unknown}" > $O/commit.txt; cd /tmp; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-prof_r06}; mkdir -p $O; echo "${FZ_COMMIT:-unknown}" > $O/commit.txt; cd /tmp; export TMPDIR=/tmp
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 if [ -z "${PASSES_ONLY:-}" ]; then
 BENCH_DETAILS=$O/bench_details_plain.json python $R/bench.py > $O/bench_plain.json 2> $O/bench_plain.err
