@@ -218,6 +218,8 @@ def test_comparison_operators_python_spelling_typing_and_isa(tmp_path, monkeypat
     a = F.compile(x * ((x > -0.5).logical_and(x < 0.5)) + 0.5 * (x >= 0.5) + -0.5 * (x <= -0.5))
     assert a.ir() == F.compile(F.from_sexpr(G.hard_clipper())).ir() and a.n_ops == 12
     assert F.compile(x.eq(F._2).logical_or(x.ne(1.0)).logical_not()).n_in == 2
+    with pytest.raises(TypeError):
+        max(x, F._2)                                              # a comparison is a graph node, not a Python truth value
     # the bool takes the type of what it meets: a float multiplication, a double one
     assert F.compile((x < F.lit64(1.0)) * x, typed=True).output_dtypes() == ["f32"]
     assert F.compile((x < 1.0) * F.lit64(2.0), typed=True).output_dtypes() == ["f64"]

@@ -44,7 +44,7 @@ for seed in range(first, first + count):
     if (seed - first) % 50 == 0:
         print(f"... seed {seed}: {ok} identical, {bad} mismatching, {skipped} skipped so far ({time.time() - t_start:.0f} s)", flush=True)
     for typed in (False, True):
-        g, n_in = (R.make_typed(seed)[:2] if typed else R.make(seed)[:2])
+        g, n_in = (R.make_typed(seed)[:2] if typed else (R.make_cmp(seed)[:2] if os.environ.get("FUZZ_CMP") else R.make(seed)[:2]))   # FUZZ_CMP=1: comparison / logical operators among the arithmetic (round 6)
         trace("seed", seed, "typed" if typed else "plain", g)
         try:
             f = O.compile(g, ns)

@@ -87,6 +87,10 @@ class Expr:
     def logical_or(self, o): return self._ar(C.FZ_OP_OR, o)
     def logical_not(self): return Expr(C.lib.fz_arith(C.FZ_OP_NOT, self._h, None))
 
+    def __bool__(self):
+        # (`_1 < _2` is an expression, not a Python truth value: `if a < b`, `max(a, b)`, `a and b` would silently take the wrong branch)
+        raise TypeError("a Flowz expression has no truth value: comparisons build graph nodes (use .logical_and / .logical_or / .logical_not to combine them)")
+
     # -- combinators -----------------------------------------------------------------------
     def __or__(self, o): return Expr(C.lib.fz_parallel(self._h, as_expr(o)._h))
     def __ror__(self, o): return Expr(C.lib.fz_parallel(as_expr(o)._h, self._h))
