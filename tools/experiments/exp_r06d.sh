@@ -7,3 +7,10 @@ for opts in "" "-DFZ_DBG_AUX_ST=0" "-DFZ_DBG_AUX_ST=2" "-DFZ_DBG_AUX_ST=16" "-DF
   FLOWZ_HIP_EXTRA_OPTS="$opts" timeout 600 python tools/experiments/exp_r06d.py >> $O/ldsring_policies.txt 2>&1
 done
 grep -v amdgpu.ids $O/ldsring_policies.txt | cut -c1-400
+# randomized parity runs on the final kernels (tools/fuzz_*.py): random graphs with comparison operators among them, whole waves (lane groups), wide frames, wave splits
+export FLOWZ_HIP_CACHE=/tmp/fz_kc_fuzz
+FUZZ_CMP=1 timeout 420 python tools/fuzz_gpu.py 60000 400 300 > $O/fuzz_gpu_cmp_ns200.txt 2>&1; tail -2 $O/fuzz_gpu_cmp_ns200.txt
+FUZZ_CMP=1 FUZZ_NS=512 timeout 420 python tools/fuzz_gpu.py 61000 400 300 > $O/fuzz_gpu_cmp_ns512.txt 2>&1; tail -2 $O/fuzz_gpu_cmp_ns512.txt
+timeout 300 python tools/fuzz_gpu.py 62000 300 200 > $O/fuzz_gpu_ns200.txt 2>&1; tail -2 $O/fuzz_gpu_ns200.txt
+timeout 300 python tools/fuzz_wide_frames.py 63000 300 200 > $O/fuzz_wide_frames.txt 2>&1; tail -2 $O/fuzz_wide_frames.txt
+timeout 300 python tools/fuzz_wave_split.py 64000 100 200 > $O/fuzz_wave_split.txt 2>&1; tail -2 $O/fuzz_wave_split.txt
