@@ -238,6 +238,24 @@ def test_comparison_operators_python_spelling_typing_and_isa(tmp_path, monkeypat
         assert not re.search(r"v_(pk_)?(fma|fmac|mad|mac)(_mix|_mixlo|_mixhi|_legacy)?_(f16|f32|f64|bf16)", dis)
 
 
+def test_kernel_experiment_switches_are_compile_time_options(tmp_path):
+    """What rounds 1-5 had as variant flags (plain loads and stores, the plain block order, cache-policy fields) are -D switches of the kernel source now,
+    handed over through FLOWZ_HIP_EXTRA_OPTS (read once per process, part of the kernel-cache key): every one of them still builds, under a name of its own."""
+    import subprocess
+    import sys
+    code = ("import sys\nfrom zignal_amd import flowz as F, workloads as W\n"
+            "p = F.compile(F.from_sexpr(W.df1_cascade(2)))\n"
+            "for v in ((2, 8, 256, 0), (1, 4, 1024, F.C.FZ_VF_LOCKSTEP | F.C.FZ_VF_GRID_SYNC), (1, 32, 0, F.C.FZ_VF_STREAM_MAJOR)):\n"
+            "    p.build(F.make_variant(*v))\nprint(p.kernel_code_id(F.make_variant(2, 8, 256, 0)))\n")
+    ids = set()
+    for opts in ("", "-DFZ_DBG_NO_NT", "-DFZ_DBG_NO_XCD_REMAP", "-DFZ_DBG_AUX_LD=0 -DFZ_DBG_AUX_ST=16"):
+        env = dict(os.environ, FLOWZ_HIP_CACHE=str(tmp_path / ("c" + str(len(ids)))), FLOWZ_HIP_EXTRA_OPTS=opts)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
+        assert out.returncode == 0, opts + ": " + out.stderr[-1500:]
+        ids.add(out.stdout.split()[-1])
+    assert len(ids) == 4
+
+
 def test_lowering_osc_chain_with_stream_params():
     g = G.osc_chain(6)
     p = F.compile(F.from_sexpr(g))
