@@ -19,7 +19,11 @@ prog = F.compile(F.from_sexpr(W.lds_ring_comb()))
 V = {"default": None, "u12": (1, 12, 256, L | G), "u20": (1, 20, 256, L | G), "free u32": (1, 32, 256, 0)}
 if not os.environ.get("FLOWZ_HIP_EXTRA_OPTS"):
     V["u16 three buffers"] = (1, 16, 256, L | G | P3)
+if os.environ.get("R06D_THREE_BUFFERS"):                     # second pass: is it the third buffer? other chunk lengths with three buffers, two buffers next to them
+    V = {"default": None, "u16 two buffers": (1, 16, 256, L | G), "u16 three buffers": (1, 16, 256, L | G | P3), "u12 three buffers": (1, 12, 256, L | G | P3),
+         "u20 three buffers": (1, 20, 256, L | G | P3), "u24 three buffers": (1, 24, 256, L | G | P3), "u8 three buffers": (1, 8, 256, L | G | P3)}
 keep, rows = [], {k: [] for k in V}
+rows = {k: [] for k in V}
 b_alg = ns * (8 * T + 8 * prog.n_state)
 for trial in range(6):
     if trial:
