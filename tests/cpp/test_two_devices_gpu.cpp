@@ -4,25 +4,16 @@
 // whose measured plans are keyed by device and whose arrival counters are per device.  Every shard must equal the columns of
 // the single-device result bit for bit.  With one visible device the same threads share device 0 (two banks, two HIP streams):
 // the thread-safety half of the test still runs; the device half is reported as skipped.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <thread>
 #include <vector>
 
 #include <flowz/flowz.hpp>
+#include <flowz/shard.hpp>      // shard_range + the statistics reduction over RCCL (brings the HIP runtime and RCCL headers)
 
-extern "C" {
-int hipMalloc(void** p, size_t n);
-int hipFree(void* p);
-int hipMemcpy(void* dst, const void* src, size_t n, int kind);
-int hipDeviceSynchronize(void);
-int hipGetDeviceCount(int* n);
-int hipSetDevice(int d);
-int hipStreamCreate(void** s);
-int hipStreamDestroy(void* s);
-int hipStreamSynchronize(void* s);
-}
-enum { H2D = 1, D2H = 2 };
+static const hipMemcpyKind H2D = hipMemcpyHostToDevice, D2H = hipMemcpyDeviceToHost;
 
 static int failures = 0;
 #define CHECK(cond)                                                                  \
@@ -55,11 +46,12 @@ int main()
    auto work = [&](uint32_t k) {
       const int dev = n_dev >= 2 ? int(k) : 0;
       if (hipSetDevice(dev) != 0) return;
-      const uint32_t begin = k * ns / shards, end = (k + 1) * ns / shards, n = end - begin;   // contiguous stream range
+      const auto range = shard_range(ns, k, shards);                        // contiguous stream range
+      const uint32_t begin = (uint32_t)range.first, n = (uint32_t)(range.second - range.first);
       std::vector<float> xin(size_t(T) * n);
       for (uint32_t t = 0; t < T; ++t) std::memcpy(&xin[size_t(t) * n], &x[size_t(t) * ns + begin], n * sizeof(float));
       float *din = nullptr, *dout = nullptr;
-      void* stream = nullptr;
+      hipStream_t stream = nullptr;
       if (hipMalloc(reinterpret_cast<void**>(&din), xin.size() * 4) || hipMalloc(reinterpret_cast<void**>(&dout), xin.size() * 4) || hipStreamCreate(&stream)) return;
       hipMemcpy(din, xin.data(), xin.size() * 4, H2D);
       try {
@@ -88,6 +80,38 @@ int main()
       bool same = true;
       for (uint32_t t = 0; t < T && same; ++t) same = !std::memcmp(&got[k][size_t(t) * n], &want[size_t(t) * ns + begin], n * sizeof(float));
       CHECK(same);
+   }
+   {  // the ONE collective of the sharded path, from C++: max seconds / sum of samples / sum of an integer checksum over RCCL (include/flowz/shard.hpp).
+      // One communicator per device in use; with one visible device the two shards' statistics are summed on the host first (world size 1).
+      auto checksum_of = [&](const float* row, uint32_t n) {
+         unsigned long long c = 0;
+         for (uint32_t i = 0; i < n; ++i) { uint32_t u; std::memcpy(&u, row + i, 4); c += u; }
+         return c;
+      };
+      const unsigned long long want_sum = checksum_of(&want[size_t(T - 1) * ns], ns);
+      std::vector<run_stats> st(n_dev >= 2 ? shards : 1);
+      for (uint32_t k = 0; k < shards; ++k) {
+         if (!ok[k]) continue;
+         const auto r = shard_range(ns, k, shards);
+         const uint32_t n = (uint32_t)(r.second - r.first);
+         run_stats& q = st[n_dev >= 2 ? k : 0];
+         q.seconds = std::max(q.seconds, 0.001 * (k + 1));
+         q.samples += double(n) * T;
+         q.checksum += checksum_of(&got[k][size_t(T - 1) * n], n);
+      }
+      try {
+         std::vector<int> devs;
+         for (size_t i = 0; i < st.size(); ++i) devs.push_back((int)i);
+         stats_reducer red(devs);
+         const run_stats all = red.reduce(st);
+         CHECK(all.samples == double(ns) * T);
+         CHECK(all.checksum == want_sum);
+         CHECK(all.seconds == 0.001 * shards);
+         std::printf("statistics reduced over RCCL, world size %u: %.0f samples, checksum %llu\n", red.world(), all.samples, all.checksum);
+      } catch (const std::exception& e) {
+         std::printf("FAILED: %s\n", e.what());
+         ++failures;
+      }
    }
    if (n_dev < 2) std::printf("one visible device: both shards ran on device 0 (two host threads, two banks, two streams); the two-device run is skipped\n");
    else std::printf("%u shards on %d devices, one host thread each\n", shards, n_dev);

@@ -44,14 +44,18 @@ def test_cpp_block_api_routes_agree_on_gpu():
     assert "all block API checks passed" in out.stdout
 
 
+# (include/flowz/shard.hpp -- the C++ host's statistics reduction -- is the one header of the front end that needs the HIP runtime and RCCL)
+TWO_DEV_FLAGS = ("-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-pthread")
+
+
 def test_cpp_two_devices_compiles():
-    build("test_two_devices_gpu", ("-L/opt/rocm/lib", "-lamdhip64", "-pthread"))
+    build("test_two_devices_gpu", TWO_DEV_FLAGS)
 
 
 @pytest.mark.gpu
 def test_cpp_shards_on_several_devices_from_one_process():
     """SURVEY 8e from ONE host process: contiguous stream shards, a host thread + hipSetDevice + bank + stream per shard, the
     compiled program shared; every shard equals the single-device result.  On a one-GPU box both threads share device 0."""
-    out = subprocess.run([build("test_two_devices_gpu", ("-L/opt/rocm/lib", "-lamdhip64", "-pthread"))], capture_output=True, text=True)
+    out = subprocess.run([build("test_two_devices_gpu", TWO_DEV_FLAGS)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "all multi-device checks passed" in out.stdout
+    assert "all multi-device checks passed" in out.stdout and "statistics reduced over RCCL" in out.stdout
