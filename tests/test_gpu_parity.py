@@ -1661,6 +1661,32 @@ def test_clipped_biquad_at_scale_in_lockstep(torch_cuda, F):
     assert float(np.abs(want).max()) <= 0.5 and float((np.abs(want) == 0.5).mean()) > 0.01   # the clipper is at work
 
 
+def test_tiles_walk_in_lockstep_for_light_graphs(torch_cuda, F):
+    """Round 6: stream tiles of >= 2^19 streams whose tile a CU-wide workgroup of two streams per lane divides run their rows in lockstep, XCD-synchronised,
+    two laps at 1 M streams: the library's default by name, sampled streams against the oracle, the whole output and the state against the free-running kernel,
+    two chained blocks; a stream count of whole tiles that is not whole laps."""
+    torch = torch_cuda
+    g = G.df1_cascade(6)
+    prog = F.compile(F.from_sexpr(g))
+    tile, T = 8192, 1100
+    ns = (1 << 19) + 3 * tile                                       # 67 tiles: two laps, the second far from full
+    LG = _capi.FZ_VF_LOCKSTEP | _capi.FZ_VF_GRID_SYNC
+    assert prog.kernel_name(None, ns, T, tile) == "fz_block_kernel_p2u2b1024f%d" % LG
+    x = torch.empty((ns // tile, T, tile, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED + 91)
+    y1, st1 = prog.run_block(x[:, :600].contiguous())
+    y2, st2 = prog.run_block(x[:, 600:].contiguous(), state=st1.clone())
+    v = F.make_variant(2, 16, 256, _capi.FZ_VF_MAX_WG(2))
+    r1, sr1 = prog.run_block(x[:, :600].contiguous(), variant=v)
+    r2, sr2 = prog.run_block(x[:, 600:].contiguous(), state=sr1.clone(), variant=v)
+    assert torch.equal(y1, r1) and torch.equal(y2, r2) and torch.equal(st1, sr1) and torch.equal(st2, sr2)
+    ids = np.concatenate([np.arange(3), np.random.default_rng(9).integers(0, ns, 100), np.arange(ns - 3, ns)])
+    want = C.df1_cascade([G.STABLE] * 6, O.synth_input(SEED + 91, ids, T))
+    idt = torch.as_tensor(ids, device="cuda")
+    got = torch.cat([y1, y2], dim=1)[idt // tile, :, idt % tile, :].permute(1, 0, 2).contiguous().cpu().numpy()
+    assert ndiff(got, want) == 0
+
+
 SM_GRAPHS = {"cascade6": lambda: G.df1_cascade(6), "par4": G.par4_sum, "cross_wire": G.cross_wire, "integrator": G.integrator,
              "lds_ring": lambda: G.seq(G.add(G.IN(1), G.mul(G.lit(0.5), G.DEL(1, 40))), G.fb(G.add(G.mul(G.lit(0.7), G.DEL(1, 23)), G.IN(2)))),
              "df2t": G.df2t}
@@ -2042,7 +2068,11 @@ def test_time_major_default_is_lockstep_and_equals_the_plain_kernel(torch_cuda, 
     assert prog.kernel_name(None, 1 << 18, 4096, 0) == "fz_block_kernel_p2u4b512f%d" % LG          # two streams per lane, 512-lane workgroups: 0.74 against 0.65 for one x 1024
     assert prog.kernel_name(None, 3 << 18, 4096, 0) == "fz_block_kernel_p4u1b768f%d" % (LG | _capi.FZ_VF_PREFETCH3)   # 786 432 = 256 workgroups x 768 lanes x 4
     assert prog.kernel_name(None, 1 << 21, 4096, 0) == "fz_block_kernel_p2u2b1024f%d" % LG          # four laps, one launch each (no persistent kernel any more)
-    assert prog.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % _capi.FZ_VF_MAX_WG(2)
+    # tiles of light graphs walk in lockstep too since round 6 (ahead on three boards: profiles/r06/tiles_in_lockstep.txt); short blocks, small tiles, the
+    # oscillator chain's 31 coefficients per stream: two free-running workgroups per CU
+    assert prog.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u2b1024f%d" % LG
+    assert prog.kernel_name(None, 1 << 20, 512, 8192) == prog.kernel_name(None, 1 << 20, 4096, 1024) == "fz_block_kernel_p2u16b256f%d" % _capi.FZ_VF_MAX_WG(2)
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % _capi.FZ_VF_MAX_WG(2)
     assert "b1024" not in prog.kernel_name(None, 1 << 17, 4096, 0)
     # a register-heavy graph steps down: with many per-stream coefficients (the oscillator chain: 31) straight to one stream per lane,
     # stage-packed (packing by stages costs no registers per stream)

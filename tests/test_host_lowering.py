@@ -779,8 +779,10 @@ def test_time_major_geometry_follows_the_cu_count():
     assert name(1_000_008) == "fz_block_kernel_p4u1b1024f%dM" % (L | GS | P3) and name(1_000_016) == "fz_block_kernel_p4u1b1024f%d" % (L | GS | P3)
     assert name(1 << 21) == "fz_block_kernel_p2u2b1024f%d" % (L | GS)                  # four laps of two streams per lane (0.75 against 0.70 for two laps of four)
     assert "b1024" not in name(1 << 17) and "f%d" % (L | GS) not in name((1 << 18) - 1024)   # below one wave per SIMD and CU: the few-stream kernels
-    # nothing of this on tiles
-    assert p.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % F.C.FZ_VF_MAX_WG(2)
+    # tiles
+    assert p.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u2b1024f%d" % (L | GS)        # (round 6: light graphs walk their tiles in lockstep too)
+    assert p.kernel_name(None, 1 << 20, 512, 8192) == p.kernel_name(None, 1 << 20, 4096, 1024) == "fz_block_kernel_p2u16b256f%d" % F.C.FZ_VF_MAX_WG(2)
+    assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % F.C.FZ_VF_MAX_WG(2)
     # LDS rings (vectorised in time: one stream per lane, a wave on every SIMD) walk along at the geometry their rings allow since round 6: 256 lanes,
     # 16-row chunks in three buffers, the resident workgroups as one lap of many; free-running on tiles, on short blocks and below CUs x 1024 streams
     ring = F.compile(F.from_sexpr(G.lds_ring_comb()))

@@ -231,7 +231,7 @@ int fz_program_build_for(fz_program* p, const fz_variant* v, uint64_t n_streams,
       (void)get_kernel(p, rv, nullptr);
       // (a plain time-major block whose laps leave a few streams over launches a second kernel next to them)
       if (!(tile_streams && tile_streams < n_streams) && !(v && (v->flags & FZ_VF_STREAM_MAJOR))) {
-         const uint64_t main_streams = lockstep_streams(p->g, v, rv, n_streams);
+         const uint64_t main_streams = lockstep_streams(p->g, v, rv, n_streams, tile_streams);
          if (main_streams < n_streams) (void)get_kernel(p, remainder_variant(p, v, n_streams, n_samples, n_streams - main_streams), nullptr);
       }
       return FZ_OK;)

@@ -288,7 +288,7 @@ struct TmGeometry {
    double score = 0.0;
 };
 TmGeometry time_major_geometry(uint64_t n_streams, uint32_t max_p, bool heavy_ops, bool ragged_ok, uint32_t only_p = 0);
-uint64_t lockstep_streams(const Graph& g, const fz_variant* uv, const Variant& v, uint64_t n_streams);
+uint64_t lockstep_streams(const Graph& g, const fz_variant* uv, const Variant& v, uint64_t n_streams, uint32_t tile_streams);
 // the kernel a launch of that shape runs: resolved, fitted to the tile / the 4 GiB chunk limit, unroll lowered until nothing spills
 Variant finalize_variant(fz_program* p, const fz_variant* v, uint64_t n_streams, uint32_t n_samples, uint32_t tile_streams, bool settle = true);
 // the second kernel of a launch whose lockstep laps leave `rem` streams to a remainder launch (lockstep_streams(...) < n_streams)

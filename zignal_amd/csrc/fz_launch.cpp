@@ -374,7 +374,7 @@ int launch(fz_program* p, const float* in, float* out, float* state, const float
    };
    // the library's own lockstep choice may cover whole laps only and leave the last few streams to a launch of their own
    // (time_major_geometry): those run what a block of that few streams runs by itself
-   const uint64_t main_streams = stream_major ? n_streams : lockstep_streams(g, uv, v, n_streams);
+   const uint64_t main_streams = stream_major ? n_streams : lockstep_streams(g, uv, v, n_streams, tile_streams);
    if (main_streams == n_streams) {
       run_part(v, 0, n_streams, stream);
       return FZ_OK;

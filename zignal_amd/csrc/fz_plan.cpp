@@ -320,8 +320,20 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
    v.flags &= ~(uint32_t)FZ_VF_NO_STAGE_PACK;
    v.block = rq.B ? rq.B : 256;
    if (v.flags & FZ_VF_STREAM_MAJOR) return resolve_stream_major(g, rq, v, n_streams, n_samples);
-   // stream-tiled frames, packed lanes, chip oversubscribed: two workgroups per CU
-   if (nothing_asked && tile_streams && v.P == 2 && n_streams >= (1u << 19) && !g.n_lds_slots) v.flags |= FZ_VF_MAX_WG(2);
+   // stream-tiled frames, packed lanes, chip oversubscribed: the tiles' rows are walked in lockstep too when a CU-wide workgroup of two streams per
+   // lane divides the tile and the graph is light on registers (round 6; three boards, tiles of 8192, 1 M streams: the cascade 0.755-0.766 against
+   // 0.748-0.762, the fan-out sum 0.784-0.795 against 0.745-0.760: ahead on every board; the oscillator chain with its 31 coefficients per stream
+   // 0.59-0.62 against 0.72-0.73: stays free-running; profiles/r06/tiles_in_lockstep.txt) -- else two free-running workgroups per CU
+   if (nothing_asked && tile_streams && v.P == 2 && n_streams >= (1u << 19) && !g.n_lds_slots) {
+      if (allow_lockstep >= 2 && tile_streams % 2048 == 0 && n_samples >= kLockstepMinRows && g.n_param < 8 && reg_state <= 16 && !g.typed && g.far_lines.empty() &&
+          g.n_in <= 2 && g.n_out <= 2) {
+         v.U = 2;
+         v.block = 1024;
+         v.flags |= FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC;
+      } else {
+         v.flags |= FZ_VF_MAX_WG(2);
+      }
+   }
    if (g.n_lds_slots) {
       // LDS rings: a workgroup's rings must fit the CU's 160 KiB (the vectorised rings pad their rows)
       auto bytes = [&](const Variant& w) { return (uint64_t)ring_plan(g, w).slots * w.block * 4u * w.P; };
@@ -335,9 +347,10 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
 
 // the streams the (first) lockstep launch of a block covers: all of them -- except for the library's own choice on plain time-major
 // frames when time_major_geometry peels a remainder off the end (its launch runs the few-stream kernels)
-uint64_t lockstep_streams(const Graph& g, const fz_variant* uv, const Variant& v, uint64_t n_streams)
+uint64_t lockstep_streams(const Graph& g, const fz_variant* uv, const Variant& v, uint64_t n_streams, uint32_t tile_streams)
 {
-   if (uv_has_shape(uv) || !(v.flags & FZ_VF_LOCKSTEP)) return n_streams;
+   // (tiles and LDS rings walk in lockstep at geometries of their own -- whole tiles, 256-lane workgroups: nothing is peeled off)
+   if (uv_has_shape(uv) || !(v.flags & FZ_VF_LOCKSTEP) || (tile_streams && tile_streams < n_streams) || g.n_lds_slots) return n_streams;
    return time_major_geometry(n_streams, v.P, g.n_ops > 30, !g.typed && g.far_lines.empty()).main_streams;
 }
 
@@ -395,7 +408,7 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
       // grid -- cost the b128 accesses 12-17 % of their rate; the lane's streams 64 apart instead (dword accesses) cost more: 9.6 ms
       // against 6.5 ms (profiles/r04/rows_off_the_grid.txt)
       v.flags &= ~FZ_VF_RAGGED;
-      if ((v.flags & FZ_VF_LOCKSTEP) && !tile_streams && !stream_major && lockstep_streams(p->g, uv, v, n_streams) % v.P) v.flags |= FZ_VF_RAGGED;
+      if ((v.flags & FZ_VF_LOCKSTEP) && !tile_streams && !stream_major && lockstep_streams(p->g, uv, v, n_streams, 0) % v.P) v.flags |= FZ_VF_RAGGED;
       // output rows off the store grid: stores that let L2 merge the sectors neighbouring waves share (see fz_block_kernel.hip.inc)
       v.flags &= ~FZ_VF_ST_MERGE;
       if (!tile_streams && !stream_major) {

@@ -146,6 +146,9 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
       cands.push_back(fz_variant{1, 24, 0, FZ_VF_STAGE_PACK});
    } else if ((d.flags & FZ_VF_LOCKSTEP) && g.n_lds_slots) {   // LDS rings in step: against the free-running four-wave workgroups with 32-row chunks
       cands.push_back(fz_variant{1, 32, 256, 0});
+   } else if ((d.flags & FZ_VF_LOCKSTEP) && tile_streams) {   // tiles in step: against two / any number of free-running workgroups per CU
+      cands.push_back(fz_variant{2, 16, 256, FZ_VF_MAX_WG(2)});
+      cands.push_back(fz_variant{2, 16, 256, 0});
    } else if (d.flags & FZ_VF_LOCKSTEP) {                 // plain rows, many streams: the walk in lockstep against its neighbours in the geometry table
       const uint32_t G = d.flags & FZ_VF_GRID_SYNC;
       cands.push_back(fz_variant{std::min(d.P, 2u), 16, 256, 0});                                  // four-wave workgroups running free
