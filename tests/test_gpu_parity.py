@@ -1670,13 +1670,13 @@ def test_tiles_walk_in_lockstep_for_light_graphs(torch_cuda, F):
     prog = F.compile(F.from_sexpr(g))
     tile, T = 8192, 1100
     ns = (1 << 19) + 3 * tile                                       # 67 tiles: two laps, the second far from full
-    LG = _capi.FZ_VF_LOCKSTEP | _capi.FZ_VF_GRID_SYNC
+    LG = F.C.FZ_VF_LOCKSTEP | F.C.FZ_VF_GRID_SYNC
     assert prog.kernel_name(None, ns, T, tile) == "fz_block_kernel_p2u2b1024f%d" % LG
     x = torch.empty((ns // tile, T, tile, 1), dtype=torch.float32, device="cuda")
     F.synth_fill(x, SEED + 91)
     y1, st1 = prog.run_block(x[:, :600].contiguous())
     y2, st2 = prog.run_block(x[:, 600:].contiguous(), state=st1.clone())
-    v = F.make_variant(2, 16, 256, _capi.FZ_VF_MAX_WG(2))
+    v = F.make_variant(2, 16, 256, F.C.FZ_VF_MAX_WG(2))
     r1, sr1 = prog.run_block(x[:, :600].contiguous(), variant=v)
     r2, sr2 = prog.run_block(x[:, 600:].contiguous(), state=sr1.clone(), variant=v)
     assert torch.equal(y1, r1) and torch.equal(y2, r2) and torch.equal(st1, sr1) and torch.equal(st2, sr2)
