@@ -1086,6 +1086,56 @@ def test_headline_time_major_cascade6_1M_x_4096(torch_cuda, F, monkeypatch):
     assert torch.equal(st.view(torch.int32), st2.view(torch.int32))
 
 
+def test_full_size_properties_power_of_two_scaling_and_time_shift(torch_cuda, F, monkeypatch):
+    """Size-independent properties of the domain at BASELINE's full sizes, on EVERY stream and sample (the oracle checks sample streams): the graphs
+    are linear and time-invariant, and in IEEE arithmetic two consequences hold bit for bit as long as nothing over- or underflows:
+    scaling the input by a power of two scales every output by it (every product and sum is the same significand, another exponent), and an
+    input delayed by d samples from zero state gives the output delayed by d samples.  Headline (6 x DF1, 1 M x 4096, plain rows, the lockstep
+    default), config 3 (4-wire sum) and config 4 (oscillator chain, per-stream coefficients, dirac drive)."""
+    torch = torch_cuda
+    monkeypatch.setenv("FLOWZ_HIP_NO_PLAN_CACHE", "1")
+    ns, T, d = 1 << 20, 4096, 7
+    prog = F.compile(F.from_sexpr(G.df1_cascade(6)))
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED + 5)
+    y1, _ = prog.run_block(x)
+    x.mul_(4.0)
+    y2, _ = prog.run_block(x)
+    y1.mul_(4.0)
+    assert torch.equal(y1.view(torch.int32), y2.view(torch.int32))
+    assert float(y2.abs().max()) < 16.0 and int((y2 != 0).sum()) > 0.99 * y2.numel()          # (a real signal, far from both ends of the exponent range)
+    del y1
+    xs = torch.empty_like(x)
+    xs[:d].zero_()
+    xs[d:].copy_(x[:-d])
+    y3, _ = prog.run_block(xs)
+    assert int((y3[:d] != 0).sum()) == 0 and torch.equal(y3[d:].view(torch.int32), y2[:-d].view(torch.int32))
+    del x, xs, y2, y3
+    torch.cuda.empty_cache()
+    # config 3: four wires in, one out
+    p4 = F.compile(F.from_sexpr(G.par4_sum()))
+    x4 = torch.empty((T, ns, 4), dtype=torch.float32, device="cuda")
+    F.synth_fill(x4, SEED + 6)
+    a, _ = p4.run_block(x4)
+    x4.mul_(0.5)
+    b, _ = p4.run_block(x4)
+    a.mul_(0.5)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    del x4, a, b
+    torch.cuda.empty_cache()
+    # config 4: the oscillator chain rings on a dirac; twice the dirac, twice the ringing, on every one of the million coefficient sets
+    po = F.compile(F.from_sexpr(G.osc_chain(6)))
+    params = torch.from_numpy(W.osc_chain_params(SEED + 1, np.arange(ns))).cuda()
+    xo = torch.zeros((T, ns, 1), dtype=torch.float32, device="cuda")
+    xo[0].fill_(1.0)
+    a, _ = po.run_block(xo, params=params)
+    xo[0].fill_(2.0)
+    b, _ = po.run_block(xo, params=params)
+    a.mul_(2.0)
+    fin = torch.isfinite(b)
+    assert bool(fin.all()) and torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 def test_remainder_launches_of_two_host_threads_keep_their_own_order(torch_cuda, F, monkeypatch):
     """A block of 262 145 streams runs as one lap of whole workgroups plus a REMAINDER launch on the program's side stream, forked from
     and joined to the caller's stream by events (fz_launch.cpp).  Two host threads, each on its own HIP stream, refill their input
