@@ -37,6 +37,15 @@ static fz_expr* parse(std::istringstream& in)
    if (op == "sub") return bin([](fz_expr* a, fz_expr* b) { return fz_arith(FZ_OP_SUB, a, b); });
    if (op == "mul") return bin([](fz_expr* a, fz_expr* b) { return fz_arith(FZ_OP_MUL, a, b); });
    if (op == "div") return bin([](fz_expr* a, fz_expr* b) { return fz_arith(FZ_OP_DIV, a, b); });
+   if (op == "not") return un([](fz_expr* a) { return fz_arith(FZ_OP_NOT, a, nullptr); });
+   if (op == "lt") return bin([](fz_expr* a, fz_expr* b) { return fz_arith(FZ_OP_LT, a, b); });
+   if (op == "le") return bin([](fz_expr* a, fz_expr* b) { return fz_arith(FZ_OP_LE, a, b); });
+   if (op == "gt") return bin([](fz_expr* a, fz_expr* b) { return fz_arith(FZ_OP_GT, a, b); });
+   if (op == "ge") return bin([](fz_expr* a, fz_expr* b) { return fz_arith(FZ_OP_GE, a, b); });
+   if (op == "eq") return bin([](fz_expr* a, fz_expr* b) { return fz_arith(FZ_OP_EQ, a, b); });
+   if (op == "ne") return bin([](fz_expr* a, fz_expr* b) { return fz_arith(FZ_OP_NE, a, b); });
+   if (op == "and") return bin([](fz_expr* a, fz_expr* b) { return fz_arith(FZ_OP_AND, a, b); });
+   if (op == "or") return bin([](fz_expr* a, fz_expr* b) { return fz_arith(FZ_OP_OR, a, b); });
    if (op == "chan") return bin(fz_channel);
    if (op == "par") return bin(fz_parallel);
    if (op == "seq") return bin(fz_sequence);
