@@ -1631,8 +1631,8 @@ def test_lds_rings_take_the_row_walk_in_lockstep_on_plain_rows(torch_cuda, F):
     g = G.lds_ring_comb()
     prog = F.compile(F.from_sexpr(g))
     ns, T = 300_000 + 37, 1100
-    assert prog.kernel_name(None, ns, T) == "fz_block_kernel_p1u16b256f8912928M"          # lockstep | XCD step | three chunk buffers (rows off the 64-byte grid: merging stores)
-    assert prog.kernel_name(None, 1 << 20, 4096) == "fz_block_kernel_p1u16b256f8912928" and prog.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p1u32b256f0"
+    assert prog.kernel_name(None, ns, T) == "fz_block_kernel_p1u16b256f8912896M"          # lockstep | XCD step (rows off the 64-byte grid: merging stores)
+    assert prog.kernel_name(None, 1 << 20, 4096) == "fz_block_kernel_p1u16b256f8912896" and prog.kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p1u32b256f0"
     x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
     F.synth_fill(x, SEED + 61)
     y1, st1 = prog.run_block(x[:600].contiguous())

@@ -784,9 +784,9 @@ def test_time_major_geometry_follows_the_cu_count():
     assert p.kernel_name(None, 1 << 20, 512, 8192) == p.kernel_name(None, 1 << 20, 4096, 1024) == "fz_block_kernel_p2u16b256f%d" % F.C.FZ_VF_MAX_WG(2)
     assert F.compile(F.from_sexpr(G.osc_chain(6))).kernel_name(None, 1 << 20, 4096, 8192) == "fz_block_kernel_p2u16b256f%d" % F.C.FZ_VF_MAX_WG(2)
     # LDS rings (vectorised in time: one stream per lane, a wave on every SIMD) walk along at the geometry their rings allow since round 6: 256 lanes,
-    # 16-row chunks in three buffers, the resident workgroups as one lap of many; free-running on tiles, on short blocks and below CUs x 1024 streams
+    # 16-row chunks, the resident workgroups as one lap of many; free-running on tiles, on short blocks and below CUs x 1024 streams
     ring = F.compile(F.from_sexpr(G.lds_ring_comb()))
-    assert ring.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u16b256f%d" % (L | GS | P3) and ring.kernel_name(None, 1 << 18, 1024, 0) == "fz_block_kernel_p1u16b256f%d" % (L | GS | P3)
+    assert ring.kernel_name(None, 1 << 20, 4096, 0) == "fz_block_kernel_p1u16b256f%d" % (L | GS) and ring.kernel_name(None, 1 << 18, 1024, 0) == "fz_block_kernel_p1u16b256f%d" % (L | GS)
     assert ring.kernel_name(None, 1 << 20, 4096, 8192) == ring.kernel_name(None, 1 << 20, 512, 0) == ring.kernel_name(None, 1 << 17, 4096, 0) == "fz_block_kernel_p1u32b256f0"
     # wide frames (the 4-wire sum): one stream per lane in 1024-lane workgroups; one lap: one row per buffer, more: chunks of three rows
     p4 = F.compile(F.from_sexpr(G.par4_sum()))

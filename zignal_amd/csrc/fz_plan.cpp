@@ -154,17 +154,16 @@ static bool lockstep_default(const Graph& g, Variant& v, uint64_t n_streams, uin
    //  a day 0.73 ... 0.80 of peak against 0.65 ... 0.77 free-running)
    const bool far = !g.far_lines.empty();
    // LDS rings walk along too (round 6) -- at the geometry their rings allow: one stream per lane, 256 lanes (one wave per SIMD; the comb's rings
-   // take 104 KiB of the CU's 160), 16-row chunks in THREE buffers, the resident workgroups as one lap of many.  On six fresh allocations the
-   // 40 / 23-sample combs at 1 M streams run 0.681-0.717 of peak with two buffers against 0.651-0.702 free-running -- ahead on every one of them --,
-   // and the third buffer adds +0.6 ... +2.5 % on ten of twelve allocations of two more boards (0.696-0.709 / 0.731-0.738), -1 ... -3 % on the two that
-   // run low for every variant (profiles/r06/placement.txt, ldsring_cache_policies.txt;
-   // 32-row chunks in step 0.638-0.695, 20 / 24-row 0.67-0.70, 12-row 0.63, 8-row 0.51-0.54, 128 lanes 0.45)
+   // take 104 KiB of the CU's 160), 16-row chunks, the resident workgroups as one lap of many.  On six fresh allocations the 40 / 23-sample
+   // combs at 1 M streams run 0.681-0.717 of peak against 0.651-0.702 free-running -- ahead on every one of them, +1 ... +5 %
+   // (profiles/r06/placement.txt; 32-row chunks in step 0.638-0.695, 20 / 24-row 0.67-0.70, 12-row 0.63, 8-row 0.51-0.54, 128 lanes 0.45; a THIRD
+   // chunk buffer wins 15 of 18 paired comparisons on two boards and loses 24 of 24 on two others, +- 1-2.5 % either way: not taken)
    if (g.n_lds_slots && n_samples >= kLockstepMinRows && n_streams >= (uint64_t)chip_cus() * 1024u && g.n_in <= 2 && g.n_out <= 2 && !g.typed && !far) {
       Variant w = v;
       w.P = 1;
       w.U = 16;
       w.block = 256;
-      w.flags |= FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC | FZ_VF_PREFETCH3;
+      w.flags |= FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC;
       if ((uint64_t)ring_plan(g, w).slots * w.block * 4u <= kMaxLdsBytes) {
          v = w;
          return true;
