@@ -297,7 +297,8 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       if (v.flags & FZ_VF_PREFETCH3) fail(FZ_E_INVALID, "FZ_VF_PREFETCH3 is not available with delays beyond LDS");
       v.U = std::min(v.U, cap);
    }
-   // few streams: the most parts whose waves still find a SIMD each (<= 16 384 streams: four or three, <= 32 768: two), with an I/O wave
+   // few streams: the most parts whose waves still find a SIMD each (<= 16 384 streams: four or three, <= 32 768: two), with an I/O wave;
+   // up to 65 536: the whole graph in one compute wave next to two I/O waves
    if (!rq.P && !rq.B && n_samples >= 256 && (rq.U == 0 || rq.U == 8 || rq.U == 16 || rq.U == 32) &&
        !(v.flags & (FZ_VF_STAGE_PACK | FZ_VF_NO_STAGE_PACK | FZ_VF_OUT_F64 | FZ_VF_PREFETCH3 | FZ_VF_STREAM_MAJOR))) {
       uint32_t W = 0;
@@ -305,6 +306,13 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       if (!W && n_streams <= 32768 && g.wave_roles(2)) W = 2;
       if (W) {
          fz_variant q{1, rq.U, 0, v.flags | (W - 1) << 10 | (W < 4 ? (uint32_t)FZ_VF_IO_WAVE : 0u)};
+         return resolve_variant(g, &q, n_streams, n_samples, tile_streams, allow_lockstep);
+      }
+      // one wave per SIMD (config 2: 65 536 streams): the stage-packed wave next to a loader and a storer.  Round 6, paired bursts on four boards:
+      // ahead of the lone stage-packed wave in 8 of 8 comparisons on tiles (+0.3 ... +3.1 %) and 6 of 8 on rows (-0.8 ... +4.4 %, mean +1.6 %:
+      // 0.682-0.699 against 0.654-0.701), and the most frugal arrangement sustained (0.541 J per launch: profiles/r06/config2_floor.txt)
+      if (n_streams > 32768 && n_streams <= 65536 && g.wave_roles(1)) {
+         fz_variant q{1, rq.U ? rq.U : 16u, 0, v.flags | FZ_VF_IO_WAVE | FZ_VF_IO_WAVE2};
          return resolve_variant(g, &q, n_streams, n_samples, tile_streams, allow_lockstep);
       }
    }

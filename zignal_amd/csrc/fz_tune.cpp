@@ -133,16 +133,18 @@ std::vector<fz_variant> tune_candidates(const Graph& g, uint64_t n_streams, uint
    const Variant d = resolve_variant(g, nullptr, n_streams, n_samples, tile_streams);
    std::vector<fz_variant> cands{fz_variant{0, 0, 0, 0}};
    const uint32_t LG = FZ_VF_LOCKSTEP | FZ_VF_GRID_SYNC;
-   if (const uint32_t W = ws_parts(d.flags)) {            // few streams: the same split without / with the I/O wave, and the single stage-packed wave
-      cands.push_back(fz_variant{1, 0, 0, ((W - 1) << 10) | (ws_io(d.flags) ? 0u : (uint32_t)FZ_VF_IO_WAVE)});
-      cands.push_back(fz_variant{1, 16, 0, FZ_VF_STAGE_PACK});
-   } else if (d.flags & FZ_VF_STAGE_PACK) {               // one wave per SIMD (config 2): I/O waves, one packed pair of segments per wave, longer chunks
-      if (n_streams <= 65536 && g.wave_roles(1)) {
+   if (const uint32_t W = ws_parts(d.flags)) {
+      if (W == 1) {                                       // one wave per SIMD (config 2), two I/O waves by default: the lone stage-packed wave, one I/O wave, a packed pair per wave
+         cands.push_back(fz_variant{1, 16, 0, FZ_VF_STAGE_PACK});
          cands.push_back(fz_variant{1, 16, 0, FZ_VF_IO_WAVE});
-         cands.push_back(fz_variant{1, 16, 0, FZ_VF_IO_WAVE | FZ_VF_IO_WAVE2});   // (the most frugal arrangement at the power cap: profiles/r06/config2_floor.txt)
+         const uint32_t Wp = g.split.K / 2;
+         if (n_streams % 256 == 0 && Wp >= 2 && Wp <= 4 && g.wave_roles(Wp)) cands.push_back(fz_variant{1, 16, 256, FZ_VF_WAVES(Wp)});
+         cands.push_back(fz_variant{1, 24, 0, FZ_VF_STAGE_PACK});
+      } else {                                            // few streams: the same split without / with the I/O wave, and the single stage-packed wave
+         cands.push_back(fz_variant{1, 0, 0, ((W - 1) << 10) | (ws_io(d.flags) ? 0u : (uint32_t)FZ_VF_IO_WAVE)});
+         cands.push_back(fz_variant{1, 16, 0, FZ_VF_STAGE_PACK});
       }
-      const uint32_t Wp = g.split.K / 2;
-      if (n_streams <= 65536 && n_streams % 256 == 0 && Wp >= 2 && Wp <= 4 && g.wave_roles(Wp)) cands.push_back(fz_variant{1, 16, 256, FZ_VF_WAVES(Wp)});
+   } else if (d.flags & FZ_VF_STAGE_PACK) {               // one stream per lane, stage-packed (65 536 < streams < 2^18, short blocks): longer chunks
       cands.push_back(fz_variant{1, 24, 0, FZ_VF_STAGE_PACK});
    } else if ((d.flags & FZ_VF_LOCKSTEP) && g.n_lds_slots) {   // LDS rings in step: against the free-running four-wave workgroups with 32-row chunks
       cands.push_back(fz_variant{1, 32, 256, 0});
