@@ -9,6 +9,6 @@ for ns in 49152 40960 36864; do $S --graph cascade6 --streams $ns 0,0 1,16,0,8 1
 $S --graph osc --streams 65536 0,0 1,16,0,8 1,16,0,32768 >> $O/io2_default.txt 2>&1
 $S --graph osc --streams 65536 --tile 8192 0,0 1,16,0,8 >> $O/io2_default.txt 2>&1
 $S --graph cascade4 --streams 65536 0,0 1,16,0,8 >> $O/io2_default.txt 2>&1
-$S --graph cascade12 --streams 65536 0,0 1,16,0,8 >> $O/io2_default.txt 2>&1
+for g in cascade8 cascade10 cascade12 cascade2 df1; do $S --graph $g --streams 65536 0,0 1,16,0,8 1,16,0,33587200 >> $O/io2_default.txt 2>&1; done
 $S --graph cascade6g --streams 65536 0,0 1,16,0,8 >> $O/io2_default.txt 2>&1
 grep -v amdgpu.ids $O/io2_default.txt | cut -c1-170

@@ -38,7 +38,7 @@ def main():
               "osc": lambda: G.osc_chain(6), "df1": G.df1, "df2": G.df2, "df1t": G.df1t, "df2t": G.df2t,
               "gain": lambda: G.mul(G.lit(0.5), G.IN(1)), "cascade2": lambda: G.df1_cascade(2), "cascade4": lambda: G.df1_cascade(4),
               "cascade6g": lambda: G.seq(G.df1_cascade(6), G.mul(G.lit(0.7), G.IN(1))),
-              "cascade12": lambda: G.df1_cascade(12), "cascade24": lambda: G.df1_cascade(24),
+              "cascade8": lambda: G.df1_cascade(8), "cascade10": lambda: G.df1_cascade(10), "cascade12": lambda: G.df1_cascade(12), "cascade24": lambda: G.df1_cascade(24),
               "mod6": lambda: G.df1_cascade_modulated(6), "ldsring": G.lds_ring_comb, "farring": lambda: G.far_comb(300), "ident": lambda: G.IN(1),
               "params6": lambda: G.df1_cascade_params(6), "c32onepole": G.complex_one_pole, "f64biquad": G.df1_double,
               # yardsticks of the typed frames: a float wire in, a double / complex<float> wire out, one operation (4 bytes read, 8 written per sample)

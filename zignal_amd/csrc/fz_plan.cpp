@@ -311,9 +311,11 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // one wave per SIMD (config 2: 65 536 streams): the stage-packed wave next to a loader and a storer.  Round 6, paired bursts on four boards:
       // ahead of the lone stage-packed wave in 8 of 8 comparisons on tiles (+0.3 ... +3.1 %) and 6 of 8 on rows (-0.8 ... +4.4 %, mean +1.6 %:
       // 0.682-0.699 against 0.654-0.701), and the most frugal arrangement sustained (0.541 J per launch: profiles/r06/config2_floor.txt)
+      // -- where four tuples fit a workgroup's LDS (and its registers: finalize_variant checks after the build)
       if (n_streams > 32768 && n_streams <= 65536 && g.wave_roles(1)) {
          fz_variant q{1, rq.U ? rq.U : 16u, 0, v.flags | FZ_VF_IO_WAVE | FZ_VF_IO_WAVE2};
-         return resolve_variant(g, &q, n_streams, n_samples, tile_streams, allow_lockstep);
+         const Variant r = resolve_variant(g, &q, n_streams, n_samples, tile_streams, allow_lockstep);
+         if (r.block == 256) return r;
       }
    }
    // stage packing: one stream per lane, pairs of isomorphic graph segments in one v_pk_* (fz_split.cpp); automatic unless the block is
@@ -439,6 +441,13 @@ Variant finalize_variant(fz_program* p, const fz_variant* uv, uint64_t n_streams
    };
    const Variant want = resolve_variant(g, uv, n_streams, n_samples, tile_streams);
    Variant v = fit(want);
+   if (settle && !uv_has_shape(uv) && ws_parts(v.flags) == 1 && (v.flags & FZ_VF_IO_WAVE2) && v.block < 256) {
+      // the library's own choice of two I/O waves next to the compute wave (config 2's shapes) needs four tuples in a workgroup -- one compute
+      // wave on every SIMD of the CU: a graph whose compute wave needs more registers than a third of a SIMD's (the 12-stage cascade) settles
+      // at two tuples, its compute waves on half of the SIMDs, 0.23 of peak against 0.39-0.40 for the lone stage-packed wave, which it runs instead
+      const fz_variant lone{1, 0, 0, FZ_VF_STAGE_PACK};
+      v = fit(resolve_variant(g, &lone, n_streams, n_samples, tile_streams));
+   }
    if (settle && (v.flags & FZ_VF_LOCKSTEP) && !(uv && (uv->flags & FZ_VF_LOCKSTEP))) {
       // the library's own lockstep choice needs its kernel in the 128 registers of a 1024-lane workgroup with the rows in flight
       // it was chosen for: step down the streams per lane until it fits; a graph that never does runs the ordinary four-wave
