@@ -807,8 +807,16 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
     p = F.compile(F.from_sexpr(G.df1_cascade(6)))
     assert p.kernel_name(None, 32768, 4096) == "fz_block_kernel_p1u32b128w2iof33792"          # two compute waves + an I/O wave per 64 streams
     assert p.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w3iof34816"           # 256 workgroups: three compute waves of two biquads each + an I/O wave
-    assert p.kernel_name(None, 65536, 4096).startswith("fz_block_kernel_p1u16b256s6f")       # one wave per SIMD already
-    assert p.kernel_name(F.make_variant(0, 0, 0, F.C.FZ_VF_IO_WAVE), 65536, 4096) == "fz_block_kernel_p1u16b256w1iof32768"   # ... or an I/O wave next to it
+    # one wave per SIMD (32 768 < streams <= 65 536): the stage-packed wave next to a loader and a storer (round 6: ahead in paired bursts on four boards) ...
+    assert p.kernel_name(None, 65536, 4096) == p.kernel_name(None, 40960, 4096) == "fz_block_kernel_p1u16b256w1io2f%d" % (F.C.FZ_VF_IO_WAVE | F.C.FZ_VF_IO_WAVE2)
+    assert p.kernel_name(None, 65536, 4096, 8192) == "fz_block_kernel_p1u16b256w1io2f%d" % (F.C.FZ_VF_IO_WAVE | F.C.FZ_VF_IO_WAVE2)
+    # ... where four tuples fit a workgroup and the graph is not all arithmetic: 12 stages settle at two tuples (0.23 against 0.39 of peak) and keep the lone wave, 8 stages too
+    assert F.compile(F.from_sexpr(G.df1_cascade(12))).kernel_name(None, 65536, 4096) == "fz_block_kernel_p1u16b256s8f8"
+    assert F.compile(F.from_sexpr(G.df1_cascade(8))).kernel_name(None, 65536, 4096) == "fz_block_kernel_p1u16b256s8f8"
+    assert F.compile(F.from_sexpr(G.df1_cascade(4))).kernel_name(None, 65536, 4096).endswith("w1io2f%d" % (F.C.FZ_VF_IO_WAVE | F.C.FZ_VF_IO_WAVE2))
+    assert p.kernel_name(None, 65537, 4096).startswith("fz_block_kernel_p1u16b256s6f") and p.kernel_name(None, 65536, 200).startswith("fz_block_kernel_p1u16b256s6f")
+    assert p.kernel_name(F.make_variant(1, 16, 0, F.C.FZ_VF_STAGE_PACK), 65536, 4096) == "fz_block_kernel_p1u16b256s6f8"        # the lone wave on request
+    assert p.kernel_name(F.make_variant(0, 0, 0, F.C.FZ_VF_IO_WAVE), 65536, 4096) == "fz_block_kernel_p1u16b256w1iof32768"   # ... or one I/O wave next to it
     assert p.kernel_name(None, 32768, 200).startswith("fz_block_kernel_p1u16b256s6f")        # short blocks: the ends would dominate
     assert p.kernel_name(F.make_variant(0, 0, 0, 16), 32768, 4096) == "fz_block_kernel_p1u16b256f0"   # FZ_VF_NO_STAGE_PACK: the plain kernel
     src = p.source(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVE_SPLIT))
@@ -821,7 +829,7 @@ def test_wave_split_is_chosen_below_128_streams_per_cu_and_only_for_two_isomorph
     # what fz_program_tune measures there (round 6: only candidates some board of rounds 3-5 saw ahead): the split without its I/O wave, the single wave
     assert [v.flags for v in p.tune_candidates(32768, 4096)] == [0, F.C.FZ_VF_WAVES(2), 8]
     assert [v.flags for v in p.tune_candidates(16384, 4096)] == [0, F.C.FZ_VF_WAVES(3), 8]
-    assert [v.flags for v in p.tune_candidates(65536, 4096)] == [0, IO, IO | F.C.FZ_VF_IO_WAVE2, F.C.FZ_VF_WAVES(3), 8]
+    assert [v.flags for v in p.tune_candidates(65536, 4096)] == [0, 8, IO, F.C.FZ_VF_WAVES(3), 8]      # (the lone wave with 16- and 24-row chunks, one I/O wave, a packed pair per wave)
     assert sum(len(p.tune_candidates(n, 4096, t)) for n in (16384, 65536, 1 << 20) for t in (0, 8192)) <= 26
     q = F.compile(F.from_sexpr(G.df1_cascade(8)))
     assert q.kernel_name(None, 16384, 4096) == "fz_block_kernel_p1u32b64w4f3072" and "#define FZ_WS_W 4" in q.source(F.make_variant(1, 16, 0, F.C.FZ_VF_WAVES(4)))

@@ -311,8 +311,10 @@ Variant resolve_variant(const Graph& g, const fz_variant* uv, uint64_t n_streams
       // one wave per SIMD (config 2: 65 536 streams): the stage-packed wave next to a loader and a storer.  Round 6, paired bursts on four boards:
       // ahead of the lone stage-packed wave in 8 of 8 comparisons on tiles (+0.3 ... +3.1 %) and 6 of 8 on rows (-0.8 ... +4.4 %, mean +1.6 %:
       // 0.682-0.699 against 0.654-0.701), and the most frugal arrangement sustained (0.541 J per launch: profiles/r06/config2_floor.txt)
-      // -- where four tuples fit a workgroup's LDS (and its registers: finalize_variant checks after the build)
-      if (n_streams > 32768 && n_streams <= 65536 && g.wave_roles(1)) {
+      // -- where four tuples fit a workgroup's LDS (and its registers: finalize_variant checks after the build), for graphs the lone wave does not spend all
+      // its time on arithmetic with (two boards: cascades of 2 / 4 / 6 stages +5-8 / +5 / +0-4 %, the cascade with a gain behind it +22 %, 40 960 streams +6 %,
+      // the oscillator chain level; 8 stages -1 ... -2 %, 10 level: profiles/r06/config2_io_waves_default.txt)
+      if (n_streams > 32768 && n_streams <= 65536 && g.n_ops <= 64 && g.wave_roles(1)) {
          fz_variant q{1, rq.U ? rq.U : 16u, 0, v.flags | FZ_VF_IO_WAVE | FZ_VF_IO_WAVE2};
          const Variant r = resolve_variant(g, &q, n_streams, n_samples, tile_streams, allow_lockstep);
          if (r.block == 256) return r;
