@@ -893,10 +893,62 @@ def test_io_wave_with_per_stream_coefficients(torch_cuda, F):
     P = W.osc_chain_params(SEED + 3, np.arange(ns))
     x = np.zeros((333, ns, 1), np.float32)
     x[0] = 1.0
-    got, st = run_gpu(torch_cuda, F, prog, x, params=P, variant=F.make_variant(1, 16, 0, F.C.FZ_VF_IO_WAVE))
-    assert ndiff(got, C.osc_chain(P, x)) == 0
     ref, st_ref = run_gpu(torch_cuda, F, prog, x, params=P, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
-    assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0
+    for io in (F.C.FZ_VF_IO_WAVE, F.C.FZ_VF_IO_WAVE | F.C.FZ_VF_IO_WAVE2):        # one I/O wave; a loader and a storer
+        got, st = run_gpu(torch_cuda, F, prog, x, params=P, variant=F.make_variant(1, 16, 0, io))
+        assert ndiff(got, C.osc_chain(P, x)) == 0
+        assert ndiff(st.cpu().numpy(), st_ref.cpu().numpy()) == 0
+
+
+def test_two_io_waves_are_the_default_between_32768_and_65536_streams(torch_cuda, F):
+    """Round 6: from 32 769 to 65 536 streams (at most one wave per SIMD of work) a stage-packable graph of <= 64 operations runs as ONE compute wave per 64
+    streams next to a loader and a storer wave (ahead of the lone wave in paired bursts on four boards: profiles/r06/config2_io_waves_default.txt).  The
+    library's default by name on rows and tiles; a stream count that fills neither the last wave nor the last workgroup; two chained blocks and a window
+    of longer buffers; the oscillator chain with its per-stream coefficients: sampled streams against the oracle, everything against the lone wave."""
+    torch = torch_cuda
+    IO2 = F.C.FZ_VF_IO_WAVE | F.C.FZ_VF_IO_WAVE2
+    g = G.df1_cascade(6)
+    prog = F.compile(F.from_sexpr(g))
+    ns, T = 40000 + 37, 1100
+    assert prog.kernel_name(None, ns, T) == "fz_block_kernel_p1u16b256w1io2f%dM" % IO2 and prog.kernel_name(None, 65536, 4096, 8192) == "fz_block_kernel_p1u16b256w1io2f%d" % IO2
+    lone = F.make_variant(1, 16, 0, F.C.FZ_VF_STAGE_PACK)
+    x = torch.empty((T, ns, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(x, SEED + 93)
+    y1, st1 = prog.run_block(x[:600].contiguous())
+    y2, st2 = prog.run_block(x[600:].contiguous(), state=st1.clone())
+    r1, sr1 = prog.run_block(x[:600].contiguous(), variant=lone)
+    r2, sr2 = prog.run_block(x[600:].contiguous(), state=sr1.clone(), variant=lone)
+    assert torch.equal(y1, r1) and torch.equal(y2, r2) and torch.equal(st1, sr1) and torch.equal(st2, sr2)
+    ids = np.concatenate([np.arange(3), np.random.default_rng(3).integers(0, ns, 90), np.arange(ns - 40, ns)])
+    want = C.df1_cascade([G.STABLE] * 6, O.synth_input(SEED + 93, ids, T))
+    assert ndiff(torch.cat([y1, y2])[:, torch.as_tensor(ids, device="cuda")].cpu().numpy(), want) == 0
+    # a window of the same buffers (rows 300 .. 899), state carried from a block over the rows before it
+    out = torch.zeros_like(x)
+    st = torch.zeros((prog.n_state, ns), device="cuda")
+    prog.run_window(x, out, st, 0, 300)
+    prog.run_window(x, out, st, 300, 600)
+    assert torch.equal(out[:900], torch.cat([y1, y2])[:900])
+    # tiles
+    nt, tile = 65536, 8192
+    xt = torch.empty((nt // tile, 700, tile, 1), dtype=torch.float32, device="cuda")
+    F.synth_fill(xt, SEED + 94)
+    yt, stt = prog.run_block(xt)
+    rt, srt = prog.run_block(xt, variant=lone)
+    assert torch.equal(yt, rt) and torch.equal(stt, srt)
+    # per-stream coefficients ride along (config 4's graph at 50 000 streams)
+    po = F.compile(F.from_sexpr(G.osc_chain(6)))
+    no = 50000
+    assert po.kernel_name(None, no, 1024).startswith("fz_block_kernel_p1u16b256w1io2f")
+    params = torch.from_numpy(W.osc_chain_params(SEED + 1, np.arange(no))).cuda()
+    xo = torch.zeros((1024, no, 1), dtype=torch.float32, device="cuda")
+    xo[0].fill_(1.0)
+    a, sa = po.run_block(xo, params=params)
+    b, sb = po.run_block(xo, params=params, variant=F.make_variant(1, 8, 256, NO_STAGE_PACK))
+    assert torch.equal(a, b) and torch.equal(sa, sb)
+    io = np.array([0, 1, 777, no - 1])
+    xh = np.zeros((1024, len(io), 1), np.float32)
+    xh[0] = 1.0
+    assert ndiff(a[:, torch.as_tensor(io, device="cuda")].cpu().numpy(), C.osc_chain(np.ascontiguousarray(W.osc_chain_params(SEED + 1, io)), xh)) == 0
 
 
 @pytest.mark.parametrize("seed", range(24))
