@@ -267,7 +267,8 @@ enum { FZ_VF_STAGE_PACK = 8u,   /* one stream per lane; the K isomorphic segment
        FZ_VF_GRID_SYNC = 8388608u, /* with FZ_VF_LOCKSTEP: the workgroups of one XCD (one contiguous 1/8 of every row) also walk the rows together:
                                    arrival counters in device memory (zeroed in stream order before the launch), bounded waits -- never a
                                    hang, never a different bit; chosen automatically when the chip holds all workgroups at once      */
-       FZ_VF_IO_WAVE2 = 33554432u, /* with FZ_VF_IO_WAVE: TWO I/O waves per tuple -- one loads the input rows, one stores the output rows.  A wave
+       FZ_VF_IO_WAVE2 = 33554432u, /* with FZ_VF_IO_WAVE: TWO I/O waves per tuple -- one loads the input rows, one stores the output rows (chosen automatically for
+                                   stage-packable graphs of <= 64 operations between 32 768 and 65 536 streams: one compute wave per SIMD next to them).  A wave
                                    issues its vector-memory instructions in order, one row of 64 streams x 4 bytes each: at one I/O wave per
                                    tuple that wave's 2 x n_samples instructions are what a round waits for (profiles/r04/few_streams_floor.txt) */
        FZ_VF_OUT_F64 = 64u };   /* `out` holds float64 frames [..][n_out] of doubles (pass the double* cast to
