@@ -212,6 +212,29 @@ def cpu_baseline(n_samples, seed, coefs):
             "note": "same arithmetic per stream, SoA state, compiler-vectorised (stronger than the reference's scalar closure)"}
     except Exception as e:                                  # never let the extra figure break the bench line
         base["vectorised_across_streams"] = {"error": str(e)[:200]}
+    # The reference's OWN code next to the port, one thread: six of its hand-written DF1 closures in series (test/benchmark.cpp:35-47, its coefficients :18-23),
+    # compiled from the reference sources by oracle/build_ref.sh into oracle/_ref/ (the checker's library: it travels with the tree, the sources do not).
+    # Not the compile()-callable either -- that needs Boost -- but reference code: it shows what the port's single-thread figure is worth.
+    try:
+        import ctypes
+        so = os.path.join(ROOT, "oracle", "_ref", "libzignal_ref.so")
+        if os.path.exists(so):
+            ref = ctypes.CDLL(so)
+            ref.zref_df1x6.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+            xr = np.ascontiguousarray(x0[:, :, 0] * np.float32(1e-3))                # [64 streams][n_samples]; small: the reference's coefficient set has a pole at z = -1
+            yr = np.zeros_like(xr)
+            run = lambda: [ref.zref_df1x6(xr[s].ctypes.data, yr[s].ctypes.data, n_samples) for s in range(xr.shape[0])]   # noqa: E731
+            run()
+            t0, n = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 0.5:
+                run()
+                n += 1
+            base["reference_code_single_thread"] = {
+                "value": round(n * xr.shape[0] * n_samples / (time.perf_counter() - t0) / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                "what": "six of the reference's hand-written DF1 closures in series (test/benchmark.cpp:35-47 built by oracle/build_ref.sh), one call per sample; "
+                        "the port's single-thread figure is single_thread_calibration_Msamples_per_s"}
+    except Exception as e:
+        base["reference_code_single_thread"] = {"error": str(e)[:200]}
     return base
 
 # ---- GPU side helpers ----------------------------------------------------------------------------------------------
@@ -427,6 +450,9 @@ def compact_line(full, details_path=None):
         v = cb.get("vectorised_across_streams") or {}
         if "value" in v:
             line["cpu_baseline"]["vectorised_across_streams"] = v["value"]
+        r1 = cb.get("reference_code_single_thread") or {}
+        if "value" in r1:                                       # one thread each: the reference's own DF1 closures x 6 against the port
+            line["cpu_baseline"]["one_thread_reference_code_vs_port"] = [r1["value"], cb.get("single_thread_calibration_Msamples_per_s")]
     for k in ("parity", "checksum", "rccl_ranks", "dist_backend", "ms_per_step_per_rank"):
         if k in full:
             line[k] = full[k]

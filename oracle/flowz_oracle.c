@@ -48,11 +48,39 @@ static inline float df1_call(const fzo_coef* c, fzo_df1_state* s, float x0)
 
 /* n_stage x DF1 in series.  coef: [n_stage] uniform, or per-stream when coef_ss != 0
  * (coefficient j of stage k for stream s at coef_ps[(k*5+j)*coef_ss + s]).              */
+/* A closure of the reference is a TYPE: its stages are inlined and their delay lines live in registers (the compile()-callable like the
+ * hand-written lambdas of test/benchmark.cpp:35-47).  A cascade of a depth known at compile time gets the same treatment here -- the
+ * stage loop unrolled, state and coefficients in locals --, so that what bench.py times as the CPU baseline is not held back by a
+ * run-time stage loop over state in memory (round 6: 1.9 x per thread; the arithmetic is df1_call either way).              */
+#define FZO_CASCADE_FIXED(N)                                                                                                  \
+   static void fzo_cascade_##N(const fzo_coef* coef, const float* xp, ptrdiff_t xts, float* yp, ptrdiff_t yts, long T)          \
+   {                                                                                                                          \
+      fzo_df1_state st[N] = {{0}};                                                                                            \
+      fzo_coef c[N];                                                                                                          \
+      for (int k = 0; k < N; ++k) c[k] = coef[k];                                                                             \
+      for (long t = 0; t < T; ++t) {                                                                                          \
+         float v = xp[t * xts];                                                                                               \
+         _Pragma("GCC unroll 8") for (int k = 0; k < N; ++k) v = df1_call(&c[k], &st[k], v);                                 \
+         yp[t * yts] = v;                                                                                                     \
+      }                                                                                                                       \
+   }
+FZO_CASCADE_FIXED(1)
+FZO_CASCADE_FIXED(2)
+FZO_CASCADE_FIXED(4)
+FZO_CASCADE_FIXED(6)
+FZO_CASCADE_FIXED(8)
+
 void fzo_df1_cascade(const fzo_coef* coef, int n_stage,
                      const float* x, ptrdiff_t xss, ptrdiff_t xts,
                      float* y, ptrdiff_t yss, ptrdiff_t yts,
                      long n_streams, long T)
 {
+   void (*fixed)(const fzo_coef*, const float*, ptrdiff_t, float*, ptrdiff_t, long) =
+      n_stage == 6 ? fzo_cascade_6 : n_stage == 1 ? fzo_cascade_1 : n_stage == 2 ? fzo_cascade_2 : n_stage == 4 ? fzo_cascade_4 : n_stage == 8 ? fzo_cascade_8 : 0;
+   if (fixed) {
+      for (long s = 0; s < n_streams; ++s) fixed(coef, x + s * xss, xts, y + s * yss, yts, T);
+      return;
+   }
    for (long s = 0; s < n_streams; ++s) {
       fzo_df1_state st[FZO_MAX_STAGES] = {{0}};
       const float* xp = x + s * xss;
